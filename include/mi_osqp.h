@@ -1,0 +1,207 @@
+/*
+ * mi_osqp.h -- C-ABI of the MI355X-native OSQP ADMM core.
+ *
+ * This is the drop-in boundary for the solver path of ZPP-Robotics/OSQP-Solver:
+ * every entry point names the reference interface it replaces ([REF] = path
+ * under /root/reference, file:line).  The reference reaches its solver only
+ * through class QPSolver ([REF] src/osqp-wrapper.h:12-60), whose four methods
+ * wrap google/osqp-cpp calls; a maintainer binds this library there (see
+ * INTEGRATION.md for the exact stub).
+ *
+ * Conventions
+ *   - plain C, no torch / Eigen types; all arrays caller-owned and copied at
+ *     the call (matches the reference: its OsqpInstance dies at the end of the
+ *     constructor, [REF] src/osqp-wrapper.h:18-31);
+ *   - sparse matrices are CSC with 64-bit indices = Eigen::SparseMatrix<double,
+ *     ColMajor, long long> ([REF] src/utils.h:12);
+ *   - +-1e30 means "unbounded" ([REF] src/constraints/constraints.h:11);
+ *   - every function returns an mi_osqp_error (0 = ok) unless stated; nothing
+ *     aborts and nothing falls back to a CPU solve: without a usable gfx950
+ *     device setup fails with MI_OSQP_ERR_DEVICE.
+ */
+#ifndef MI_OSQP_H
+#define MI_OSQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MI_OSQP_OK = 0,
+  MI_OSQP_ERR_INVALID_DATA = 1,      /* dims, l>u, bad CSC      -> osqp-cpp InvalidArgument */
+  MI_OSQP_ERR_INVALID_SETTINGS = 2,
+  MI_OSQP_ERR_PATTERN_CHANGED = 3,   /* UpdateConstraintMatrix with a new pattern */
+  MI_OSQP_ERR_NONCONVEX = 4,         /* KKT inertia wrong / zero pivot */
+  MI_OSQP_ERR_DEVICE = 5,            /* HIP error or no gfx950 device */
+  MI_OSQP_ERR_NULL = 6,
+  MI_OSQP_ERR_ALLOC = 7
+} mi_osqp_error;
+
+/* exit codes = osqp::OsqpExitCode as consumed by the reference
+ * ([REF] src/utils.h:11; src/gomp-solver.h:40,46-49,68,72,79;
+ *  examples/solver-example.cpp:71,94).  Values follow the osqp-cpp enum order. */
+typedef enum {
+  MI_OSQP_EXIT_OPTIMAL = 0,
+  MI_OSQP_EXIT_PRIMAL_INFEASIBLE = 1,
+  MI_OSQP_EXIT_DUAL_INFEASIBLE = 2,
+  MI_OSQP_EXIT_OPTIMAL_INACCURATE = 3,
+  MI_OSQP_EXIT_PRIMAL_INFEASIBLE_INACCURATE = 4,
+  MI_OSQP_EXIT_DUAL_INFEASIBLE_INACCURATE = 5,
+  MI_OSQP_EXIT_MAX_ITERATIONS = 6,
+  MI_OSQP_EXIT_INTERRUPTED = 7,
+  MI_OSQP_EXIT_TIME_LIMIT_REACHED = 8,
+  MI_OSQP_EXIT_NON_CONVEX = 9,
+  MI_OSQP_EXIT_UNKNOWN = 10
+} mi_osqp_exit_code;
+
+/* OsqpSettings subset that influences the iterates.  The reference sets only
+ * `verbose` ([REF] src/osqp-wrapper.h:26-27), so defaults = osqp 0.6.x defaults. */
+typedef struct {
+  double  rho;                    /* 0.1  */
+  double  sigma;                  /* 1e-6 */
+  int64_t scaling;                /* 10   */
+  int64_t adaptive_rho;           /* 1    */
+  int64_t adaptive_rho_interval;  /* 0 = auto -> 4*check_termination (deterministic) */
+  double  adaptive_rho_tolerance; /* 5    */
+  int64_t max_iter;               /* 4000 */
+  double  eps_abs;                /* 1e-3 */
+  double  eps_rel;                /* 1e-3 */
+  double  eps_prim_inf;           /* 1e-4 */
+  double  eps_dual_inf;           /* 1e-4 */
+  double  alpha;                  /* 1.6  */
+  int64_t scaled_termination;     /* 0    */
+  int64_t check_termination;      /* 25   */
+  int64_t warm_start;             /* 1    */
+  int64_t verbose;                /* 0 here; the reference passes 1 (log only) */
+} mi_osqp_settings;
+
+typedef struct {
+  int64_t iter;
+  int64_t status_val;   /* raw osqp status (1 solved, -2 max iter, ...) */
+  int64_t exit_code;    /* mi_osqp_exit_code */
+  double  obj_val;
+  double  pri_res;
+  double  dua_res;
+  int64_t rho_updates;
+  double  rho_estimate;
+  double  rho;
+} mi_osqp_info;
+
+/* analysis / schedule statistics (DESIGN.md quotes these) */
+typedef struct {
+  int64_t n, m, N, batch, tile, n_tiles;
+  int64_t nnz_P_triu, nnz_A, nnz_KKT, nnz_L;
+  int64_t n_supernodes, n_blocks;
+  int64_t fwd_levels, bwd_levels, fwd_slots, bwd_slots, chk_slots;
+  int64_t lds_bytes, threads_per_block;
+  double  setup_seconds_host, setup_seconds_factor, setup_seconds_upload;
+} mi_osqp_stats;
+
+typedef struct mi_osqp_solver mi_osqp_solver; /* one QP  */
+typedef struct mi_osqp_batch  mi_osqp_batch;  /* B QPs, ONE shared sparsity pattern */
+
+void        mi_osqp_default_settings(mi_osqp_settings *s);
+const char *mi_osqp_exit_code_name(int64_t exit_code);  /* replaces osqp::ToString(OsqpExitCode) */
+const char *mi_osqp_error_name(int64_t err);
+const char *mi_osqp_version(void);
+const char *mi_osqp_last_error(void);   /* text of the last MI_OSQP_ERR_DEVICE / _ALLOC on this thread */
+
+/* ------------------------------------------------------------------ single QP
+ * Replaces QPSolver::QPSolver(const QPConstraints&, const QPMatrixSparse&)
+ * = OsqpSolver::Init ([REF] src/osqp-wrapper.h:16-31).  P may hold both
+ * triangles (the reference's triDiagonalMatrix does, [REF] src/utils.h:53-61);
+ * the upper one is used.  q may be NULL (= 0, [REF] src/osqp-wrapper.h:22). */
+int mi_osqp_setup(mi_osqp_solver **out, int64_t n, int64_t m,
+                  const int64_t *P_colptr, const int64_t *P_rowidx, const double *P_val,
+                  const double *q,
+                  const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                  const double *l, const double *u, const mi_osqp_settings *settings);
+/* QPSolver::update, first half = OsqpSolver::UpdateConstraintMatrix
+ * ([REF] src/osqp-wrapper.h:36): same pattern required. */
+int mi_osqp_update_A(mi_osqp_solver *h, const int64_t *A_colptr, const int64_t *A_rowidx,
+                     const double *A_val);
+/* QPSolver::update, second half = OsqpSolver::SetBounds ([REF] src/osqp-wrapper.h:40). */
+int mi_osqp_update_bounds(mi_osqp_solver *h, const double *l, const double *u);
+/* QPSolver::setWarmStart = SetPrimalWarmStart ([REF] src/osqp-wrapper.h:45-49). */
+int mi_osqp_warm_start_x(mi_osqp_solver *h, const double *x);
+/* QPSolver::solve = Solve ([REF] src/osqp-wrapper.h:52); returns error code,
+ * exit code and residuals in *info (may be NULL). */
+int mi_osqp_solve(mi_osqp_solver *h, mi_osqp_info *info);
+/* primal_solution() ([REF] src/osqp-wrapper.h:53) / dual_solution(); NaN-filled
+ * when the exit code carries no solution. */
+int mi_osqp_get_primal(mi_osqp_solver *h, double *x_out);
+int mi_osqp_get_dual(mi_osqp_solver *h, double *y_out);
+int mi_osqp_get_stats(mi_osqp_solver *h, mi_osqp_stats *st);
+void mi_osqp_free(mi_osqp_solver *h);
+
+/* --------------------------------------------------------------------- batch
+ * B independent QPs sharing ONE sparsity pattern (the GOMP situation: the
+ * reference keeps A's pattern constant on purpose, [REF]
+ * src/constraints/constraint-builder.h:112-116).  Values/bounds are QP-major:
+ * P_val[B][nnzP], q[B][n] (or NULL), A_val[B][nnzA], l/u[B][m].
+ * device < 0 selects the current HIP device. */
+int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m,
+                        const int64_t *P_colptr, const int64_t *P_rowidx, const double *P_val,
+                        const double *q,
+                        const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                        const double *l, const double *u, const mi_osqp_settings *settings,
+                        int64_t device);
+int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *A_colptr, const int64_t *A_rowidx,
+                           const double *A_val);
+int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u);
+int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x);
+/* Blocking solve of all B QPs (the ADMM iterate runs on the GPU). */
+int mi_osqp_batch_solve(mi_osqp_batch *h);
+int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x_out /*[B][n]*/);
+int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y_out /*[B][m]*/);
+int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info /*[B]*/);
+int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st);
+void mi_osqp_batch_free(mi_osqp_batch *h);
+
+/* Device-resident I/O (HBM pointers on the solver's device; `stream` is a
+ * hipStream_t passed as void*, NULL = default stream).
+ * d_l/d_u: [B][m] doubles, unscaled; the E-scaling and the constraint-type
+ * check run on the device (no refactor happens unless a type changes, in which
+ * case the call returns through the host path transparently). */
+int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream);
+/* Solve and leave x[B][n] (and optionally status[B]/iters[B], int32) in HBM. */
+int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream);
+/* Benchmark helper: cold-start every QP and restore rho and the factor that
+ * setup produced, so that repeated solves do identical work. */
+int mi_osqp_batch_reset(mi_osqp_batch *h);
+/* Totals of the last solve: ADMM iterations summed over QPs, launches, seconds
+ * spent in the device iterate and in host refactorisations. */
+int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64_t *kernel_launches,
+                                   double *device_seconds, double *refactor_seconds, int64_t *refactor_count);
+
+/* ------------------------------------------------- the path's kernels as ops
+ * (parity tests and roofline measurements call these; all pointers HBM)
+ * KKT-structured SpMV on the scaled data: from x[B][n], y[B][m] compute
+ * Px[B][n], Aty[B][n], Ax[B][m]  (rows E11/E14 of SURVEY 8(a)). */
+int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y,
+                       double *d_Px, double *d_Aty, double *d_Ax, void *stream);
+/* One KKT solve per QP with the current factor: sol = K^-1 rhs, [B][n+m]
+ * (row E7: permute, level-scheduled L solve, D^-1, L' solve, un-permute). */
+int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol, void *stream);
+/* average duration (ms) of the last `iterate` launches measured with HIP events
+ * on the launch stream, and their count (bench.py's roofline leg). */
+int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launches);
+
+/* --------------------------------------------------- host-only diagnostics
+ * No GPU needed: analyse a pattern + one value set and replay the DEVICE
+ * schedules on the host (a sequential interpreter of the same task tables) so
+ * that the schedule builder is testable in CPU-only CI.  Not a solve path. */
+int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m,
+                                 const int64_t *P_colptr, const int64_t *P_rowidx, const double *P_val,
+                                 const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                                 const double *l, const double *u, const mi_osqp_settings *settings,
+                                 int64_t tile, const double *rhs /*[n+m], scaled space*/,
+                                 double *sol_schedule /*[n+m]*/, double *sol_direct /*[n+m]*/,
+                                 mi_osqp_stats *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_OSQP_H */

@@ -1,0 +1,305 @@
+"""osqp-solver_amd -- MI355X-native OSQP ADMM core behind the reference's QPSolver API.
+
+Python here is only the test/bench harness language (the reference is C++; its
+drop-in is include/mi_osqp.h + include/mi_osqp/qp_solver.hpp).  This module is
+a ctypes binding of the C-ABI; it never computes anything itself and never
+touches oracle/.  If libmi_osqp.so cannot be built/loaded, import fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXIT_NAMES = ["kOptimal", "kPrimalInfeasible", "kDualInfeasible", "kOptimalInaccurate",
+              "kPrimalInfeasibleInaccurate", "kDualInfeasibleInaccurate", "kMaxIterations",
+              "kInterrupted", "kTimeLimitReached", "kNonConvex", "kUnknown"]
+K_OPTIMAL = 0
+
+
+class Settings(C.Structure):
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("scaling", C.c_int64),
+                ("adaptive_rho", C.c_int64), ("adaptive_rho_interval", C.c_int64),
+                ("adaptive_rho_tolerance", C.c_double), ("max_iter", C.c_int64),
+                ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("eps_prim_inf", C.c_double),
+                ("eps_dual_inf", C.c_double), ("alpha", C.c_double), ("scaled_termination", C.c_int64),
+                ("check_termination", C.c_int64), ("warm_start", C.c_int64), ("verbose", C.c_int64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("iter", C.c_int64), ("status_val", C.c_int64), ("exit_code", C.c_int64),
+                ("obj_val", C.c_double), ("pri_res", C.c_double), ("dua_res", C.c_double),
+                ("rho_updates", C.c_int64), ("rho_estimate", C.c_double), ("rho", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in
+                ("n", "m", "N", "batch", "tile", "n_tiles", "nnz_P_triu", "nnz_A", "nnz_KKT", "nnz_L",
+                 "n_supernodes", "n_blocks", "fwd_levels", "bwd_levels", "fwd_slots", "bwd_slots",
+                 "chk_slots", "lds_bytes", "threads_per_block")] + \
+               [(k, C.c_double) for k in ("setup_seconds_host", "setup_seconds_factor", "setup_seconds_upload")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class MiOsqpError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = int(code)
+        L = lib()
+        msg = L.mi_osqp_error_name(int(code)).decode()
+        extra = L.mi_osqp_last_error().decode()
+        super().__init__(f"{where}: error {int(code)} ({msg}) {extra}")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmi_osqp.so")
+        try:
+            path = _build.build()
+        except Exception as e:  # hipcc missing on this machine: use the shipped .so or fail
+            if not os.path.exists(path):
+                raise ImportError(f"libmi_osqp.so missing and could not be built: {e}") from e
+        L = C.CDLL(path)
+        ip, dp, vp = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
+        L.mi_osqp_default_settings.argtypes = [C.POINTER(Settings)]
+        for f in ("mi_osqp_exit_code_name", "mi_osqp_error_name"):
+            getattr(L, f).restype = C.c_char_p; getattr(L, f).argtypes = [C.c_int64]
+        L.mi_osqp_version.restype = C.c_char_p
+        L.mi_osqp_last_error.restype = C.c_char_p
+        L.mi_osqp_batch_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, ip, ip, dp, dp, ip, ip, dp,
+                                          dp, dp, C.POINTER(Settings), C.c_int64]
+        L.mi_osqp_batch_update_A.argtypes = [vp, ip, ip, dp]
+        L.mi_osqp_batch_update_bounds.argtypes = [vp, dp, dp]
+        L.mi_osqp_batch_warm_start_x.argtypes = [vp, dp]
+        L.mi_osqp_batch_solve.argtypes = [vp]
+        L.mi_osqp_batch_get_primal.argtypes = [vp, dp]
+        L.mi_osqp_batch_get_dual.argtypes = [vp, dp]
+        L.mi_osqp_batch_get_info.argtypes = [vp, C.POINTER(Info)]
+        L.mi_osqp_batch_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mi_osqp_batch_free.argtypes = [vp]; L.mi_osqp_batch_free.restype = None
+        L.mi_osqp_batch_update_bounds_device.argtypes = [vp, vp, vp, vp]
+        L.mi_osqp_batch_solve_device.argtypes = [vp, vp, vp, vp, vp]
+        L.mi_osqp_batch_reset.argtypes = [vp]
+        L.mi_osqp_batch_last_solve_stats.argtypes = [vp, ip, ip, dp, dp, ip]
+        L.mi_osqp_batch_spmv.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.mi_osqp_batch_kkt_solve.argtypes = [vp, vp, vp, vp]
+        L.mi_osqp_batch_kernel_time.argtypes = [vp, dp, ip]
+        L.mi_osqp_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, ip, ip, dp, dp, ip, ip, dp, dp, dp, C.POINTER(Settings)]
+        L.mi_osqp_update_A.argtypes = [vp, ip, ip, dp]
+        L.mi_osqp_update_bounds.argtypes = [vp, dp, dp]
+        L.mi_osqp_warm_start_x.argtypes = [vp, dp]
+        L.mi_osqp_solve.argtypes = [vp, C.POINTER(Info)]
+        L.mi_osqp_get_primal.argtypes = [vp, dp]
+        L.mi_osqp_get_dual.argtypes = [vp, dp]
+        L.mi_osqp_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mi_osqp_free.argtypes = [vp]; L.mi_osqp_free.restype = None
+        L.mi_osqp_debug_host_kkt_solve.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
+                                                   C.POINTER(Settings), C.c_int64, dp, dp, dp, C.POINTER(Stats)]
+        _LIB = L
+    return _LIB
+
+
+def default_settings(**kw):
+    s = Settings()
+    lib().mi_osqp_default_settings(C.byref(s))
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise KeyError(k)
+        setattr(s, k, v)
+    return s
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise MiOsqpError(rc, where)
+
+
+def _csc(M):
+    import scipy.sparse as sp
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    return M
+
+
+class BatchSolver:
+    """B QPs with one shared sparsity pattern (P_pattern / A_pattern are scipy
+    sparse matrices carrying the pattern; Px[B,nnzP], Ax[B,nnzA] the per-QP values
+    in CSC order of those patterns)."""
+
+    def __init__(self, P_pattern, Px, q, A_pattern, Ax, l, u, device=-1, **settings):
+        L = lib()
+        P, A = _csc(P_pattern), _csc(A_pattern)
+        self.n, self.m = A.shape[1], A.shape[0]
+        Px, Ax, l, u = _f64(Px), _f64(Ax), _f64(l), _f64(u)
+        if Ax.ndim == 1:
+            Px, Ax, l, u = Px[None], Ax[None], l[None], u[None]
+            q = None if q is None else _f64(q)[None]
+        self.B = Ax.shape[0]
+        q = None if q is None else _f64(q)
+        self._Pp, self._Pi = _i64(P.indptr), _i64(P.indices)
+        self._Ap, self._Ai = _i64(A.indptr), _i64(A.indices)
+        self.settings = default_settings(**settings)
+        self._h = C.c_void_p()
+        rc = L.mi_osqp_batch_setup(C.byref(self._h), self.B, self.n, self.m, _ip(self._Pp), _ip(self._Pi), _dp(Px),
+                                   _dp(q), _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(l), _dp(u),
+                                   C.byref(self.settings), device)
+        _chk(rc, "mi_osqp_batch_setup")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().mi_osqp_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    close = __del__
+
+    def solve(self):
+        _chk(lib().mi_osqp_batch_solve(self._h), "mi_osqp_batch_solve")
+        return self.info()
+
+    def primal(self):
+        x = np.empty((self.B, self.n))
+        _chk(lib().mi_osqp_batch_get_primal(self._h, _dp(x)), "get_primal")
+        return x
+
+    def dual(self):
+        y = np.empty((self.B, self.m))
+        _chk(lib().mi_osqp_batch_get_dual(self._h, _dp(y)), "get_dual")
+        return y
+
+    def info(self):
+        arr = (Info * self.B)()
+        _chk(lib().mi_osqp_batch_get_info(self._h, arr), "get_info")
+        return list(arr)
+
+    def stats(self):
+        s = Stats()
+        _chk(lib().mi_osqp_batch_get_stats(self._h, C.byref(s)), "get_stats")
+        return s.as_dict()
+
+    def update_A(self, Ax, A_pattern=None):
+        Ax = _f64(Ax).reshape(self.B, -1)
+        Ap, Ai = self._Ap, self._Ai
+        if A_pattern is not None:
+            A = _csc(A_pattern)
+            Ap, Ai = _i64(A.indptr), _i64(A.indices)
+            if len(Ai) != len(self._Ai):
+                raise MiOsqpError(3, "update_A")
+        _chk(lib().mi_osqp_batch_update_A(self._h, _ip(Ap), _ip(Ai), _dp(Ax)), "update_A")
+
+    def update_bounds(self, l, u):
+        l, u = _f64(l).reshape(self.B, -1), _f64(u).reshape(self.B, -1)
+        _chk(lib().mi_osqp_batch_update_bounds(self._h, _dp(l), _dp(u)), "update_bounds")
+
+    def warm_start_x(self, x):
+        x = _f64(x).reshape(self.B, -1)
+        _chk(lib().mi_osqp_batch_warm_start_x(self._h, _dp(x)), "warm_start_x")
+
+    def reset(self):
+        _chk(lib().mi_osqp_batch_reset(self._h), "reset")
+
+    def last_solve_stats(self):
+        it, ln, rc = C.c_int64(), C.c_int64(), C.c_int64()
+        ds, rs = C.c_double(), C.c_double()
+        _chk(lib().mi_osqp_batch_last_solve_stats(self._h, C.byref(it), C.byref(ln), C.byref(ds), C.byref(rs), C.byref(rc)), "stats")
+        return dict(total_iters=it.value, launches=ln.value, device_s=ds.value, refactor_s=rs.value, refactors=rc.value)
+
+    def kernel_time(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        _chk(lib().mi_osqp_batch_kernel_time(self._h, C.byref(ms), C.byref(cnt)), "kernel_time")
+        return ms.value, cnt.value
+
+    # ---- device-resident variants (torch tensors on the solver's GPU)
+    def solve_device(self, x_out=None, status=None, iters=None, stream=None):
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _chk(lib().mi_osqp_batch_solve_device(self._h, p(x_out), p(status), p(iters),
+                                              None if stream is None else C.c_void_p(stream)), "solve_device")
+
+    def update_bounds_device(self, l, u, stream=None):
+        _chk(lib().mi_osqp_batch_update_bounds_device(self._h, C.c_void_p(l.data_ptr()), C.c_void_p(u.data_ptr()),
+                                                      None if stream is None else C.c_void_p(stream)), "update_bounds_device")
+
+    def spmv_device(self, x, y, Px, Aty, Ax, stream=None):
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _chk(lib().mi_osqp_batch_spmv(self._h, p(x), p(y), p(Px), p(Aty), p(Ax),
+                                      None if stream is None else C.c_void_p(stream)), "spmv")
+
+    def kkt_solve_device(self, rhs, sol, stream=None):
+        _chk(lib().mi_osqp_batch_kkt_solve(self._h, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()),
+                                           None if stream is None else C.c_void_p(stream)), "kkt_solve")
+
+
+class QPSolver:
+    """Python twin of the reference class QPSolver
+    ([REF] /root/reference/src/osqp-wrapper.h:12-60): ctor(constraints, P),
+    update(constraints), setWarmStart(x), solve() -> (exit_code, x).
+    `constraints` = (l, A, u) like the reference's QPConstraints tuple."""
+
+    def __init__(self, constraints, P, q=None, **settings):
+        l, A, u = constraints
+        self._b = BatchSolver(P, _csc(P).data, q, A, _csc(A).data, l, u, **settings)
+
+    def update(self, constraints):
+        l, A, u = constraints
+        A = _csc(A)
+        try:
+            self._b.update_A(A.data, A_pattern=A)
+            self._b.update_bounds(l, u)
+        except MiOsqpError as e:           # the reference throws std::invalid_argument here
+            raise ValueError(str(e)) from e
+
+    def setWarmStart(self, x):
+        self._b.warm_start_x(x)
+
+    def solve(self):
+        info = self._b.solve()[0]
+        return int(info.exit_code), self._b.primal()[0]
+
+    def info(self):
+        return self._b.info()[0]
+
+    def dual(self):
+        return self._b.dual()[0]
+
+    def stats(self):
+        return self._b.stats()
+
+
+def debug_host_kkt_solve(P, A, l, u, rhs, **settings):
+    """Host-only: factor one QP's KKT and solve K sol = rhs twice -- by replaying
+    the DEVICE schedules sequentially and by a plain CSC solve.  (No GPU.)"""
+    L = lib()
+    P, A = _csc(P), _csc(A)
+    n, m = A.shape[1], A.shape[0]
+    s = default_settings(**settings)
+    rhs = _f64(rhs)
+    sol_s, sol_d = np.empty(n + m), np.empty(n + m)
+    st = Stats()
+    Pp, Pi, Px = _i64(P.indptr), _i64(P.indices), _f64(P.data)
+    Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), _f64(A.data)
+    l, u = _f64(l), _f64(u)
+    rc = L.mi_osqp_debug_host_kkt_solve(n, m, _ip(Pp), _ip(Pi), _dp(Px), _ip(Ap), _ip(Ai), _dp(Ax), _dp(l), _dp(u),
+                                        C.byref(s), 1, _dp(rhs), _dp(sol_s), _dp(sol_d), C.byref(st))
+    _chk(rc, "debug_host_kkt_solve")
+    return sol_s, sol_d, st.as_dict()

@@ -1,0 +1,43 @@
+"""Build the C-ABI shared library (hipcc, gfx950 only) in-tree."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmi_osqp.so")
+SOURCES = ["solver.hip", "kernels.hip", "host_core.cpp"]
+HEADERS = ["device_types.h", "host_core.hpp", os.path.join("..", "..", "include", "mi_osqp.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for f in SOURCES:
+        obj = os.path.join(CSRC, f + ".o")
+        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
+               "-c", os.path.join(CSRC, f), "-o", obj]
+        if f.endswith(".cpp"):
+            cmd.insert(1, "-x"); cmd.insert(2, "c++")
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,55 @@
+// device_types.h -- POD shared by kernels.hip and solver.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace miosqp {
+
+#define MI_CHUNK 16
+
+// device view of one host_core.hpp Schedule (index arrays are shared by all tiles)
+struct SchedDev {
+  const uint32_t *lvl, *taskA, *outA, *taskB, *outB, *idx;
+  int n_levels;
+  uint32_t n_slots;
+};
+
+// per-QP double scalars, laid out [tile][DS_COUNT][BT]
+enum { DS_C = 0, DS_CINV, DS_RHO, DS_RHO_EST, DS_PRI_RES, DS_DUA_RES, DS_OBJ, DS_COUNT };
+// per-QP int scalars, laid out [tile][IS_COUNT][BT]
+enum { IS_STATUS = 0, IS_ITER, IS_RHO_UPDATES, IS_DONE, IS_NEED_REFACTOR, IS_COUNT };
+
+struct KernelArgs {
+  int n, m, N, B;
+  SchedDev fwd, bwd, chk;
+  const uint32_t *pinv;                 // natural index -> position in the permuted LDS vector
+  // tile-interleaved value arrays: [tile][len][BT]
+  const double *fwd_val, *bwd_val, *chk_val, *dinv;
+  double *x, *z, *y;
+  const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
+  double *dx, *dy, *out1, *out2, *dscal;
+  int *iscal, *tile_iter;
+  double *x_out, *y_out;                // QP-major [B][n], [B][m]
+  // settings (row S)
+  double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
+  int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;
+  int iter_budget;
+};
+
+hipError_t launch_admm(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
+hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                       const double *x, const double *y, double *Px, double *Aty, double *Ax);
+hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                            const double *rhs, double *sol);
+hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                             const double *x0);
+hipError_t launch_interleave(const double *src, double *dst, const int *ids, int nq, int len, int BT, hipStream_t st);
+hipError_t launch_scatter(const double *src, double *dst, const int *map, const int *ids, int nq, int srclen,
+                          int slots, int BT, hipStream_t st);
+hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st);
+hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
+hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,
+                         const double *rho_vec, const double *dscal, int *changed, int B, int m, int BT,
+                         int scaling, hipStream_t st);
+
+}  // namespace miosqp

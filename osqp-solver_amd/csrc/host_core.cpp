@@ -1,0 +1,626 @@
+// host_core.cpp -- see host_core.hpp.  Citations: [REF] = /root/reference,
+// "row Ex" = SURVEY.md section 8(a).
+#include "host_core.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/mi_osqp.h"
+
+namespace miosqp {
+
+int validate_settings(const Settings &s) {
+  if (s.scaling < 0 || s.max_iter <= 0 || s.check_termination < 0) return 1;
+  if (s.adaptive_rho != 0 && s.adaptive_rho != 1) return 1;
+  if (s.adaptive_rho_interval < 0 || s.adaptive_rho_tolerance < 1.0) return 1;
+  if (!(s.rho > 0.0) || !(s.sigma > 0.0)) return 1;
+  if (s.eps_abs < 0.0 || s.eps_rel < 0.0 || (s.eps_abs == 0.0 && s.eps_rel == 0.0)) return 1;
+  if (!(s.eps_prim_inf > 0.0) || !(s.eps_dual_inf > 0.0)) return 1;
+  if (!(s.alpha > 0.0) || !(s.alpha < 2.0)) return 1;
+  if ((s.scaled_termination | 1) != 1 || (s.warm_start | 1) != 1) return 1;
+  return 0;
+}
+
+// ------------------------------------------------------------------ ordering
+
+// Minimum-degree ordering on the explicit elimination graph (sorted adjacency
+// vectors; degree buckets).  Plays the part AMD plays upstream (row E5); any
+// permutation yields the same KKT solution up to round-off.
+static void min_degree(int N, const std::vector<int> &Kp, const std::vector<int> &Ki,
+                       std::vector<int> &perm) {
+  std::vector<std::vector<int>> adj(N);
+  for (int j = 0; j < N; j++)
+    for (int k = Kp[j]; k < Kp[j + 1]; k++) {
+      int i = Ki[k];
+      if (i != j) { adj[i].push_back(j); adj[j].push_back(i); }
+    }
+  for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  std::vector<char> dead(N, 0);
+  // bucket lists by degree (lazy: entries may be stale, checked on pop)
+  std::vector<std::vector<int>> bucket(N + 1);
+  for (int v = 0; v < N; v++) bucket[adj[v].size()].push_back(v);
+  for (auto &b : bucket) std::sort(b.begin(), b.end(), std::greater<int>());  // pop_back = smallest index
+  perm.assign(N, 0);
+  std::vector<int> tmp;
+  int alive = N, mind = 0;
+  for (int step = 0; step < N;) {
+    int v = -1;
+    while (true) {
+      while (mind <= N && bucket[mind].empty()) mind++;
+      if (mind > N) break;
+      int cand = bucket[mind].back(); bucket[mind].pop_back();
+      if (!dead[cand] && (int)adj[cand].size() == mind) { v = cand; break; }
+    }
+    if (v < 0) break;
+    if ((int)adj[v].size() == alive - 1) {        // remaining graph is a clique
+      perm[step++] = v; dead[v] = 1;
+      std::vector<int> rest;
+      for (int u = 0; u < N; u++) if (!dead[u]) rest.push_back(u);
+      for (int u : rest) { perm[step++] = u; dead[u] = 1; }
+      break;
+    }
+    perm[step++] = v; dead[v] = 1; alive--;
+    const std::vector<int> S = adj[v];
+    for (int u : S) {
+      tmp.clear();
+      std::set_union(adj[u].begin(), adj[u].end(), S.begin(), S.end(), std::back_inserter(tmp));
+      tmp.erase(std::remove_if(tmp.begin(), tmp.end(), [&](int x) { return x == u || x == v; }), tmp.end());
+      adj[u].swap(tmp);
+      int d = (int)adj[u].size();
+      // keep buckets sorted descending so that pop_back yields the smallest index
+      auto &b = bucket[d];
+      b.insert(std::upper_bound(b.begin(), b.end(), u, std::greater<int>()), u);
+      if (d < mind) mind = d;
+    }
+    std::vector<int>().swap(adj[v]);
+  }
+}
+
+// lower-triangular CSC of the permuted KKT with a natural->permuted entry map
+static void build_permuted_lower(Analysis &an) {
+  int N = an.N, nnz = an.nnzK();
+  std::vector<int> cnt(N + 1, 0);
+  std::vector<int> colOf(nnz), rowOf(nnz);
+  for (int j = 0; j < N; j++)
+    for (int k = an.Kp[j]; k < an.Kp[j + 1]; k++) {
+      int a = an.pinv[an.Ki[k]], b = an.pinv[j];
+      colOf[k] = std::min(a, b); rowOf[k] = std::max(a, b);
+      cnt[colOf[k]]++;
+    }
+  an.Klp.assign(N + 1, 0);
+  for (int j = 0; j < N; j++) an.Klp[j + 1] = an.Klp[j] + cnt[j];
+  // sort entries of each column by row so that symbolic merges see sorted lists
+  std::vector<int> order(nnz);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (colOf[a] != colOf[b]) return colOf[a] < colOf[b];
+    return rowOf[a] < rowOf[b];
+  });
+  an.Kli.assign(nnz, 0); an.KtoKl.assign(nnz, 0);
+  for (int pos = 0; pos < nnz; pos++) { int k = order[pos]; an.Kli[pos] = rowOf[k]; an.KtoKl[k] = pos; }
+}
+
+// column structures of L (sorted) + elimination tree
+static void symbolic(const Analysis &an, std::vector<std::vector<int>> &cols, std::vector<int> &parent) {
+  int N = an.N;
+  cols.assign(N, {});
+  parent.assign(N, -1);
+  std::vector<std::vector<int>> children(N);
+  std::vector<int> tmp;
+  for (int j = 0; j < N; j++) {
+    std::vector<int> &s = cols[j];
+    for (int p = an.Klp[j]; p < an.Klp[j + 1]; p++) if (an.Kli[p] > j) s.push_back(an.Kli[p]);
+    for (int c : children[j]) {
+      tmp.clear();
+      const std::vector<int> &cs = cols[c];
+      // cs[0] == j ; merge the remainder
+      std::set_union(s.begin(), s.end(), cs.begin() + 1, cs.end(), std::back_inserter(tmp));
+      s.swap(tmp);
+    }
+    if (!s.empty()) { parent[j] = s[0]; children[s[0]].push_back(j); }
+  }
+}
+
+static void postorder(const std::vector<int> &parent, std::vector<int> &post) {
+  int N = (int)parent.size();
+  std::vector<std::vector<int>> children(N);
+  std::vector<int> roots;
+  for (int j = 0; j < N; j++) { if (parent[j] >= 0) children[parent[j]].push_back(j); else roots.push_back(j); }
+  post.clear(); post.reserve(N);
+  std::vector<std::pair<int, size_t>> stack;
+  for (int r : roots) {
+    stack.push_back({r, 0});
+    while (!stack.empty()) {
+      auto &[v, ci] = stack.back();
+      if (ci < children[v].size()) { int c = children[v][ci++]; stack.push_back({c, 0}); }
+      else { post.push_back(v); stack.pop_back(); }
+    }
+  }
+}
+
+// ------------------------------------------------------------ schedule packing
+
+namespace {
+struct RowWork { uint32_t row; std::vector<std::pair<uint32_t, int32_t>> ent; };
+struct BlockWork { std::vector<uint32_t> rows; std::vector<int32_t> tri; };  // tri[p*r+i]
+struct LevelWork { std::vector<RowWork> rowsA; std::vector<BlockWork> blocksB; };
+
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+
+void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch) {
+  sch = Schedule();
+  sch.n_levels = (int)levels.size();
+  auto emit = [&](const std::vector<const RowWork *> &rows, int T, int S) {
+    uint32_t base = sch.n_slots;
+    sch.n_slots += 64u * (uint32_t)S;
+    sch.idx.resize(sch.n_slots, 0u);
+    sch.src.resize(sch.n_slots, -1);
+    uint32_t out_base = (uint32_t)sch.outA.size();
+    int per = 64 / T;
+    for (int g = 0; g < per; g++) sch.outA.push_back(g < (int)rows.size() ? rows[g]->row : kNoRow);
+    for (int g = 0; g < (int)rows.size(); g++) {
+      const auto &ent = rows[g]->ent;
+      for (int e = 0; e < (int)ent.size(); e++) {
+        uint32_t slot = base + (uint32_t)(e / T) * 64u + (uint32_t)(g * T + e % T);
+        sch.idx[slot] = ent[e].first; sch.src[slot] = ent[e].second;
+      }
+    }
+    sch.taskA.insert(sch.taskA.end(), {base, (uint32_t)S, (uint32_t)ilog2(T), out_base});
+  };
+  for (const LevelWork &lw : levels) {
+    uint32_t a_begin = (uint32_t)sch.n_taskA();
+    std::vector<const RowWork *> longs;
+    std::vector<std::vector<const RowWork *>> byT(7);
+    for (const RowWork &rw : lw.rowsA) {
+      int len = std::max<int>(1, (int)rw.ent.size());
+      if (len > 64) longs.push_back(&rw);
+      else byT[ilog2(pow2ceil(len))].push_back(&rw);
+    }
+    std::stable_sort(longs.begin(), longs.end(),
+                     [](const RowWork *a, const RowWork *b) { return a->ent.size() > b->ent.size(); });
+    for (const RowWork *rw : longs) emit({rw}, 64, ((int)rw->ent.size() + 63) / 64);
+    for (int lt = 6; lt >= 0; lt--) {
+      int T = 1 << lt, per = 64 / T;
+      const auto &v = byT[lt];
+      for (size_t i = 0; i < v.size(); i += per) {
+        std::vector<const RowWork *> grp(v.begin() + i, v.begin() + std::min(v.size(), i + per));
+        emit(grp, T, 1);
+      }
+    }
+    uint32_t a_end = (uint32_t)sch.n_taskA();
+    uint32_t b_begin = (uint32_t)sch.n_taskB();
+    for (const BlockWork &bw : lw.blocksB) {
+      int r = (int)bw.rows.size();
+      if (r < 2) continue;
+      uint32_t base = sch.n_slots;
+      sch.n_slots += (uint32_t)(kChunk * (r - 1));
+      sch.idx.resize(sch.n_slots, 0u);
+      sch.src.resize(sch.n_slots, -1);
+      for (int p = 0; p < r - 1; p++)
+        for (int i = p + 1; i < r; i++) sch.src[base + p * kChunk + i] = bw.tri[p * r + i];
+      uint32_t out_base = (uint32_t)sch.outB.size();
+      for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < r ? bw.rows[i] : kNoRow);
+      sch.taskB.insert(sch.taskB.end(), {base, (uint32_t)r, out_base, 0u});
+    }
+    uint32_t b_end = (uint32_t)sch.n_taskB();
+    sch.lvl.insert(sch.lvl.end(), {a_begin, a_end, b_begin, b_end});
+  }
+}
+}  // namespace
+
+static void build_tri_schedules(Analysis &an) {
+  int N = an.N;
+  int nch = (int)an.chunk_start.size() - 1;
+  std::vector<int> chunk_of(N);
+  for (int c = 0; c < nch; c++) for (int j = an.chunk_start[c]; j < an.chunk_start[c + 1]; j++) chunk_of[j] = c;
+  // ---- forward: rows ascending, sources are columns j < row
+  {
+    std::vector<int> lev(nch, 0);
+    int maxlev = 0;
+    for (int c = 0; c < nch; c++) {
+      int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], L = 0;
+      for (int i = c0; i < c1; i++)
+        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0) L = std::max(L, lev[chunk_of[j]] + 1); }
+      lev[c] = L; maxlev = std::max(maxlev, L);
+    }
+    std::vector<LevelWork> lw(maxlev + 1);
+    for (int c = 0; c < nch; c++) {
+      int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
+      BlockWork bw;
+      if (r >= 2) { bw.rows.resize(r); bw.tri.assign((size_t)r * r, -1); for (int i = 0; i < r; i++) bw.rows[i] = (uint32_t)(c0 + i); }
+      for (int i = c0; i < c1; i++) {
+        RowWork rw; rw.row = (uint32_t)i;
+        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) {
+          int j = an.Rj[t];
+          if (j < c0) rw.ent.push_back({(uint32_t)j, an.Rpos[t]});
+          else bw.tri[(size_t)(j - c0) * r + (i - c0)] = an.Rpos[t];
+        }
+        if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
+      }
+      if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
+    }
+    pack_schedule(lw, an.fwd);
+  }
+  // ---- backward: columns descending, sources are rows j > column
+  {
+    std::vector<int> lev(nch, 0);
+    int maxlev = 0;
+    for (int c = nch - 1; c >= 0; c--) {
+      int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], L = 0;
+      for (int col = c0; col < c1; col++)
+        for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) { int j = an.Li[p]; if (j >= c1) L = std::max(L, lev[chunk_of[j]] + 1); }
+      lev[c] = L; maxlev = std::max(maxlev, L);
+    }
+    std::vector<LevelWork> lw(maxlev + 1);
+    for (int c = nch - 1; c >= 0; c--) {
+      int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
+      BlockWork bw;
+      if (r >= 2) { bw.rows.resize(r); bw.tri.assign((size_t)r * r, -1); for (int i = 0; i < r; i++) bw.rows[i] = (uint32_t)(c1 - 1 - i); }
+      for (int col = c1 - 1; col >= c0; col--) {
+        RowWork rw; rw.row = (uint32_t)col;
+        for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
+          int j = an.Li[p];
+          if (j >= c1) rw.ent.push_back({(uint32_t)j, p});
+          else bw.tri[(size_t)(c1 - 1 - j) * r + (c1 - 1 - col)] = p;
+        }
+        if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
+      }
+      if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
+    }
+    pack_schedule(lw, an.bwd);
+  }
+}
+
+// check-SpMV: rows 0..n-1 = P x, n..2n-1 = A' y, 2n..2n+m-1 = A x; gather vector
+// is [x ; y]; values come from the combined array [P triu | A].
+static void build_chk_schedule(Analysis &an) {
+  int n = an.n, m = an.m, nnzP = an.Pp[n];
+  std::vector<LevelWork> lw(3);
+  std::vector<RowWork> px(n), aty(n), ax(m);
+  for (int i = 0; i < n; i++) { px[i].row = (uint32_t)i; aty[i].row = (uint32_t)(n + i); }
+  for (int r = 0; r < m; r++) ax[r].row = (uint32_t)(2 * n + r);
+  for (int c = 0; c < n; c++)
+    for (int k = an.Pp[c]; k < an.Pp[c + 1]; k++) {
+      int r = an.Pi[k];
+      px[r].ent.push_back({(uint32_t)c, k});
+      if (r != c) px[c].ent.push_back({(uint32_t)r, k});
+    }
+  for (int c = 0; c < n; c++)
+    for (int k = an.Ap[c]; k < an.Ap[c + 1]; k++) {
+      int r = an.Ai[k];
+      aty[c].ent.push_back({(uint32_t)(n + r), nnzP + k});
+      ax[r].ent.push_back({(uint32_t)c, nnzP + k});
+    }
+  lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
+  pack_schedule(lw, an.chk);
+}
+
+// --------------------------------------------------------------------- analyze
+
+int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
+            const int64_t *Ai, Analysis &an) {
+  if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
+  int n = (int)n64, m = (int)m64, N = n + m;
+  an = Analysis();
+  an.n = n; an.m = m; an.N = N;
+  if (Pp[0] != 0 || Ap[0] != 0) return MI_OSQP_ERR_INVALID_DATA;
+  for (int j = 0; j < n; j++) {
+    if (Pp[j + 1] < Pp[j] || Ap[j + 1] < Ap[j]) return MI_OSQP_ERR_INVALID_DATA;
+    for (int64_t k = Pp[j]; k < Pp[j + 1]; k++) if (Pi[k] < 0 || Pi[k] >= n) return MI_OSQP_ERR_INVALID_DATA;
+    for (int64_t k = Ap[j]; k < Ap[j + 1]; k++) if (Ai[k] < 0 || Ai[k] >= m) return MI_OSQP_ERR_INVALID_DATA;
+  }
+  if (Pp[n] > (int64_t)1 << 30 || Ap[n] > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
+  // triu(P)
+  an.Pp.assign(n + 1, 0);
+  for (int j = 0; j < n; j++) {
+    an.Pp[j] = (int)an.Pi.size();
+    for (int64_t k = Pp[j]; k < Pp[j + 1]; k++)
+      if (Pi[k] <= j) { an.Pi.push_back((int)Pi[k]); an.Psrc.push_back((int)k); }
+  }
+  an.Pp[n] = (int)an.Pi.size();
+  an.Ap.assign(Ap, Ap + n + 1);
+  an.Ai.assign(Ai, Ai + Ap[n]);
+  // ---- natural upper KKT (row E4)
+  int nnzP = an.Pp[n], nnzA = an.Ap[n];
+  std::vector<int> cnt(N, 0);
+  an.PisDiag.assign(nnzP, 0);
+  std::vector<char> hasDiag(n, 0);
+  for (int j = 0; j < n; j++)
+    for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) { cnt[j]++; if (an.Pi[k] == j) { hasDiag[j] = 1; an.PisDiag[k] = 1; } }
+  for (int j = 0; j < n; j++) if (!hasDiag[j]) cnt[j]++;
+  for (int k = 0; k < nnzA; k++) cnt[n + an.Ai[k]]++;
+  for (int r = 0; r < m; r++) cnt[n + r]++;
+  an.Kp.assign(N + 1, 0);
+  for (int j = 0; j < N; j++) an.Kp[j + 1] = an.Kp[j] + cnt[j];
+  an.Ki.assign(an.Kp[N], 0);
+  an.PtoK.assign(nnzP, 0); an.AtoK.assign(nnzA, 0); an.rhotoK.assign(m, 0);
+  std::vector<int> nxt(an.Kp.begin(), an.Kp.end() - 1);
+  for (int j = 0; j < n; j++) {
+    for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) { int pos = nxt[j]++; an.Ki[pos] = an.Pi[k]; an.PtoK[k] = pos; }
+    if (!hasDiag[j]) { int pos = nxt[j]++; an.Ki[pos] = j; an.sigmaOnlyK.push_back(pos); }
+  }
+  for (int j = 0; j < n; j++)
+    for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) { int pos = nxt[n + an.Ai[k]]++; an.Ki[pos] = j; an.AtoK[k] = pos; }
+  for (int r = 0; r < m; r++) { int pos = nxt[n + r]++; an.Ki[pos] = n + r; an.rhotoK[r] = pos; }
+  // ---- ordering, then etree postorder so that supernodes are contiguous
+  min_degree(N, an.Kp, an.Ki, an.perm);
+  an.pinv.assign(N, 0);
+  for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
+  build_permuted_lower(an);
+  std::vector<std::vector<int>> cols;
+  std::vector<int> parent, post;
+  symbolic(an, cols, parent);
+  postorder(parent, post);
+  {
+    std::vector<int> p2(N);
+    for (int k = 0; k < N; k++) p2[k] = an.perm[post[k]];
+    an.perm.swap(p2);
+    for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
+  }
+  build_permuted_lower(an);
+  symbolic(an, cols, parent);
+  an.etree = parent;
+  an.Lp.assign(N + 1, 0);
+  for (int j = 0; j < N; j++) an.Lp[j + 1] = an.Lp[j] + (int)cols[j].size();
+  an.Li.resize(an.Lp[N]);
+  for (int j = 0; j < N; j++) std::copy(cols[j].begin(), cols[j].end(), an.Li.begin() + an.Lp[j]);
+  // row view of L
+  an.Rp.assign(N + 1, 0);
+  for (int p = 0; p < an.Lp[N]; p++) an.Rp[an.Li[p] + 1]++;
+  for (int i = 0; i < N; i++) an.Rp[i + 1] += an.Rp[i];
+  an.Rj.resize(an.Lp[N]); an.Rpos.resize(an.Lp[N]);
+  {
+    std::vector<int> fill(an.Rp.begin(), an.Rp.end() - 1);
+    for (int j = 0; j < N; j++)
+      for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int q = fill[an.Li[p]]++; an.Rj[q] = j; an.Rpos[q] = p; }
+  }
+  // fundamental supernodes: j+1 joins j when parent(j)=j+1 and |col j| = |col j+1| + 1
+  an.sn_start.clear(); an.sn_start.push_back(0);
+  for (int j = 0; j + 1 < N; j++) {
+    bool join = parent[j] == j + 1 && cols[j].size() == cols[j + 1].size() + 1;
+    if (!join) an.sn_start.push_back(j + 1);
+  }
+  an.sn_start.push_back(N);
+  an.chunk_start.clear();
+  for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
+    for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) an.chunk_start.push_back(c);
+  an.chunk_start.push_back(N);
+  build_tri_schedules(an);
+  build_chk_schedule(an);
+  return MI_OSQP_OK;
+}
+
+// --------------------------------------------------------------- per-QP numeric
+
+void load_qp(const Analysis &an, const Settings &st, const double *Pval, const double *q,
+             const double *Aval, const double *l, const double *u, QPNumeric &qp) {
+  int n = an.n, m = an.m;
+  qp.Pv.resize(an.Pp[n]);
+  for (int k = 0; k < an.Pp[n]; k++) qp.Pv[k] = Pval[an.Psrc[k]];
+  qp.Av.assign(Aval, Aval + an.Ap[n]);
+  if (q) qp.q.assign(q, q + n); else qp.q.assign(n, 0.0);
+  qp.l.resize(m); qp.u.resize(m);
+  for (int i = 0; i < m; i++) { qp.l[i] = std::max(l[i], -kInfty); qp.u[i] = std::min(u[i], kInfty); }
+  qp.D.assign(n, 1.0); qp.Dinv.assign(n, 1.0); qp.E.assign(m, 1.0); qp.Einv.assign(m, 1.0);
+  qp.c = qp.cinv = 1.0;
+  qp.rho = st.rho;
+}
+
+static inline double limit_scaling(double v) {
+  v = v < kMinScaling ? 1.0 : v;
+  return v > kMaxScaling ? kMaxScaling : v;
+}
+
+// Ruiz equilibration of [[P, A'],[A, 0]] + cost normalisation (row E2).  The
+// arithmetic is the published algorithm; the loops are fused per pattern walk.
+void scale_qp(const Analysis &an, const Settings &st, QPNumeric &qp) {
+  int n = an.n, m = an.m;
+  std::fill(qp.D.begin(), qp.D.end(), 1.0);
+  std::fill(qp.E.begin(), qp.E.end(), 1.0);
+  qp.c = 1.0;
+  std::vector<double> dn(n), en(m);
+  for (int64_t it = 0; it < st.scaling; it++) {
+    std::fill(dn.begin(), dn.end(), 0.0);
+    std::fill(en.begin(), en.end(), 0.0);
+    for (int j = 0; j < n; j++)
+      for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) {
+        double a = std::fabs(qp.Pv[k]); int i = an.Pi[k];
+        if (a > dn[j]) dn[j] = a;
+        if (i != j && a > dn[i]) dn[i] = a;
+      }
+    for (int j = 0; j < n; j++)
+      for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) {
+        double a = std::fabs(qp.Av[k]);
+        if (a > dn[j]) dn[j] = a;
+        if (a > en[an.Ai[k]]) en[an.Ai[k]] = a;
+      }
+    for (int j = 0; j < n; j++) dn[j] = 1.0 / std::sqrt(limit_scaling(dn[j]));
+    for (int i = 0; i < m; i++) en[i] = 1.0 / std::sqrt(limit_scaling(en[i]));
+    for (int j = 0; j < n; j++)
+      for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) { qp.Pv[k] *= dn[an.Pi[k]]; qp.Pv[k] *= dn[j]; }
+    for (int j = 0; j < n; j++)
+      for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) { qp.Av[k] *= en[an.Ai[k]]; qp.Av[k] *= dn[j]; }
+    for (int j = 0; j < n; j++) { qp.q[j] *= dn[j]; qp.D[j] *= dn[j]; }
+    for (int i = 0; i < m; i++) qp.E[i] *= en[i];
+    // cost normalisation
+    std::fill(dn.begin(), dn.end(), 0.0);
+    for (int j = 0; j < n; j++)
+      for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) {
+        double a = std::fabs(qp.Pv[k]); int i = an.Pi[k];
+        if (a > dn[j]) dn[j] = a;
+        if (i != j && a > dn[i]) dn[i] = a;
+      }
+    double mean = 0.0;
+    for (int j = 0; j < n; j++) mean += dn[j];
+    mean /= (double)n;
+    double nq = 0.0;
+    for (int j = 0; j < n; j++) nq = std::max(nq, std::fabs(qp.q[j]));
+    nq = limit_scaling(nq);
+    double ct = limit_scaling(std::max(mean, nq));
+    ct = 1.0 / ct;
+    for (double &v : qp.Pv) v *= ct;
+    for (double &v : qp.q) v *= ct;
+    qp.c *= ct;
+  }
+  qp.cinv = 1.0 / qp.c;
+  for (int j = 0; j < n; j++) qp.Dinv[j] = 1.0 / qp.D[j];
+  for (int i = 0; i < m; i++) qp.Einv[i] = 1.0 / qp.E[i];
+  for (int i = 0; i < m; i++) { qp.l[i] *= qp.E[i]; qp.u[i] *= qp.E[i]; }
+}
+
+void unscale_qp(const Analysis &an, QPNumeric &qp) {
+  int n = an.n, m = an.m;
+  for (int j = 0; j < n; j++)
+    for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) { qp.Pv[k] *= qp.cinv; qp.Pv[k] *= qp.Dinv[an.Pi[k]]; qp.Pv[k] *= qp.Dinv[j]; }
+  for (int j = 0; j < n; j++) qp.q[j] *= qp.cinv * qp.Dinv[j];
+  for (int j = 0; j < n; j++)
+    for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) { qp.Av[k] *= qp.Einv[an.Ai[k]]; qp.Av[k] *= qp.Dinv[j]; }
+  for (int i = 0; i < m; i++) { qp.l[i] *= qp.Einv[i]; qp.u[i] *= qp.Einv[i]; }
+}
+
+static inline int8_t row_type(double l, double u) {
+  if (l < -kInfty * kMinScaling && u > kInfty * kMinScaling) return -1;
+  if (u - l < kRhoTol) return 1;
+  return 0;
+}
+static inline double rho_of_type(int8_t t, double rho) {
+  return t < 0 ? kRhoMin : (t > 0 ? kRhoEqOverIneq * rho : rho);
+}
+
+void set_rho_vec(const Analysis &an, const Settings &, QPNumeric &qp) {
+  int m = an.m;
+  qp.rho = std::min(std::max(qp.rho, kRhoMin), kRhoMax);
+  qp.rho_vec.resize(m); qp.rho_inv.resize(m); qp.ctype.resize(m);
+  for (int i = 0; i < m; i++) {
+    qp.ctype[i] = row_type(qp.l[i], qp.u[i]);
+    qp.rho_vec[i] = rho_of_type(qp.ctype[i], qp.rho);
+    qp.rho_inv[i] = 1.0 / qp.rho_vec[i];
+  }
+}
+
+int refresh_rho_types(const Analysis &an, QPNumeric &qp) {
+  int changed = 0;
+  for (int i = 0; i < an.m; i++) {
+    int8_t t = row_type(qp.l[i], qp.u[i]);
+    if (t != qp.ctype[i]) {
+      qp.ctype[i] = t; qp.rho_vec[i] = rho_of_type(t, qp.rho); qp.rho_inv[i] = 1.0 / qp.rho_vec[i]; changed = 1;
+    }
+  }
+  return changed;
+}
+
+void apply_rho(const Analysis &an, QPNumeric &qp, double rho_new) {
+  qp.rho = std::min(std::max(rho_new, kRhoMin), kRhoMax);
+  for (int i = 0; i < an.m; i++) {
+    if (qp.ctype[i] == 0) { qp.rho_vec[i] = qp.rho; qp.rho_inv[i] = 1.0 / qp.rho; }
+    else if (qp.ctype[i] == 1) { qp.rho_vec[i] = kRhoEqOverIneq * qp.rho; qp.rho_inv[i] = 1.0 / qp.rho_vec[i]; }
+  }
+}
+
+// Left-looking LDL' on the permuted KKT using the precomputed pattern of L
+// (sorted columns + row view).  work: N doubles, zero on entry and exit.
+int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector<double> &w) {
+  int n = an.n, m = an.m, N = an.N, nnzP = an.Pp[n], nnzA = an.Ap[n];
+  // permuted lower KKT values
+  std::vector<double> Kl(an.nnzK());
+  for (int k = 0; k < nnzP; k++) Kl[an.KtoKl[an.PtoK[k]]] = qp.Pv[k] + (an.PisDiag[k] ? st.sigma : 0.0);
+  for (int pos : an.sigmaOnlyK) Kl[an.KtoKl[pos]] = st.sigma;
+  for (int k = 0; k < nnzA; k++) Kl[an.KtoKl[an.AtoK[k]]] = qp.Av[k];
+  for (int r = 0; r < m; r++) Kl[an.KtoKl[an.rhotoK[r]]] = -qp.rho_inv[r];
+  qp.Lx.assign(an.nnzL(), 0.0); qp.Dl.assign(N, 0.0); qp.Dlinv.assign(N, 0.0);
+  if ((int)w.size() < N) w.assign(N, 0.0);
+  int positive = 0;
+  for (int j = 0; j < N; j++) {
+    for (int p = an.Klp[j]; p < an.Klp[j + 1]; p++) w[an.Kli[p]] = Kl[p];
+    for (int t = an.Rp[j]; t < an.Rp[j + 1]; t++) {
+      int k = an.Rj[t], pos = an.Rpos[t];
+      double ljk = qp.Lx[pos], f = ljk * qp.Dl[k];
+      w[j] -= ljk * f;
+      const int end = an.Lp[k + 1];
+      for (int p = pos + 1; p < end; p++) w[an.Li[p]] -= qp.Lx[p] * f;
+    }
+    double d = w[j]; w[j] = 0.0;
+    if (d == 0.0) { for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) w[an.Li[p]] = 0.0; return MI_OSQP_ERR_NONCONVEX; }
+    if (d > 0.0) positive++;
+    qp.Dl[j] = d;
+    double dinv = 1.0 / d;
+    qp.Dlinv[j] = dinv;
+    for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int i = an.Li[p]; qp.Lx[p] = w[i] * dinv; w[i] = 0.0; }
+  }
+  return positive == n ? MI_OSQP_OK : MI_OSQP_ERR_NONCONVEX;
+}
+
+void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
+  int N = an.N;
+  std::vector<double> b(N);
+  for (int k = 0; k < N; k++) b[k] = rhs[an.perm[k]];
+  for (int j = 0; j < N; j++) { double v = b[j]; for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) b[an.Li[p]] -= qp.Lx[p] * v; }
+  for (int j = 0; j < N; j++) b[j] *= qp.Dlinv[j];
+  for (int j = N - 1; j >= 0; j--) { double v = b[j]; for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) v -= qp.Lx[p] * b[an.Li[p]]; b[j] = v; }
+  for (int k = 0; k < N; k++) sol[an.perm[k]] = b[k];
+}
+
+static void replay(const Schedule &s, const double *canon, double *xs, bool subtract, double *out) {
+  for (int L = 0; L < s.n_levels; L++) {
+    const uint32_t *lv = &s.lvl[4 * L];
+    for (uint32_t t = lv[0]; t < lv[1]; t++) {
+      const uint32_t *tk = &s.taskA[4 * t];
+      uint32_t base = tk[0], S = tk[1], T = 1u << tk[2], ob = tk[3];
+      for (uint32_t g = 0; g < 64 / T; g++) {
+        uint32_t row = s.outA[ob + g];
+        if (row == kNoRow) continue;
+        double acc = 0.0;
+        for (uint32_t st = 0; st < S; st++)
+          for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) {
+            uint32_t slot = base + st * 64 + ln;
+            double v = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
+            acc += v * xs[s.idx[slot]];
+          }
+        if (subtract) xs[row] -= acc; else out[row] = acc;
+      }
+    }
+    for (uint32_t t = lv[2]; t < lv[3]; t++) {
+      const uint32_t *tk = &s.taskB[4 * t];
+      uint32_t base = tk[0], r = tk[1], ob = tk[2];
+      double acc[kChunk];
+      for (uint32_t i = 0; i < r; i++) acc[i] = xs[s.outB[ob + i]];
+      for (uint32_t p = 0; p + 1 < r; p++) {
+        double v = acc[p];
+        for (uint32_t i = 0; i < r; i++) {
+          uint32_t slot = base + p * kChunk + i;
+          double lv2 = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
+          acc[i] -= lv2 * v;
+        }
+      }
+      for (uint32_t i = 0; i < r; i++) xs[s.outB[ob + i]] = acc[i];
+    }
+  }
+}
+
+void replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
+  int N = an.N;
+  std::vector<double> xs(N);
+  for (int k = 0; k < N; k++) xs[k] = rhs[an.perm[k]];
+  replay(an.fwd, qp.Lx.data(), xs.data(), true, nullptr);
+  for (int k = 0; k < N; k++) xs[k] *= qp.Dlinv[k];
+  replay(an.bwd, qp.Lx.data(), xs.data(), true, nullptr);
+  for (int k = 0; k < N; k++) sol[an.perm[k]] = xs[k];
+}
+
+void replay_spmv(const Analysis &an, const QPNumeric &qp, const double *x, const double *y,
+                 double *Px, double *Aty, double *Ax) {
+  int n = an.n, m = an.m;
+  std::vector<double> xs(n + m), out(2 * n + m, 0.0), pa(qp.Pv.size() + qp.Av.size());
+  std::copy(x, x + n, xs.begin()); std::copy(y, y + m, xs.begin() + n);
+  std::copy(qp.Pv.begin(), qp.Pv.end(), pa.begin());
+  std::copy(qp.Av.begin(), qp.Av.end(), pa.begin() + qp.Pv.size());
+  replay(an.chk, pa.data(), xs.data(), false, out.data());
+  std::copy(out.begin(), out.begin() + n, Px);
+  std::copy(out.begin() + n, out.begin() + 2 * n, Aty);
+  std::copy(out.begin() + 2 * n, out.end(), Ax);
+}
+
+}  // namespace miosqp

@@ -1,0 +1,108 @@
+// host_core.hpp -- host side of the MI355X OSQP core: everything setup() does
+// before the ADMM iterate moves to the GPU (SURVEY.md section 8(a) rows E1-E5,
+// E13) plus the builder of the device schedules.  Pure C++17, no HIP types, so
+// that CPU-only CI can exercise it through the mi_osqp_debug_* entry points.
+//
+// Nothing here is shared with oracle/: the oracle is an up-looking QDLDL-style
+// restatement, this file is an independent left-looking factorisation with a
+// supernode-aware, level-scheduled layout designed for wave64 execution.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace miosqp {
+
+constexpr double kInfty = 1e30;          // [REF] src/constraints/constraints.h:11
+constexpr double kRhoMin = 1e-6, kRhoMax = 1e6, kRhoEqOverIneq = 1e3, kRhoTol = 1e-4;
+constexpr double kMinScaling = 1e-4, kMaxScaling = 1e4;
+constexpr double kDivisionTol = 1.0 / kInfty;
+constexpr int kChunk = 16;               // rows of one in-block triangle (phase B)
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+
+struct Settings {
+  double rho = 0.1, sigma = 1e-6;
+  int64_t scaling = 10, adaptive_rho = 1, adaptive_rho_interval = 0;
+  double adaptive_rho_tolerance = 5.0;
+  int64_t max_iter = 4000;
+  double eps_abs = 1e-3, eps_rel = 1e-3, eps_prim_inf = 1e-4, eps_dual_inf = 1e-4, alpha = 1.6;
+  int64_t scaled_termination = 0, check_termination = 25, warm_start = 1, verbose = 0;
+};
+int validate_settings(const Settings &s);   // 0 ok
+
+// One pull-schedule: every target row t gets  xs[t] -= sum_k val[k] * xs[idx[k]].
+// Phase A ("row tasks"): a wave task covers 64 lanes x S steps; groups of T lanes
+// (T a power of two) own one target row and are reduced by a butterfly.
+// Phase B ("block tasks"): the dense in-block triangle of a <=16-row chunk of a
+// supernode, solved column-by-column inside one wave.
+struct Schedule {
+  int n_levels = 0;
+  std::vector<uint32_t> lvl;    // 4/level: a_begin, a_end, b_begin, b_end (task indices)
+  std::vector<uint32_t> taskA;  // 4/task : slot_base, S, log2T, out_base
+  std::vector<uint32_t> outA;   // target rows per task (64/T each), kNoRow = none
+  std::vector<uint32_t> taskB;  // 4/task : slot_base, r, out_base, 0
+  std::vector<uint32_t> outB;   // kChunk rows per block task, processing order
+  std::vector<uint32_t> idx;    // per slot: gather index into the LDS vector
+  std::vector<int32_t> src;     // per slot: canonical value index, -1 = structural zero
+  uint32_t n_slots = 0;
+  size_t n_taskA() const { return taskA.size() / 4; }
+  size_t n_taskB() const { return taskB.size() / 4; }
+};
+
+struct Analysis {
+  int n = 0, m = 0, N = 0;
+  // triu(P) and A patterns (CSC, 32-bit on our side)
+  std::vector<int> Pp, Pi, Psrc;   // Psrc: index into the caller's P value array
+  std::vector<int> Ap, Ai;
+  // natural upper-triangular KKT [[P+sigma I, A'],[A, -1/rho]]
+  std::vector<int> Kp, Ki, PtoK, AtoK, rhotoK, sigmaOnlyK;
+  std::vector<char> PisDiag;
+  // fill-reducing permutation (perm[new] = old)
+  std::vector<int> perm, pinv;
+  // permuted KKT, lower triangle by columns, and map natural entry -> position
+  std::vector<int> Klp, Kli, KtoKl;
+  // symbolic factor: strictly-lower L by columns (sorted rows) + row view
+  std::vector<int> Lp, Li, Rp, Rj, Rpos, etree;
+  std::vector<int> sn_start;       // supernode boundaries
+  std::vector<int> chunk_start;    // <=16-column chunks (phase-B blocks)
+  Schedule fwd, bwd, chk;
+  int nnzL() const { return Lp.empty() ? 0 : Lp.back(); }
+  int nnzK() const { return Kp.empty() ? 0 : Kp.back(); }
+};
+
+// E1 (pattern part), E4, E5-symbolic and the schedules.  Returns 0 or an error
+// code of include/mi_osqp.h.
+int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
+            const int64_t *Ai, Analysis &an);
+
+// Per-QP numeric state kept on the host (needed for rescaling and refactors).
+struct QPNumeric {
+  std::vector<double> Pv, Av, q, l, u;            // scaled problem data
+  std::vector<double> D, Dinv, E, Einv;           // Ruiz scaling
+  double c = 1.0, cinv = 1.0;
+  double rho = 0.1;
+  std::vector<double> rho_vec, rho_inv;
+  std::vector<int8_t> ctype;
+  std::vector<double> Lx, Dl, Dlinv;              // factor (canonical CSC order)
+};
+
+void load_qp(const Analysis &an, const Settings &st, const double *Pval, const double *q,
+             const double *Aval, const double *l, const double *u, QPNumeric &qp);
+void scale_qp(const Analysis &an, const Settings &st, QPNumeric &qp);       // E2
+void unscale_qp(const Analysis &an, QPNumeric &qp);
+void set_rho_vec(const Analysis &an, const Settings &st, QPNumeric &qp);    // E3
+// returns 1 if any constraint type changed (bounds update path of E13)
+int refresh_rho_types(const Analysis &an, QPNumeric &qp);
+void apply_rho(const Analysis &an, QPNumeric &qp, double rho_new);
+// E5 numeric: left-looking LDL' on the permuted KKT. 0 ok, MI_OSQP_ERR_NONCONVEX else.
+int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector<double> &work);
+// reference solve with the canonical factor (natural order in/out)
+void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
+// sequential interpreter of the device schedules (tests only; see mi_osqp.h)
+void replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
+// combined value array the check-SpMV schedule indexes: [P triu | A]
+void replay_spmv(const Analysis &an, const QPNumeric &qp, const double *x, const double *y,
+                 double *Px, double *Aty, double *Ax);
+
+}  // namespace miosqp

@@ -1,0 +1,678 @@
+// kernels.hip -- hand-written gfx950 kernels of the OSQP ADMM iterate
+// (SURVEY.md section 8(a) rows E6-E14).  fp64 throughout, no MFMA: the path is
+// sparse and HBM-bound.
+//
+// Execution model (MI355X-first, not a translation of anything):
+//   * B QPs share ONE sparsity pattern; they are cut into tiles of BT QPs whose
+//     values are interleaved innermost ([entry][BT]) so that one wave64 load
+//     instruction streams 64 consecutive entries x BT doubles (512 B .. 2 KiB).
+//   * ONE workgroup owns ONE tile for the WHOLE solve: QPs are independent, so
+//     no grid-wide synchronisation ever exists; the KKT solve vector lives in
+//     LDS (N*BT doubles), the factor streams from HBM in schedule order.
+//   * The triangular solves are "pull" schedules built on the host
+//     (host_core.cpp): per elimination level, phase A = wave tasks that gather
+//     from the LDS vector and butterfly-reduce groups of T lanes into one
+//     target row; phase B = the dense in-chunk triangle of a supernode solved
+//     column-by-column inside one wave with lane broadcasts.
+//   * The same row-task machinery evaluates P x, A' y and A x for the residuals.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace miosqp {
+
+#define MI_INFTY 1e30
+#define MI_MIN_SCALING 1e-4
+#define MI_DIV_TOL 1e-30
+#define MI_RHO_MIN 1e-6
+#define MI_RHO_MAX 1e6
+#define MI_NOROW 0xFFFFFFFFu
+
+template <int BT>
+struct VecBT;
+template <>
+struct VecBT<1> { double v[1]; };
+template <>
+struct VecBT<2> { double v[2]; };
+template <>
+struct VecBT<4> { double v[4]; };
+
+template <int BT>
+__device__ __forceinline__ void load_bt(const double *__restrict__ p, double (&o)[BT]) {
+  if constexpr (BT == 1) {
+    o[0] = p[0];
+  } else if constexpr (BT == 2) {
+    double2 t = *reinterpret_cast<const double2 *>(p);
+    o[0] = t.x; o[1] = t.y;
+  } else {
+    double2 t0 = reinterpret_cast<const double2 *>(p)[0];
+    double2 t1 = reinterpret_cast<const double2 *>(p)[1];
+    o[0] = t0.x; o[1] = t0.y; o[2] = t1.x; o[3] = t1.y;
+  }
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+
+// ----------------------------------------------------------------- row tasks
+// SUB = true : xs[row] -= acc   (triangular solves, vector in LDS)
+// SUB = false: out[row] = acc   (SpMV for residuals; out in global memory)
+template <int BT, bool SUB>
+__device__ __forceinline__ void run_taskA(const SchedDev &s, const double *__restrict__ vals,
+                                          double *xs, double *out, uint32_t t, int lane) {
+  const uint4 tk = reinterpret_cast<const uint4 *>(s.taskA)[t];
+  const uint32_t base = tk.x, S = tk.y, lt = tk.z, ob = tk.w;
+  double acc[BT];
+#pragma unroll
+  for (int b = 0; b < BT; b++) acc[b] = 0.0;
+  uint32_t slot = base + (uint32_t)lane;
+#pragma unroll 4
+  for (uint32_t st = 0; st < S; st++, slot += 64u) {
+    const uint32_t gi = s.idx[slot];
+    double v[BT], xv[BT];
+    load_bt<BT>(vals + (size_t)slot * BT, v);
+    load_bt<BT>(xs + (size_t)gi * BT, xv);
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
+  }
+  const int T = 1 << lt;
+  for (int off = 1; off < T; off <<= 1) {
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[b] += shfl_xor_d(acc[b], off);
+  }
+  if ((lane & (T - 1)) == 0) {
+    const uint32_t row = s.outA[ob + ((uint32_t)lane >> lt)];
+    if (row != MI_NOROW) {
+      double *dst = (SUB ? xs : out) + (size_t)row * BT;
+#pragma unroll
+      for (int b = 0; b < BT; b++) {
+        if (SUB) dst[b] -= acc[b]; else dst[b] = acc[b];
+      }
+    }
+  }
+}
+
+// dense in-chunk triangle (<=16 rows) solved inside one wave: lane = (i, b);
+// for p = 0..r-2 the finished value of local row p is broadcast and every lane
+// i > p subtracts L[p->i] * v (structural zeros are stored as 0).
+template <int BT>
+__device__ __forceinline__ void run_taskB(const SchedDev &s, const double *__restrict__ vals,
+                                          double *xs, uint32_t t, int lane) {
+  const uint4 tk = reinterpret_cast<const uint4 *>(s.taskB)[t];
+  const uint32_t base = tk.x, r = tk.y, ob = tk.z;
+  const int i = lane / BT, b = lane % BT;
+  const bool active = lane < MI_CHUNK * BT;
+  uint32_t row = MI_NOROW;
+  if (active) row = s.outB[ob + i];
+  const bool valid = row != MI_NOROW;
+  double acc = valid ? xs[(size_t)row * BT + b] : 0.0;
+  double lv[MI_CHUNK - 1];
+#pragma unroll
+  for (int p = 0; p < MI_CHUNK - 1; p++)
+    lv[p] = (active && (uint32_t)p + 1 < r) ? vals[((size_t)base + p * MI_CHUNK + i) * BT + b] : 0.0;
+#pragma unroll
+  for (int p = 0; p < MI_CHUNK - 1; p++) {
+    const double v = shfl_d(acc, p * BT + b);
+    acc = fma(-lv[p], v, acc);
+  }
+  if (valid) xs[(size_t)row * BT + b] = acc;
+}
+
+template <int BT>
+__device__ __forceinline__ void run_tri(const SchedDev &s, const double *__restrict__ vals, double *xs,
+                                        int wave, int nw, int lane) {
+  for (int L = 0; L < s.n_levels; L++) {
+    const uint4 lv = reinterpret_cast<const uint4 *>(s.lvl)[L];
+    if (lv.y > lv.x) {
+      for (uint32_t t = lv.x + wave; t < lv.y; t += nw) run_taskA<BT, true>(s, vals, xs, nullptr, t, lane);
+      __syncthreads();
+    }
+    if (lv.w > lv.z) {
+      for (uint32_t t = lv.z + wave; t < lv.w; t += nw) run_taskB<BT>(s, vals, xs, t, lane);
+      __syncthreads();
+    }
+  }
+}
+
+template <int BT>
+__device__ __forceinline__ void run_spmv(const SchedDev &s, const double *__restrict__ vals, double *xs,
+                                         double *out, int wave, int nw, int lane, int lvl0, int lvl1) {
+  const uint32_t t0 = s.lvl[4 * lvl0], t1 = s.lvl[4 * (lvl1 - 1) + 1];
+  for (uint32_t t = t0 + wave; t < t1; t += nw) run_taskA<BT, false>(s, vals, xs, out, t, lane);
+}
+
+// --------------------------------------------------------- block reductions
+// K values per thread, reduced over all threads with the same (tid % BT);
+// result broadcast to every thread of that class.  red: nw*K*BT + K*BT doubles.
+template <int BT, int K, bool IS_MAX>
+__device__ __forceinline__ void block_reduce(double (&v)[K], double *red, int tid, int wave, int nw, int lane) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int off = BT; off < 64; off <<= 1) {
+      const double o = shfl_xor_d(v[k], off);
+      v[k] = IS_MAX ? fmax(v[k], o) : v[k] + o;
+    }
+  }
+  if (lane < BT) {
+#pragma unroll
+    for (int k = 0; k < K; k++) red[(wave * K + k) * BT + lane] = v[k];
+  }
+  __syncthreads();
+  double *res = red + nw * K * BT;
+  if (tid < K * BT) {
+    const int k = tid / BT, b = tid % BT;
+    double r = red[k * BT + b];
+    for (int w = 1; w < nw; w++) {
+      const double o = red[(w * K + k) * BT + b];
+      r = IS_MAX ? fmax(r, o) : r + o;
+    }
+    res[k * BT + b] = r;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = res[k * BT + (tid % BT)];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------ the ADMM kernel
+
+template <int BT>
+struct TilePtrs {
+  const double *fwd_val, *bwd_val, *chk_val, *dinv;
+  double *x, *z, *y;
+  const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
+  double *dx, *dy, *out1, *out2, *dscal;
+  int *iscal;
+};
+
+template <int BT>
+__device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile) {
+  TilePtrs<BT> p;
+  const size_t n = a.n, m = a.m, N = a.N, t = tile;
+  p.fwd_val = a.fwd_val + t * a.fwd.n_slots * BT;
+  p.bwd_val = a.bwd_val + t * a.bwd.n_slots * BT;
+  p.chk_val = a.chk_val + t * a.chk.n_slots * BT;
+  p.dinv = a.dinv + t * N * BT;
+  p.x = a.x + t * n * BT; p.z = a.z + t * m * BT; p.y = a.y + t * m * BT;
+  p.q = a.q + t * n * BT; p.l = a.l + t * m * BT; p.u = a.u + t * m * BT;
+  p.rho_vec = a.rho_vec + t * m * BT; p.rho_inv = a.rho_inv + t * m * BT;
+  p.Dsc = a.Dsc + t * n * BT; p.Dsc_inv = a.Dsc_inv + t * n * BT;
+  p.Esc = a.Esc + t * m * BT; p.Esc_inv = a.Esc_inv + t * m * BT;
+  p.dx = a.dx + t * n * BT; p.dy = a.dy + t * m * BT;
+  p.out1 = a.out1 + t * (2 * n + m) * BT; p.out2 = a.out2 + t * (2 * n + m) * BT;
+  p.dscal = a.dscal + t * DS_COUNT * BT;
+  p.iscal = a.iscal + t * IS_COUNT * BT;
+  return p;
+}
+
+// K solve on the LDS vector: fwd levels, D^-1, bwd levels (row E7)
+template <int BT>
+__device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
+                                              int tid, int nthr, int wave, int nw, int lane) {
+  run_tri<BT>(a.fwd, p.fwd_val, xs, wave, nw, lane);
+  for (int e = tid; e < a.N * BT; e += nthr) xs[e] *= p.dinv[e];
+  __syncthreads();
+  run_tri<BT>(a.bwd, p.bwd_val, xs, wave, nw, lane);
+}
+
+template <int BT>
+__global__ __launch_bounds__(1024) void admm_kernel(KernelArgs a) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int b = tid % BT;
+  const int n = a.n, m = a.m, N = a.N;
+  double *xs = smem;
+  double *red = smem + (size_t)N * BT;
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  const int qp = tile * BT + b;             // global QP id of this thread's class
+
+  int done = p.iscal[IS_DONE * BT + b];
+  if (__syncthreads_and(done)) return;
+  int iter = a.tile_iter[tile];
+  int status = p.iscal[IS_STATUS * BT + b];
+  int rho_updates = p.iscal[IS_RHO_UPDATES * BT + b];
+  double rho = p.dscal[DS_RHO * BT + b];
+  const double c = p.dscal[DS_C * BT + b], cinv = p.dscal[DS_CINV * BT + b];
+  const double alpha = a.alpha, sigma = a.sigma;
+  const bool unscale = a.scaling && !a.scaled_termination;
+  int budget = a.iter_budget;
+
+  while (true) {
+    iter++;
+    const bool is_last = iter >= a.max_iter;
+    const bool is_check = a.check_termination && (iter % a.check_termination == 0);
+    const bool is_rho = a.adaptive_rho && a.rho_interval && (iter % a.rho_interval == 0);
+    const bool do_info = is_check || is_rho || is_last;
+
+    // ---- E6: rhs into the permuted LDS vector
+    for (int e = tid; e < N * BT; e += nthr) {
+      const int i = e / BT;
+      double v;
+      if (i < n) v = sigma * p.x[e] - p.q[e];
+      else { const int ez = e - n * BT; v = p.z[ez] - p.rho_inv[ez] * p.y[ez]; }
+      xs[(size_t)a.pinv[i] * BT + b] = v;
+    }
+    __syncthreads();
+    // ---- E7
+    kkt_solve_lds<BT>(a, p, xs, tid, nthr, wave, nw, lane);
+    // ---- E8-E10 (run_tri ends with a barrier)
+    for (int e = tid; e < n * BT; e += nthr) {
+      const int i = e / BT;
+      const double xt = xs[(size_t)a.pinv[i] * BT + b], xp = p.x[e];
+      const double xn = alpha * xt + (1.0 - alpha) * xp;
+      if (!done) { p.x[e] = xn; if (do_info) p.dx[e] = xn - xp; }
+    }
+    for (int e = tid; e < m * BT; e += nthr) {
+      const int j = e / BT;
+      const double nu = xs[(size_t)a.pinv[n + j] * BT + b];
+      const double zp = p.z[e], yv = p.y[e], ri = p.rho_inv[e], rv = p.rho_vec[e];
+      double zt = zp - ri * yv;
+      zt += ri * nu;
+      const double zr = alpha * zt + (1.0 - alpha) * zp;
+      const double zn = fmin(fmax(zr + ri * yv, p.l[e]), p.u[e]);
+      const double dyv = rv * (zr - zn);
+      if (!done) { p.z[e] = zn; p.y[e] = yv + dyv; if (do_info) p.dy[e] = dyv; }
+    }
+    __syncthreads();
+
+    int need_refactor = 0;
+    if (do_info) {
+      // ---- E11: [x;y] -> LDS, P x / A' y / A x
+      for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
+      for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
+      __syncthreads();
+      run_spmv<BT>(a.chk, p.chk_val, xs, p.out1, wave, nw, lane, 0, 3);
+      __syncthreads();
+      // residual vectors and the norms termination + rho estimate need
+      double mx[14];
+#pragma unroll
+      for (int k = 0; k < 14; k++) mx[k] = 0.0;
+      double sm[1] = {0.0};
+      for (int e = tid; e < n * BT; e += nthr) {
+        const double px = p.out1[e], aty = p.out1[(size_t)n * BT + e], qv = p.q[e], xv = p.x[e];
+        const double di = p.Dsc_inv[e];
+        double dres = qv + px;
+        dres += aty;
+        mx[0] = fmax(mx[0], fabs(dres));      mx[1] = fmax(mx[1], fabs(di * dres));
+        mx[2] = fmax(mx[2], fabs(qv));        mx[3] = fmax(mx[3], fabs(aty));   mx[4] = fmax(mx[4], fabs(px));
+        mx[5] = fmax(mx[5], fabs(di * qv));   mx[6] = fmax(mx[6], fabs(di * aty)); mx[7] = fmax(mx[7], fabs(di * px));
+        sm[0] += 0.5 * xv * px + qv * xv;
+      }
+      for (int e = tid; e < m * BT; e += nthr) {
+        const double ax = p.out1[(size_t)2 * n * BT + e], zv = p.z[e], ei = p.Esc_inv[e];
+        const double pres = ax - zv;
+        mx[8] = fmax(mx[8], fabs(pres));      mx[9] = fmax(mx[9], fabs(ei * pres));
+        mx[10] = fmax(mx[10], fabs(zv));      mx[11] = fmax(mx[11], fabs(ax));
+        mx[12] = fmax(mx[12], fabs(ei * zv)); mx[13] = fmax(mx[13], fabs(ei * ax));
+      }
+      block_reduce<BT, 14, true>(mx, red, tid, wave, nw, lane);
+      block_reduce<BT, 1, false>(sm, red, tid, wave, nw, lane);
+      const double pri_res = (m == 0) ? 0.0 : (unscale ? mx[9] : mx[8]);
+      const double dua_res = unscale ? cinv * mx[1] : mx[0];
+      double obj = sm[0];
+      if (a.scaling) obj *= cinv;
+      const double pri_nrm = unscale ? fmax(mx[12], mx[13]) : fmax(mx[10], mx[11]);
+      const double dua_nrm = unscale ? cinv * fmax(fmax(mx[5], mx[6]), mx[7]) : fmax(fmax(mx[2], mx[3]), mx[4]);
+
+      // ---- E12 ingredients that do not depend on the tolerances
+      // infeasibility certificates on delta_y / delta_x
+      double mi[4] = {0.0, 0.0, 0.0, 0.0};   // norm_dy, norm_dx, |Dinv A'dy|, |Dinv P dx|
+      double si[2] = {0.0, 0.0};             // ineq_lhs, q'dx
+      for (int e = tid; e < n * BT; e += nthr) {
+        const double d = p.dx[e];
+        xs[e] = d;
+        mi[1] = fmax(mi[1], unscale ? fabs(p.Dsc[e] * d) : fabs(d));
+        si[1] += p.q[e] * d;
+      }
+      for (int e = tid; e < m * BT; e += nthr) {
+        double d = p.dy[e];
+        const double lo = p.l[e], up = p.u[e];
+        if (up > MI_INFTY * MI_MIN_SCALING) {
+          if (lo < -MI_INFTY * MI_MIN_SCALING) d = 0.0; else d = fmin(d, 0.0);
+        } else if (lo < -MI_INFTY * MI_MIN_SCALING) d = fmax(d, 0.0);
+        xs[(size_t)n * BT + e] = d;
+        mi[0] = fmax(mi[0], unscale ? fabs(p.Esc[e] * d) : fabs(d));
+        si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
+      }
+      __syncthreads();
+      run_spmv<BT>(a.chk, p.chk_val, xs, p.out2, wave, nw, lane, 0, 3);
+      __syncthreads();
+      for (int e = tid; e < n * BT; e += nthr) {
+        const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
+        const double di = unscale ? p.Dsc_inv[e] : 1.0;
+        mi[2] = fmax(mi[2], fabs(di * atdy));
+        mi[3] = fmax(mi[3], fabs(di * pdx));
+      }
+      block_reduce<BT, 4, true>(mi, red, tid, wave, nw, lane);
+      block_reduce<BT, 2, false>(si, red, tid, wave, nw, lane);
+      const double norm_dy = mi[0], norm_dx = mi[1];
+      const double cost_scaling = unscale ? c : 1.0;
+
+      // tolerance-dependent decision; approx = 10x tolerances (max_iter path)
+      auto decide = [&](bool approx) -> int {
+        const double f = approx ? 10.0 : 1.0;
+        const double eps_abs = f * a.eps_abs, eps_rel = f * a.eps_rel;
+        const double eps_pinf = f * a.eps_prim_inf, eps_dinf = f * a.eps_dual_inf;
+        // rows of A dx outside the recession cone (needs its own reduction)
+        double viol[1] = {0.0};
+        for (int e = tid; e < m * BT; e += nthr) {
+          double adx = p.out2[(size_t)2 * n * BT + e];
+          if (unscale) adx *= p.Esc_inv[e];
+          const double lo = p.l[e], up = p.u[e];
+          if ((up < MI_INFTY * MI_MIN_SCALING && adx > eps_dinf * norm_dx) ||
+              (lo > -MI_INFTY * MI_MIN_SCALING && adx < -eps_dinf * norm_dx)) viol[0] = 1.0;
+        }
+        block_reduce<BT, 1, true>(viol, red, tid, wave, nw, lane);
+        if (pri_res > MI_INFTY || dua_res > MI_INFTY) return -7;   // non-convex / diverged
+        int prim_ok = 0, dual_ok = 0, prim_inf = 0, dual_inf = 0;
+        if (m == 0) prim_ok = 1;
+        else {
+          const double eps_prim = eps_abs + eps_rel * pri_nrm;
+          if (pri_res < eps_prim) prim_ok = 1;
+          else if (norm_dy > MI_DIV_TOL && si[0] < -eps_pinf * norm_dy) prim_inf = mi[2] < eps_pinf * norm_dy;
+        }
+        const double eps_dual = eps_abs + eps_rel * dua_nrm;
+        if (dua_res < eps_dual) dual_ok = 1;
+        else if (norm_dx > MI_DIV_TOL && si[1] < -cost_scaling * eps_dinf * norm_dx &&
+                 mi[3] < cost_scaling * eps_dinf * norm_dx) dual_inf = viol[0] == 0.0;
+        if (prim_ok && dual_ok) return approx ? 2 : 1;
+        if (prim_inf) return approx ? 3 : -3;
+        if (dual_inf) return approx ? 4 : -4;
+        return 0;
+      };
+
+      int new_status = 0;
+      if (is_check || is_last) new_status = decide(false);
+      double rho_est = p.dscal[DS_RHO_EST * BT + b];
+      // ---- E13: rho estimate from the SCALED residual norms
+      auto rho_estimate = [&]() -> double {
+        const double pr = mx[8] / (fmax(mx[10], mx[11]) + MI_DIV_TOL);
+        const double du = mx[0] / (fmax(fmax(mx[2], mx[3]), mx[4]) + MI_DIV_TOL);
+        double e = rho * sqrt(pr / du);
+        return fmin(fmax(e, MI_RHO_MIN), MI_RHO_MAX);
+      };
+      if (!done && new_status == 0 && is_rho) {
+        const double rn = rho_estimate();
+        rho_est = rn;
+        if (rn > rho * a.rho_tolerance || rn < rho / a.rho_tolerance) {
+          need_refactor = 1;
+          rho = fmin(fmax(rn, MI_RHO_MIN), MI_RHO_MAX);
+          rho_updates++;
+        }
+      }
+      if (!done && new_status == 0 && is_last) {
+        new_status = decide(true);
+        if (new_status == 0) new_status = -2;   // max iterations reached
+      } else if (is_last) {
+        decide(true);   // keep barriers uniform across the workgroup
+      }
+      if (!done && new_status != 0) {
+        // ---- E14: store_solution
+        done = 1; status = new_status;
+        if (!need_refactor) rho_est = rho_estimate();
+        if (tid < BT) {
+          p.dscal[DS_PRI_RES * BT + b] = pri_res; p.dscal[DS_DUA_RES * BT + b] = dua_res;
+          p.dscal[DS_OBJ * BT + b] = (status == -3 || status == 3) ? MI_INFTY
+                                     : (status == -4 || status == 4) ? -MI_INFTY
+                                     : (status == -7) ? __builtin_nan("") : obj;
+          p.iscal[IS_ITER * BT + b] = iter;
+        }
+      }
+      if (tid < BT) p.dscal[DS_RHO_EST * BT + b] = rho_est;
+      // outputs for QPs that finished in this pass (done is uniform per class b)
+      const int just_done = done && (p.iscal[IS_DONE * BT + b] == 0);
+      __syncthreads();
+      if (just_done && qp < a.B) {
+        const bool has_sol = !(status == -3 || status == 3 || status == -4 || status == 4 || status == -7);
+        const double nanv = __builtin_nan("");
+        for (int e = tid; e < n * BT; e += nthr) {
+          const int i = e / BT;
+          a.x_out[(size_t)qp * n + i] = has_sol ? (a.scaling ? p.Dsc[e] * p.x[e] : p.x[e]) : nanv;
+          if (!has_sol) p.x[e] = 0.0;
+        }
+        for (int e = tid; e < m * BT; e += nthr) {
+          const int j = e / BT;
+          a.y_out[(size_t)qp * m + j] = has_sol ? (a.scaling ? p.Esc[e] * p.y[e] * cinv : p.y[e]) : nanv;
+          if (!has_sol) { p.y[e] = 0.0; p.z[e] = 0.0; }
+        }
+      }
+      __syncthreads();
+      if (tid < BT) {
+        p.iscal[IS_DONE * BT + b] = done; p.iscal[IS_STATUS * BT + b] = status;
+        p.iscal[IS_RHO_UPDATES * BT + b] = rho_updates;
+        p.iscal[IS_NEED_REFACTOR * BT + b] = need_refactor;
+        p.dscal[DS_RHO * BT + b] = rho;
+      }
+    }
+    budget--;
+    const int all_done = __syncthreads_and(done);
+    const int any_ref = __syncthreads_or(need_refactor);
+    if (all_done || any_ref || budget <= 0 || is_last) break;
+  }
+  if (tid == 0) a.tile_iter[tile] = iter;
+}
+
+// ---------------------------------------------------------- standalone ops
+
+// Px, A'y, Ax for QP-major x[B][n], y[B][m]  (rows E11 / E14)
+template <int BT>
+__global__ __launch_bounds__(1024) void spmv_kernel(KernelArgs a, const double *__restrict__ gx,
+                                                    const double *__restrict__ gy, double *gPx,
+                                                    double *gAty, double *gAx) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int n = a.n, m = a.m;
+  const int qp = tile * BT + b;
+  double *xs = smem;
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  for (int e = tid; e < n * BT; e += nthr) xs[e] = (qp < a.B && gx) ? gx[(size_t)qp * n + e / BT] : 0.0;
+  for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = (qp < a.B && gy) ? gy[(size_t)qp * m + e / BT] : 0.0;
+  __syncthreads();
+  run_spmv<BT>(a.chk, p.chk_val, xs, p.out1, wave, nw, lane, 0, 3);
+  __syncthreads();
+  if (qp < a.B) {
+    if (gPx) for (int e = tid; e < n * BT; e += nthr) gPx[(size_t)qp * n + e / BT] = p.out1[e];
+    if (gAty) for (int e = tid; e < n * BT; e += nthr) gAty[(size_t)qp * n + e / BT] = p.out1[(size_t)n * BT + e];
+    if (gAx) for (int e = tid; e < m * BT; e += nthr) gAx[(size_t)qp * m + e / BT] = p.out1[(size_t)2 * n * BT + e];
+  }
+}
+
+// sol = K^-1 rhs for QP-major rhs[B][N]  (row E7)
+template <int BT>
+__global__ __launch_bounds__(1024) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int N = a.N;
+  const int qp = tile * BT + b;
+  double *xs = smem;
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  for (int e = tid; e < N * BT; e += nthr) {
+    const int i = e / BT;
+    xs[(size_t)a.pinv[i] * BT + b] = qp < a.B ? rhs[(size_t)qp * N + i] : 0.0;
+  }
+  __syncthreads();
+  kkt_solve_lds<BT>(a, p, xs, tid, nthr, wave, nw, lane);
+  if (qp < a.B)
+    for (int e = tid; e < N * BT; e += nthr) { const int i = e / BT; sol[(size_t)qp * N + i] = xs[(size_t)a.pinv[i] * BT + b]; }
+}
+
+// warm start (row E14): x <- Dinv .* x0 ; z <- A x   (QP-major x0[B][n])
+template <int BT>
+__global__ __launch_bounds__(1024) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int n = a.n, m = a.m;
+  const int qp = tile * BT + b;
+  double *xs = smem;
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  for (int e = tid; e < n * BT; e += nthr) {
+    double v = qp < a.B ? x0[(size_t)qp * n + e / BT] : 0.0;
+    if (a.scaling) v *= p.Dsc_inv[e];
+    xs[e] = v; p.x[e] = v;
+  }
+  for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
+  __syncthreads();
+  run_spmv<BT>(a.chk, p.chk_val, xs, p.out1, wave, nw, lane, 2, 3);
+  __syncthreads();
+  for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
+}
+
+// ------------------------------------------------- layout / upload kernels
+
+// dst[tile][i][b] = src[q][i]   (q = ids ? ids[j] : j)
+__global__ void interleave_kernel(const double *__restrict__ src, double *dst, const int *ids, int nq,
+                                  int len, int BT) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nq * len) return;
+  const int j = (int)(g / len), i = (int)(g % len);
+  const int q = ids ? ids[j] : j;
+  dst[((size_t)(q / BT) * len + i) * BT + (q % BT)] = src[g];
+}
+// dst[tile][slot][b] = map[slot] >= 0 ? src[q][map[slot]] : 0
+__global__ void scatter_kernel(const double *__restrict__ src, double *dst, const int *__restrict__ map,
+                               const int *ids, int nq, int srclen, int slots, int BT) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nq * slots) return;
+  const int j = (int)(g / slots), s = (int)(g % slots);
+  const int q = ids ? ids[j] : j;
+  const int mp = map[s];
+  dst[((size_t)(q / BT) * slots + s) * BT + (q % BT)] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
+}
+// dst[q][i] = src[tile][i][b]
+__global__ void deinterleave_kernel(const double *__restrict__ src, double *dst, int nq, int len, int BT) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)nq * len) return;
+  const int q = (int)(g / len), i = (int)(g % len);
+  dst[g] = src[((size_t)(q / BT) * len + i) * BT + (q % BT)];
+}
+__global__ void gather_status_kernel(const int *__restrict__ iscal, int32_t *status, int32_t *iters, int B, int BT) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= B) return;
+  const int *t = iscal + (size_t)(q / BT) * IS_COUNT * BT;
+  if (status) status[q] = t[IS_STATUS * BT + q % BT];
+  if (iters) iters[q] = t[IS_ITER * BT + q % BT];
+}
+// bounds update on device: l,u <- E .* clip(l,u); flags a constraint-type change
+__global__ void bounds_kernel(const double *__restrict__ gl, const double *__restrict__ gu, double *l, double *u,
+                              const double *__restrict__ Esc, const double *__restrict__ rho_vec,
+                              const double *__restrict__ dscal, int *changed, int B, int m, int BT, int scaling) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)B * m) return;
+  const int q = (int)(g / m), i = (int)(g % m);
+  const size_t e = ((size_t)(q / BT) * m + i) * BT + (q % BT);
+  double lo = fmax(gl[g], -MI_INFTY), up = fmin(gu[g], MI_INFTY);
+  if (lo > up) { atomicOr(changed, 2); return; }
+  if (scaling) { lo *= Esc[e]; up *= Esc[e]; }
+  l[e] = lo; u[e] = up;
+  const double rho = dscal[((size_t)(q / BT) * DS_COUNT + DS_RHO) * BT + (q % BT)];
+  double want;
+  if (lo < -MI_INFTY * MI_MIN_SCALING && up > MI_INFTY * MI_MIN_SCALING) want = MI_RHO_MIN;
+  else if (up - lo < 1e-4) want = 1e3 * rho;
+  else want = rho;
+  if (want != rho_vec[e]) atomicOr(changed, 1);
+}
+
+// --------------------------------------------------------------- launchers
+
+template <int BT>
+static hipError_t launch_admm_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&admm_kernel<BT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(admm_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_admm(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
+  switch (BT) {
+    case 1: return launch_admm_t<1>(a, tiles, threads, lds, st);
+    case 2: return launch_admm_t<2>(a, tiles, threads, lds, st);
+    default: return launch_admm_t<4>(a, tiles, threads, lds, st);
+  }
+}
+template <int BT>
+static hipError_t launch_spmv_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st,
+                                const double *x, const double *y, double *Px, double *Aty, double *Ax) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_kernel<BT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(spmv_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a, x, y, Px, Aty, Ax);
+  return hipGetLastError();
+}
+hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                       const double *x, const double *y, double *Px, double *Aty, double *Ax) {
+  switch (BT) {
+    case 1: return launch_spmv_t<1>(a, tiles, threads, lds, st, x, y, Px, Aty, Ax);
+    case 2: return launch_spmv_t<2>(a, tiles, threads, lds, st, x, y, Px, Aty, Ax);
+    default: return launch_spmv_t<4>(a, tiles, threads, lds, st, x, y, Px, Aty, Ax);
+  }
+}
+template <int BT>
+static hipError_t launch_kkt_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st,
+                               const double *rhs, double *sol) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_solve_kernel<BT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kkt_solve_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a, rhs, sol);
+  return hipGetLastError();
+}
+hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                            const double *rhs, double *sol) {
+  switch (BT) {
+    case 1: return launch_kkt_t<1>(a, tiles, threads, lds, st, rhs, sol);
+    case 2: return launch_kkt_t<2>(a, tiles, threads, lds, st, rhs, sol);
+    default: return launch_kkt_t<4>(a, tiles, threads, lds, st, rhs, sol);
+  }
+}
+template <int BT>
+static hipError_t launch_warm_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st, const double *x0) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&warm_start_kernel<BT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(warm_start_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a, x0);
+  return hipGetLastError();
+}
+hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st, const double *x0) {
+  switch (BT) {
+    case 1: return launch_warm_t<1>(a, tiles, threads, lds, st, x0);
+    case 2: return launch_warm_t<2>(a, tiles, threads, lds, st, x0);
+    default: return launch_warm_t<4>(a, tiles, threads, lds, st, x0);
+  }
+}
+
+static inline unsigned nblk(size_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
+
+hipError_t launch_interleave(const double *src, double *dst, const int *ids, int nq, int len, int BT, hipStream_t st) {
+  if (!nq || !len) return hipSuccess;
+  hipLaunchKernelGGL(interleave_kernel, dim3(nblk((size_t)nq * len, 256)), dim3(256), 0, st, src, dst, ids, nq, len, BT);
+  return hipGetLastError();
+}
+hipError_t launch_scatter(const double *src, double *dst, const int *map, const int *ids, int nq, int srclen,
+                          int slots, int BT, hipStream_t st) {
+  if (!nq || !slots) return hipSuccess;
+  hipLaunchKernelGGL(scatter_kernel, dim3(nblk((size_t)nq * slots, 256)), dim3(256), 0, st, src, dst, map, ids, nq, srclen, slots, BT);
+  return hipGetLastError();
+}
+hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st) {
+  if (!nq || !len) return hipSuccess;
+  hipLaunchKernelGGL(deinterleave_kernel, dim3(nblk((size_t)nq * len, 256)), dim3(256), 0, st, src, dst, nq, len, BT);
+  return hipGetLastError();
+}
+hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st) {
+  hipLaunchKernelGGL(gather_status_kernel, dim3(nblk((size_t)B, 256)), dim3(256), 0, st, iscal, status, iters, B, BT);
+  return hipGetLastError();
+}
+hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,
+                         const double *rho_vec, const double *dscal, int *changed, int B, int m, int BT,
+                         int scaling, hipStream_t st) {
+  if (!m) return hipSuccess;
+  hipLaunchKernelGGL(bounds_kernel, dim3(nblk((size_t)B * m, 256)), dim3(256), 0, st, gl, gu, l, u, Esc, rho_vec, dscal, changed, B, m, BT, scaling);
+  return hipGetLastError();
+}
+
+}  // namespace miosqp

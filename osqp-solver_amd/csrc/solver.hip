@@ -1,0 +1,827 @@
+// solver.hip -- C-ABI (include/mi_osqp.h) over host_core + kernels.
+//
+// setup(): host analysis + Ruiz scaling + KKT + LDL' per QP (rows E1-E5), upload
+// in tile-interleaved, schedule-ordered layout.  solve(): the whole ADMM loop
+// runs inside admm_kernel; the host only reacts to "rho changed" requests
+// (row E13: numeric refactor on the host, first version) and reads statuses.
+// There is NO CPU solve path: without a gfx950 device setup returns
+// MI_OSQP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mi_osqp.h"
+#include "device_types.h"
+#include "host_core.hpp"
+
+using namespace miosqp;
+
+static thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
+      return MI_OSQP_ERR_DEVICE;                                                         \
+    }                                                                                    \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static int host_threads() {
+  const char *e = getenv("MI_OSQP_HOST_THREADS");
+  int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  return std::max(1, std::min(t, 128));
+}
+
+template <class F>
+static void parallel_for(int count, F &&fn) {
+  int nt = std::min(host_threads(), count);
+  if (nt <= 1) { for (int i = 0; i < count; i++) fn(i, 0); return; }
+  std::atomic<int> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; t++)
+    th.emplace_back([&, t]() { for (int i; (i = next.fetch_add(1)) < count;) fn(i, t); });
+  for (auto &x : th) x.join();
+}
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr; size_t n = 0;
+  int alloc(size_t count) {
+    free();
+    n = count;
+    if (!count) return 0;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return MI_OSQP_ERR_ALLOC; }
+    return 0;
+  }
+  int zero(hipStream_t s) { if (n && hipMemsetAsync(p, 0, n * sizeof(T), s) != hipSuccess) return MI_OSQP_ERR_DEVICE; return 0; }
+  int upload(const std::vector<T> &v) {
+    int rc = alloc(v.size());
+    if (rc) return rc;
+    if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return MI_OSQP_ERR_DEVICE;
+    return 0;
+  }
+  void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DevBuf() { free(); }
+};
+
+struct SchedBufs {
+  DevBuf<uint32_t> lvl, taskA, outA, taskB, outB, idx;
+  DevBuf<int32_t> src;
+  int upload(const Schedule &s) {
+    int rc;
+    if ((rc = lvl.upload(s.lvl)) || (rc = taskA.upload(s.taskA)) || (rc = outA.upload(s.outA)) ||
+        (rc = taskB.upload(s.taskB)) || (rc = outB.upload(s.outB)) || (rc = idx.upload(s.idx)) ||
+        (rc = src.upload(s.src))) return rc;
+    return 0;
+  }
+  SchedDev view(const Schedule &s) const {
+    SchedDev d; d.lvl = lvl.p; d.taskA = taskA.p; d.outA = outA.p; d.taskB = taskB.p; d.outB = outB.p; d.idx = idx.p;
+    d.n_levels = s.n_levels; d.n_slots = s.n_slots; return d;
+  }
+};
+
+struct mi_osqp_batch {
+  Settings st;
+  Analysis an;
+  int B = 0, BT = 1, ntiles = 0, threads = 1024, device = 0;
+  size_t lds = 0;
+  std::vector<QPNumeric> qp;
+  bool host_bounds_stale = false;
+  hipStream_t stream = nullptr;
+  SchedBufs fwd, bwd, chk;
+  DevBuf<uint32_t> pinv;
+  DevBuf<double> fwd_val, bwd_val, chk_val, dinv, x, z, y, q, l, u, rho_vec, rho_inv, Dsc, Dsc_inv, Esc, Esc_inv;
+  DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out;
+  DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
+  DevBuf<int> iscal, tile_iter, flag;
+  DevBuf<double> stage; DevBuf<int> ids;
+  int *h_iscal = nullptr;     // pinned
+  double *h_dscal = nullptr;  // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  mi_osqp_stats stats{};
+  // last-solve accounting
+  int64_t last_total_iters = 0, last_launches = 0, last_refactors = 0;
+  double last_device_s = 0.0, last_refactor_s = 0.0, kernel_ms_sum = 0.0;
+  int64_t kernel_launches = 0;
+  bool solved_once = false;
+  ~mi_osqp_batch() {
+    if (h_iscal) (void)hipHostFree(h_iscal);
+    if (h_dscal) (void)hipHostFree(h_dscal);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+struct mi_osqp_solver { mi_osqp_batch *b = nullptr; };
+
+// ------------------------------------------------------------------ helpers
+
+static Settings to_settings(const mi_osqp_settings *s) {
+  Settings t;
+  if (!s) return t;
+  t.rho = s->rho; t.sigma = s->sigma; t.scaling = s->scaling; t.adaptive_rho = s->adaptive_rho;
+  t.adaptive_rho_interval = s->adaptive_rho_interval; t.adaptive_rho_tolerance = s->adaptive_rho_tolerance;
+  t.max_iter = s->max_iter; t.eps_abs = s->eps_abs; t.eps_rel = s->eps_rel; t.eps_prim_inf = s->eps_prim_inf;
+  t.eps_dual_inf = s->eps_dual_inf; t.alpha = s->alpha; t.scaled_termination = s->scaled_termination;
+  t.check_termination = s->check_termination; t.warm_start = s->warm_start; t.verbose = s->verbose;
+  return t;
+}
+
+static size_t lds_bytes(int N, int BT, int threads) {
+  int nw = threads / 64;
+  return ((size_t)N * BT + (size_t)nw * 14 * BT + 14 * BT) * sizeof(double);
+}
+
+static KernelArgs make_args(mi_osqp_batch *h) {
+  KernelArgs a{};
+  a.n = h->an.n; a.m = h->an.m; a.N = h->an.N; a.B = h->B;
+  a.fwd = h->fwd.view(h->an.fwd); a.bwd = h->bwd.view(h->an.bwd); a.chk = h->chk.view(h->an.chk);
+  a.pinv = h->pinv.p;
+  a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.chk_val = h->chk_val.p; a.dinv = h->dinv.p;
+  a.x = h->x.p; a.z = h->z.p; a.y = h->y.p; a.q = h->q.p; a.l = h->l.p; a.u = h->u.p;
+  a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Dsc = h->Dsc.p; a.Dsc_inv = h->Dsc_inv.p;
+  a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
+  a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.tile_iter = h->tile_iter.p;
+  a.x_out = h->x_out.p; a.y_out = h->y_out.p;
+  const Settings &s = h->st;
+  a.sigma = s.sigma; a.alpha = s.alpha; a.eps_abs = s.eps_abs; a.eps_rel = s.eps_rel;
+  a.eps_prim_inf = s.eps_prim_inf; a.eps_dual_inf = s.eps_dual_inf; a.rho_tolerance = s.adaptive_rho_tolerance;
+  a.check_termination = (int)s.check_termination; a.rho_interval = (int)s.adaptive_rho_interval;
+  a.max_iter = (int)s.max_iter; a.scaled_termination = (int)s.scaled_termination; a.scaling = s.scaling ? 1 : 0;
+  a.adaptive_rho = (int)s.adaptive_rho; a.iter_budget = (int)s.max_iter;
+  return a;
+}
+
+static int ensure_stage(mi_osqp_batch *h, size_t doubles, size_t ints) {
+  int rc;
+  if (h->stage.n < doubles && (rc = h->stage.alloc(doubles))) return rc;
+  if (h->ids.n < ints && (rc = h->ids.alloc(ints))) return rc;
+  return 0;
+}
+
+// upload QP-major host rows [nq][len] into a tile-interleaved device array
+static int upload_rows(mi_osqp_batch *h, const std::vector<double> &rows, const std::vector<int> *ids, int nq,
+                       int len, double *dst) {
+  if (!nq || !len) return 0;
+  int rc = ensure_stage(h, rows.size(), ids ? ids->size() : 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->stage.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (ids) HIPCHK(hipMemcpyAsync(h->ids.p, ids->data(), ids->size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(launch_interleave(h->stage.p, dst, ids ? h->ids.p : nullptr, nq, len, h->BT, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+template <class G>
+static std::vector<double> gather_rows(const std::vector<int> &ids, int len, G &&get) {
+  std::vector<double> rows((size_t)ids.size() * len);
+  for (size_t j = 0; j < ids.size(); j++) { const std::vector<double> &v = get(ids[j]); std::copy(v.begin(), v.begin() + len, rows.begin() + j * len); }
+  return rows;
+}
+
+// upload factors (canonical Lx + Dlinv on the host) of the listed QPs
+static int upload_factors(mi_osqp_batch *h, const std::vector<int> &ids) {
+  const Analysis &an = h->an;
+  int nq = (int)ids.size(), nnzL = an.nnzL(), N = an.N;
+  if (!nq) return 0;
+  std::vector<double> rows = gather_rows(ids, nnzL, [&](int q) -> const std::vector<double> & { return h->qp[q].Lx; });
+  int rc = ensure_stage(h, std::max<size_t>(rows.size(), 1), ids.size());
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (nnzL) {
+    HIPCHK(hipMemcpyAsync(h->stage.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(launch_scatter(h->stage.p, h->fwd_val.p, h->fwd.src.p, h->ids.p, nq, nnzL, an.fwd.n_slots, h->BT, h->stream));
+    HIPCHK(launch_scatter(h->stage.p, h->bwd_val.p, h->bwd.src.p, h->ids.p, nq, nnzL, an.bwd.n_slots, h->BT, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  std::vector<double> drows = gather_rows(ids, N, [&](int q) -> const std::vector<double> & { return h->qp[q].Dlinv; });
+  return upload_rows(h, drows, &ids, nq, N, h->dinv.p);
+}
+
+static int upload_rho(mi_osqp_batch *h, const std::vector<int> &ids) {
+  int m = h->an.m, nq = (int)ids.size(), rc;
+  if (!nq || !m) return 0;
+  std::vector<double> r1 = gather_rows(ids, m, [&](int q) -> const std::vector<double> & { return h->qp[q].rho_vec; });
+  if ((rc = upload_rows(h, r1, &ids, nq, m, h->rho_vec.p))) return rc;
+  std::vector<double> r2 = gather_rows(ids, m, [&](int q) -> const std::vector<double> & { return h->qp[q].rho_inv; });
+  return upload_rows(h, r2, &ids, nq, m, h->rho_inv.p);
+}
+
+// scaled problem data, scalings, scalars of the listed QPs
+static int upload_problem(mi_osqp_batch *h, const std::vector<int> &ids, bool with_matrices) {
+  const Analysis &an = h->an;
+  int n = an.n, m = an.m, nq = (int)ids.size(), rc;
+  if (!nq) return 0;
+  auto up = [&](int len, double *dst, auto get) -> int {
+    std::vector<double> rows = gather_rows(ids, len, get);
+    return upload_rows(h, rows, &ids, nq, len, dst);
+  };
+  if (with_matrices) {
+    int nnzP = an.Pp[n], nnzA = an.Ap[n];
+    std::vector<double> pa((size_t)nq * (nnzP + nnzA));
+    for (int j = 0; j < nq; j++) {
+      const QPNumeric &q = h->qp[ids[j]];
+      std::copy(q.Pv.begin(), q.Pv.end(), pa.begin() + (size_t)j * (nnzP + nnzA));
+      std::copy(q.Av.begin(), q.Av.end(), pa.begin() + (size_t)j * (nnzP + nnzA) + nnzP);
+    }
+    if ((rc = ensure_stage(h, std::max<size_t>(pa.size(), 1), ids.size()))) return rc;
+    HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (!pa.empty()) {
+      HIPCHK(hipMemcpyAsync(h->stage.p, pa.data(), pa.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(launch_scatter(h->stage.p, h->chk_val.p, h->chk.src.p, h->ids.p, nq, nnzP + nnzA, an.chk.n_slots, h->BT, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if ((rc = up(n, h->q.p, [&](int q) -> const std::vector<double> & { return h->qp[q].q; }))) return rc;
+    if ((rc = up(n, h->Dsc.p, [&](int q) -> const std::vector<double> & { return h->qp[q].D; }))) return rc;
+    if ((rc = up(n, h->Dsc_inv.p, [&](int q) -> const std::vector<double> & { return h->qp[q].Dinv; }))) return rc;
+    if ((rc = up(m, h->Esc.p, [&](int q) -> const std::vector<double> & { return h->qp[q].E; }))) return rc;
+    if ((rc = up(m, h->Esc_inv.p, [&](int q) -> const std::vector<double> & { return h->qp[q].Einv; }))) return rc;
+  }
+  if ((rc = up(m, h->l.p, [&](int q) -> const std::vector<double> & { return h->qp[q].l; }))) return rc;
+  if ((rc = up(m, h->u.p, [&](int q) -> const std::vector<double> & { return h->qp[q].u; }))) return rc;
+  return 0;
+}
+
+// write c, cinv, rho of the listed QPs into dscal (read-modify-write via host mirror)
+static int sync_scalars_to_device(mi_osqp_batch *h, const std::vector<int> &ids, bool with_c) {
+  size_t cnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+  for (int q : ids) {
+    double *t = h->h_dscal + (size_t)(q / h->BT) * DS_COUNT * h->BT;
+    int b = q % h->BT;
+    if (with_c) { t[DS_C * h->BT + b] = h->qp[q].c; t[DS_CINV * h->BT + b] = h->qp[q].cinv; }
+    t[DS_RHO * h->BT + b] = h->qp[q].rho;
+    t[DS_RHO_EST * h->BT + b] = h->qp[q].rho;
+  }
+  HIPCHK(hipMemcpy(h->dscal.p, h->h_dscal, cnt * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+static int snapshot(mi_osqp_batch *h) {
+  auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
+    if (dst.n != src.n) { int rc = dst.alloc(src.n); if (rc) return rc; }
+    if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  };
+  int rc;
+  if ((rc = cp(h->fwd_val0, h->fwd_val)) || (rc = cp(h->bwd_val0, h->bwd_val)) || (rc = cp(h->dinv0, h->dinv)) ||
+      (rc = cp(h->rho_vec0, h->rho_vec)) || (rc = cp(h->rho_inv0, h->rho_inv)) || (rc = cp(h->dscal0, h->dscal))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// download scaled l,u from the device into the host mirrors (after device-side bound updates)
+static int sync_bounds_to_host(mi_osqp_batch *h) {
+  if (!h->host_bounds_stale) return 0;
+  int m = h->an.m, B = h->B, rc;
+  if ((rc = ensure_stage(h, (size_t)B * m + 1, 0))) return rc;
+  std::vector<double> tmp((size_t)B * m);
+  for (int which = 0; which < 2; which++) {
+    HIPCHK(launch_deinterleave(which ? h->u.p : h->l.p, h->stage.p, B, m, h->BT, h->stream));
+    HIPCHK(hipMemcpyAsync(tmp.data(), h->stage.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < B; q++) {
+      std::vector<double> &dst = which ? h->qp[q].u : h->qp[q].l;
+      std::copy(tmp.begin() + (size_t)q * m, tmp.begin() + (size_t)(q + 1) * m, dst.begin());
+    }
+  }
+  h->host_bounds_stale = false;
+  return 0;
+}
+
+static int reset_solve_state(mi_osqp_batch *h, bool cold) {
+  int rc;
+  // statuses: UNSOLVED, not done (padding lanes of the last tile stay done)
+  size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT;
+  for (size_t k = 0; k < icnt; k++) h->h_iscal[k] = 0;
+  for (int t = 0; t < h->ntiles; t++)
+    for (int b = 0; b < h->BT; b++) {
+      int *p = h->h_iscal + (size_t)t * IS_COUNT * h->BT;
+      p[IS_STATUS * h->BT + b] = -10;
+      p[IS_DONE * h->BT + b] = (t * h->BT + b >= h->B) ? 1 : 0;
+    }
+  HIPCHK(hipMemcpyAsync(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if ((rc = h->tile_iter.zero(h->stream))) return rc;
+  if (cold) { if ((rc = h->x.zero(h->stream)) || (rc = h->z.zero(h->stream)) || (rc = h->y.zero(h->stream))) return rc; }
+  return 0;
+}
+
+// ------------------------------------------------------------------- setup
+
+static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
+                            const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai,
+                            const double *Av, const double *l, const double *u, int64_t device) {
+  double t0 = now_s();
+  if (B <= 0 || !Pp || !Ap || (m > 0 && (!l || !u)) || (Pp[n] > 0 && !Pv) || (Ap[n] > 0 && !Av)) return MI_OSQP_ERR_INVALID_DATA;
+  if (validate_settings(h->st)) return MI_OSQP_ERR_INVALID_SETTINGS;
+  if (h->st.adaptive_rho && !h->st.adaptive_rho_interval)   // deterministic "auto" (upstream non-PROFILING rule)
+    h->st.adaptive_rho_interval = h->st.check_termination ? 4 * h->st.check_termination : 100;
+  for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an);
+  if (rc) return rc;
+  const Analysis &an = h->an;
+  h->B = (int)B;
+  // ---- device
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible"; return MI_OSQP_ERR_DEVICE; }
+  if (device >= 0) { HIPCHK(hipSetDevice((int)device)); h->device = (int)device; } else HIPCHK(hipGetDevice(&h->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, h->device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_last_error = std::string("device is not gfx950: ") + prop.gcnArchName; return MI_OSQP_ERR_DEVICE; }
+  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  // ---- tile shape
+  const char *et = getenv("MI_OSQP_TILE"), *eth = getenv("MI_OSQP_THREADS");
+  h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 1024;
+  int BT = B >= 768 ? 4 : (B >= 384 ? 2 : 1);
+  if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
+  const size_t lds_cap = 160 * 1024;
+  while (BT > 1 && lds_bytes(an.N, BT, h->threads) > lds_cap) BT /= 2;
+  if (lds_bytes(an.N, BT, h->threads) > lds_cap) {
+    g_last_error = "KKT dimension too large for the LDS-resident solve vector (n+m <= ~20000 supported)";
+    return MI_OSQP_ERR_ALLOC;
+  }
+  h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT); h->lds = lds_bytes(an.N, BT, h->threads);
+  // ---- device arrays
+  size_t T = (size_t)h->ntiles * BT;
+  if ((rc = h->fwd.upload(an.fwd)) || (rc = h->bwd.upload(an.bwd)) || (rc = h->chk.upload(an.chk))) return rc;
+  { std::vector<uint32_t> pv(an.pinv.begin(), an.pinv.end()); if ((rc = h->pinv.upload(pv))) return rc; }
+#define ALLOC(buf, len) if ((rc = h->buf.alloc((size_t)(len) * T)) || (rc = h->buf.zero(h->stream))) return rc
+  ALLOC(fwd_val, an.fwd.n_slots); ALLOC(bwd_val, an.bwd.n_slots); ALLOC(chk_val, an.chk.n_slots); ALLOC(dinv, an.N);
+  ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
+  ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
+  ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
+#undef ALLOC
+  if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->tile_iter.alloc(h->ntiles)) || (rc = h->flag.alloc(4))) return rc;
+  if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
+  if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
+  HIPCHK(hipHostMalloc((void **)&h->h_iscal, (size_t)IS_COUNT * T * sizeof(int)));
+  HIPCHK(hipHostMalloc((void **)&h->h_dscal, (size_t)DS_COUNT * T * sizeof(double)));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double t1 = now_s();
+  // ---- per-QP numeric (host threads), uploaded in chunks to bound host memory
+  h->qp.resize(B);
+  int nnzPin = (int)Pp[n], nnzA = (int)Ap[n];
+  std::atomic<int> fail{0};
+  const int CH = 128;
+  std::vector<std::vector<double>> works(host_threads());
+  double t_factor = 0.0, t_upload = 0.0;
+  for (int c0 = 0; c0 < B; c0 += CH) {
+    int c1 = (int)std::min<int64_t>(B, c0 + CH);
+    double ta = now_s();
+    parallel_for(c1 - c0, [&](int k, int tid) {
+      int qi = c0 + k;
+      QPNumeric &Q = h->qp[qi];
+      load_qp(an, h->st, Pv + (size_t)qi * nnzPin, q ? q + (size_t)qi * n : nullptr, Av + (size_t)qi * nnzA,
+              l + (size_t)qi * m, u + (size_t)qi * m, Q);
+      if (h->st.scaling) scale_qp(an, h->st, Q);
+      set_rho_vec(an, h->st, Q);
+      int r = factor_qp(an, h->st, Q, works[tid]);
+      if (r) fail.store(r);
+    });
+    double tb = now_s();
+    t_factor += tb - ta;
+    if (fail.load()) return fail.load();
+    std::vector<int> ids(c1 - c0);
+    for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
+    if ((rc = upload_factors(h, ids)) || (rc = upload_rho(h, ids)) || (rc = upload_problem(h, ids, true))) return rc;
+    for (int qi = c0; qi < c1; qi++) { std::vector<double>().swap(h->qp[qi].Lx); }
+    t_upload += now_s() - tb;
+  }
+  {
+    std::vector<int> all(B);
+    for (int i = 0; i < B; i++) all[i] = i;
+    size_t cnt = (size_t)DS_COUNT * T;
+    for (size_t k = 0; k < cnt; k++) h->h_dscal[k] = 0.0;
+    HIPCHK(hipMemcpy(h->dscal.p, h->h_dscal, cnt * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = sync_scalars_to_device(h, all, true))) return rc;
+  }
+  if ((rc = reset_solve_state(h, true))) return rc;
+  if ((rc = snapshot(h))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  mi_osqp_stats &s = h->stats;
+  s.n = n; s.m = m; s.N = an.N; s.batch = B; s.tile = BT; s.n_tiles = h->ntiles;
+  s.nnz_P_triu = an.Pp[n]; s.nnz_A = nnzA; s.nnz_KKT = an.nnzK(); s.nnz_L = an.nnzL();
+  s.n_supernodes = (int64_t)an.sn_start.size() - 1; s.n_blocks = (int64_t)an.chunk_start.size() - 1;
+  s.fwd_levels = an.fwd.n_levels; s.bwd_levels = an.bwd.n_levels;
+  s.fwd_slots = an.fwd.n_slots; s.bwd_slots = an.bwd.n_slots; s.chk_slots = an.chk.n_slots;
+  s.lds_bytes = (int64_t)h->lds; s.threads_per_block = h->threads;
+  s.setup_seconds_host = t1 - t0; s.setup_seconds_factor = t_factor; s.setup_seconds_upload = t_upload;
+  return MI_OSQP_OK;
+}
+
+// ------------------------------------------------------------------- solve
+
+static int refactor_flagged(mi_osqp_batch *h, const std::vector<int> &ids) {
+  if (ids.empty()) return 0;
+  const Analysis &an = h->an;
+  int rc;
+  if ((rc = sync_bounds_to_host(h))) return rc;
+  std::vector<std::vector<double>> works(host_threads());
+  std::atomic<int> fail{0};
+  parallel_for((int)ids.size(), [&](int k, int tid) {
+    QPNumeric &Q = h->qp[ids[k]];
+    int r = factor_qp(an, h->st, Q, works[tid]);
+    if (r) fail.store(r);
+  });
+  if (fail.load()) return fail.load();
+  if ((rc = upload_factors(h, ids)) || (rc = upload_rho(h, ids))) return rc;
+  for (int q : ids) std::vector<double>().swap(h->qp[q].Lx);
+  return 0;
+}
+
+static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream) {
+  hipStream_t keep = h->stream;
+  struct Restore { mi_osqp_batch *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, keep};
+  if (user_stream) h->stream = user_stream;
+  int rc;
+  if ((rc = reset_solve_state(h, !h->st.warm_start))) return rc;
+  KernelArgs a = make_args(h);
+  if (d_x_out) a.x_out = d_x_out;
+  h->last_total_iters = h->last_launches = h->last_refactors = 0;
+  h->last_device_s = h->last_refactor_s = 0.0;
+  size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  const int BT = h->BT;
+  for (int guard = 0; guard < 100000; guard++) {
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(launch_admm(a, BT, h->ntiles, h->threads, h->lds, h->stream));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
+    bool all_done = true;
+    std::vector<int> ref;
+    for (int qi = 0; qi < h->B; qi++) {
+      const int *t = h->h_iscal + (size_t)(qi / BT) * IS_COUNT * BT;
+      if (!t[IS_DONE * BT + qi % BT]) all_done = false;
+      if (t[IS_NEED_REFACTOR * BT + qi % BT]) ref.push_back(qi);
+    }
+    if (!ref.empty()) {
+      double tr = now_s();
+      HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
+      for (int qi : ref) {
+        double rho_new = h->h_dscal[(size_t)(qi / BT) * DS_COUNT * BT + DS_RHO * BT + qi % BT];
+        apply_rho(h->an, h->qp[qi], rho_new);
+        h->h_iscal[(size_t)(qi / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + qi % BT] = 0;
+      }
+      if ((rc = refactor_flagged(h, ref))) return rc;
+      HIPCHK(hipMemcpy(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice));
+      h->last_refactors += (int64_t)ref.size();
+      h->last_refactor_s += now_s() - tr;
+    }
+    if (all_done) break;
+  }
+  for (int qi = 0; qi < h->B; qi++)
+    h->last_total_iters += h->h_iscal[(size_t)(qi / BT) * IS_COUNT * BT + IS_ITER * BT + qi % BT];
+  h->solved_once = true;
+  return MI_OSQP_OK;
+}
+
+// ---------------------------------------------------------------- C entry points
+
+extern "C" {
+
+void mi_osqp_default_settings(mi_osqp_settings *s) {
+  if (!s) return;
+  s->rho = 0.1; s->sigma = 1e-6; s->scaling = 10; s->adaptive_rho = 1; s->adaptive_rho_interval = 0;
+  s->adaptive_rho_tolerance = 5.0; s->max_iter = 4000; s->eps_abs = 1e-3; s->eps_rel = 1e-3;
+  s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4; s->alpha = 1.6; s->scaled_termination = 0;
+  s->check_termination = 25; s->warm_start = 1; s->verbose = 0;
+}
+
+const char *mi_osqp_exit_code_name(int64_t c) {
+  static const char *names[] = {"kOptimal", "kPrimalInfeasible", "kDualInfeasible", "kOptimalInaccurate",
+                                "kPrimalInfeasibleInaccurate", "kDualInfeasibleInaccurate", "kMaxIterations",
+                                "kInterrupted", "kTimeLimitReached", "kNonConvex", "kUnknown"};
+  return (c >= 0 && c <= 10) ? names[c] : "kUnknown";
+}
+const char *mi_osqp_error_name(int64_t e) {
+  static const char *names[] = {"ok", "invalid data", "invalid settings", "sparsity pattern changed",
+                                "non-convex problem / KKT inertia", "device error", "null argument", "allocation / size"};
+  return (e >= 0 && e <= 7) ? names[e] : "unknown";
+}
+const char *mi_osqp_version(void) { return "mi-osqp 0.1 (gfx950)"; }
+const char *mi_osqp_last_error(void) { return g_last_error.c_str(); }
+
+static int64_t exit_code_of(int status) {
+  switch (status) {
+    case 1: return MI_OSQP_EXIT_OPTIMAL;
+    case 2: return MI_OSQP_EXIT_OPTIMAL_INACCURATE;
+    case -3: return MI_OSQP_EXIT_PRIMAL_INFEASIBLE;
+    case 3: return MI_OSQP_EXIT_PRIMAL_INFEASIBLE_INACCURATE;
+    case -4: return MI_OSQP_EXIT_DUAL_INFEASIBLE;
+    case 4: return MI_OSQP_EXIT_DUAL_INFEASIBLE_INACCURATE;
+    case -2: return MI_OSQP_EXIT_MAX_ITERATIONS;
+    case -5: return MI_OSQP_EXIT_INTERRUPTED;
+    case -6: return MI_OSQP_EXIT_TIME_LIMIT_REACHED;
+    case -7: return MI_OSQP_EXIT_NON_CONVEX;
+    default: return MI_OSQP_EXIT_UNKNOWN;
+  }
+}
+
+int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
+                        const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai, const double *Av,
+                        const double *l, const double *u, const mi_osqp_settings *settings, int64_t device) {
+  if (!out) return MI_OSQP_ERR_NULL;
+  *out = nullptr;
+  if (n <= 0 || m < 0) return MI_OSQP_ERR_INVALID_DATA;
+  mi_osqp_batch *h = new (std::nothrow) mi_osqp_batch();
+  if (!h) return MI_OSQP_ERR_ALLOC;
+  h->st = to_settings(settings);
+  int rc = batch_setup_impl(h, B, n, m, Pp, Pi, Pv, q, Ap, Ai, Av, l, u, device);
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return MI_OSQP_OK;
+}
+
+void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }
+
+int mi_osqp_batch_solve(mi_osqp_batch *h) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  return solve_impl(h, nullptr, nullptr);
+}
+
+int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  int rc = solve_impl(h, d_x_out, (hipStream_t)stream);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  if (d_x_out) {   // keep the internal copy coherent for get_primal()
+    HIPCHK(hipMemcpyAsync(h->x_out.p, d_x_out, (size_t)h->B * h->an.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  }
+  if (d_status || d_iters) HIPCHK(launch_gather_status(h->iscal.p, d_status, d_iters, h->B, h->BT, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x) {
+  if (!h || !x) return MI_OSQP_ERR_NULL;
+  HIPCHK(hipMemcpy(x, h->x_out.p, (size_t)h->B * h->an.n * sizeof(double), hipMemcpyDeviceToHost));
+  return MI_OSQP_OK;
+}
+int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y) {
+  if (!h || !y) return MI_OSQP_ERR_NULL;
+  if (h->an.m) HIPCHK(hipMemcpy(y, h->y_out.p, (size_t)h->B * h->an.m * sizeof(double), hipMemcpyDeviceToHost));
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info) {
+  if (!h || !info) return MI_OSQP_ERR_NULL;
+  size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
+  const int BT = h->BT;
+  for (int q = 0; q < h->B; q++) {
+    const int *ti = h->h_iscal + (size_t)(q / BT) * IS_COUNT * BT;
+    const double *td = h->h_dscal + (size_t)(q / BT) * DS_COUNT * BT;
+    int b = q % BT;
+    mi_osqp_info &I = info[q];
+    I.iter = ti[IS_ITER * BT + b]; I.status_val = ti[IS_STATUS * BT + b]; I.exit_code = exit_code_of((int)I.status_val);
+    I.obj_val = td[DS_OBJ * BT + b]; I.pri_res = td[DS_PRI_RES * BT + b]; I.dua_res = td[DS_DUA_RES * BT + b];
+    I.rho_updates = ti[IS_RHO_UPDATES * BT + b]; I.rho_estimate = td[DS_RHO_EST * BT + b]; I.rho = td[DS_RHO * BT + b];
+  }
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st) {
+  if (!h || !st) return MI_OSQP_ERR_NULL;
+  *st = h->stats;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64_t *kernel_launches, double *device_seconds,
+                                   double *refactor_seconds, int64_t *refactor_count) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (total_iters) *total_iters = h->last_total_iters;
+  if (kernel_launches) *kernel_launches = h->last_launches;
+  if (device_seconds) *device_seconds = h->last_device_s;
+  if (refactor_seconds) *refactor_seconds = h->last_refactor_s;
+  if (refactor_count) *refactor_count = h->last_refactors;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launches) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (avg_ms) *avg_ms = h->kernel_launches ? h->kernel_ms_sum / (double)h->kernel_launches : 0.0;
+  if (launches) *launches = h->kernel_launches;
+  h->kernel_ms_sum = 0.0; h->kernel_launches = 0;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_reset(mi_osqp_batch *h) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
+    if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+  };
+  int rc;
+  if ((rc = cp(h->fwd_val, h->fwd_val0)) || (rc = cp(h->bwd_val, h->bwd_val0)) || (rc = cp(h->dinv, h->dinv0)) ||
+      (rc = cp(h->rho_vec, h->rho_vec0)) || (rc = cp(h->rho_inv, h->rho_inv0)) || (rc = cp(h->dscal, h->dscal0))) return rc;
+  if ((rc = reset_solve_state(h, true))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  // host mirrors of rho follow the snapshot
+  if ((rc = sync_bounds_to_host(h))) return rc;
+  size_t dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
+  for (int q = 0; q < h->B; q++) {
+    h->qp[q].rho = h->h_dscal[(size_t)(q / h->BT) * DS_COUNT * h->BT + DS_RHO * h->BT + q % h->BT];
+    set_rho_vec(h->an, h->st, h->qp[q]);
+  }
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
+  if (!h || !x) return MI_OSQP_ERR_NULL;
+  h->st.warm_start = 1;
+  size_t cnt = (size_t)h->B * h->an.n;
+  int rc = ensure_stage(h, cnt, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h->stage.p, x, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  KernelArgs a = make_args(h);
+  HIPCHK(launch_warm_start(a, h->BT, h->ntiles, h->threads, h->lds, h->stream, h->stage.p));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u) {
+  if (!h || !l || !u) return MI_OSQP_ERR_NULL;
+  const Analysis &an = h->an;
+  int m = an.m, B = h->B, rc;
+  for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  h->host_bounds_stale = false;   // host copy becomes authoritative
+  std::vector<int> changed;
+  for (int q = 0; q < B; q++) {
+    QPNumeric &Q = h->qp[q];
+    for (int i = 0; i < m; i++) {
+      Q.l[i] = std::max(l[(size_t)q * m + i], -kInfty); Q.u[i] = std::min(u[(size_t)q * m + i], kInfty);
+      if (h->st.scaling) { Q.l[i] *= Q.E[i]; Q.u[i] *= Q.E[i]; }
+    }
+    if (refresh_rho_types(an, Q)) changed.push_back(q);
+  }
+  std::vector<int> all(B);
+  for (int i = 0; i < B; i++) all[i] = i;
+  if ((rc = upload_problem(h, all, false))) return rc;
+  if ((rc = refactor_flagged(h, changed))) return rc;
+  if (!changed.empty() && (rc = snapshot(h))) return rc;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream) {
+  if (!h || !d_l || !d_u) return MI_OSQP_ERR_NULL;
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  int m = h->an.m, B = h->B;
+  if (!m) return MI_OSQP_OK;
+  // pass 1: validate + detect constraint-type changes without writing
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), s));
+  HIPCHK(launch_bounds(d_l, d_u, h->out1.p /*scratch*/, h->out2.p /*scratch*/, h->Esc.p, h->rho_vec.p, h->dscal.p, h->flag.p, B,
+                       m, h->BT, h->st.scaling ? 1 : 0, s));
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (flag & 2) return MI_OSQP_ERR_INVALID_DATA;
+  if (flag & 1) {   // a row changed type -> needs the refactor path: go through the host
+    std::vector<double> hl((size_t)B * m), hu((size_t)B * m);
+    HIPCHK(hipMemcpy(hl.data(), d_l, hl.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hu.data(), d_u, hu.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return mi_osqp_batch_update_bounds(h, hl.data(), hu.data());
+  }
+  HIPCHK(launch_bounds(d_l, d_u, h->l.p, h->u.p, h->Esc.p, h->rho_vec.p, h->dscal.p, h->flag.p, B, m, h->BT,
+                       h->st.scaling ? 1 : 0, s));
+  HIPCHK(hipStreamSynchronize(s));
+  h->host_bounds_stale = true;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
+  if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
+  const Analysis &an = h->an;
+  int n = an.n, B = h->B, nnzA = an.Ap[n], rc;
+  for (int j = 0; j <= n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
+  for (int k = 0; k < nnzA; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
+  if ((rc = sync_bounds_to_host(h))) return rc;
+  std::vector<std::vector<double>> works(host_threads());
+  std::atomic<int> fail{0};
+  const int CH = 128;
+  for (int c0 = 0; c0 < B; c0 += CH) {
+    int c1 = std::min(B, c0 + CH);
+    parallel_for(c1 - c0, [&](int k, int tid) {
+      int qi = c0 + k;
+      QPNumeric &Q = h->qp[qi];
+      if (h->st.scaling) unscale_qp(an, Q);
+      std::copy(Av + (size_t)qi * nnzA, Av + (size_t)(qi + 1) * nnzA, Q.Av.begin());
+      if (h->st.scaling) scale_qp(an, h->st, Q);
+      int r = factor_qp(an, h->st, Q, works[tid]);
+      if (r) fail.store(r);
+    });
+    if (fail.load()) return fail.load();
+    std::vector<int> ids(c1 - c0);
+    for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
+    if ((rc = upload_factors(h, ids)) || (rc = upload_problem(h, ids, true)) || (rc = sync_scalars_to_device(h, ids, true))) return rc;
+    for (int qi = c0; qi < c1; qi++) std::vector<double>().swap(h->qp[qi].Lx);
+  }
+  return snapshot(h);
+}
+
+int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, double *d_Px, double *d_Aty, double *d_Ax,
+                       void *stream) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  KernelArgs a = make_args(h);
+  HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, h->lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
+  HIPCHK(hipStreamSynchronize(s));
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol, void *stream) {
+  if (!h || !d_rhs || !d_sol) return MI_OSQP_ERR_NULL;
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  KernelArgs a = make_args(h);
+  HIPCHK(launch_kkt_solve(a, h->BT, h->ntiles, h->threads, h->lds, s, d_rhs, d_sol));
+  HIPCHK(hipStreamSynchronize(s));
+  return MI_OSQP_OK;
+}
+
+// ------------------------------------------------------------------ single QP
+
+int mi_osqp_setup(mi_osqp_solver **out, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const double *Pv,
+                  const double *q, const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l,
+                  const double *u, const mi_osqp_settings *settings) {
+  if (!out) return MI_OSQP_ERR_NULL;
+  *out = nullptr;
+  mi_osqp_batch *b = nullptr;
+  int rc = mi_osqp_batch_setup(&b, 1, n, m, Pp, Pi, Pv, q, Ap, Ai, Av, l, u, settings, -1);
+  if (rc) return rc;
+  mi_osqp_solver *s = new (std::nothrow) mi_osqp_solver();
+  if (!s) { delete b; return MI_OSQP_ERR_ALLOC; }
+  s->b = b; *out = s;
+  return MI_OSQP_OK;
+}
+void mi_osqp_free(mi_osqp_solver *h) { if (h) { delete h->b; delete h; } }
+int mi_osqp_update_A(mi_osqp_solver *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
+  return h ? mi_osqp_batch_update_A(h->b, Ap, Ai, Av) : MI_OSQP_ERR_NULL;
+}
+int mi_osqp_update_bounds(mi_osqp_solver *h, const double *l, const double *u) {
+  return h ? mi_osqp_batch_update_bounds(h->b, l, u) : MI_OSQP_ERR_NULL;
+}
+int mi_osqp_warm_start_x(mi_osqp_solver *h, const double *x) { return h ? mi_osqp_batch_warm_start_x(h->b, x) : MI_OSQP_ERR_NULL; }
+int mi_osqp_solve(mi_osqp_solver *h, mi_osqp_info *info) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  int rc = mi_osqp_batch_solve(h->b);
+  if (rc) return rc;
+  if (info) return mi_osqp_batch_get_info(h->b, info);
+  return MI_OSQP_OK;
+}
+int mi_osqp_get_primal(mi_osqp_solver *h, double *x) { return h ? mi_osqp_batch_get_primal(h->b, x) : MI_OSQP_ERR_NULL; }
+int mi_osqp_get_dual(mi_osqp_solver *h, double *y) { return h ? mi_osqp_batch_get_dual(h->b, y) : MI_OSQP_ERR_NULL; }
+int mi_osqp_get_stats(mi_osqp_solver *h, mi_osqp_stats *st) { return h ? mi_osqp_batch_get_stats(h->b, st) : MI_OSQP_ERR_NULL; }
+
+// ------------------------------------------------------ host-only diagnostics
+
+int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const double *Pv,
+                                 const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l,
+                                 const double *u, const mi_osqp_settings *settings, int64_t tile, const double *rhs,
+                                 double *sol_schedule, double *sol_direct, mi_osqp_stats *st) {
+  (void)tile;
+  Settings s = to_settings(settings);
+  if (validate_settings(s)) return MI_OSQP_ERR_INVALID_SETTINGS;
+  Analysis an;
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, an);
+  if (rc) return rc;
+  QPNumeric Q;
+  load_qp(an, s, Pv, nullptr, Av, l, u, Q);
+  if (s.scaling) scale_qp(an, s, Q);
+  set_rho_vec(an, s, Q);
+  std::vector<double> w;
+  if ((rc = factor_qp(an, s, Q, w))) return rc;
+  if (sol_direct) direct_kkt_solve(an, Q, rhs, sol_direct);
+  if (sol_schedule) replay_kkt_solve(an, Q, rhs, sol_schedule);
+  if (st) {
+    memset(st, 0, sizeof(*st));
+    st->n = n; st->m = m; st->N = an.N; st->batch = 1; st->tile = 1; st->n_tiles = 1;
+    st->nnz_P_triu = an.Pp[n]; st->nnz_A = an.Ap[n]; st->nnz_KKT = an.nnzK(); st->nnz_L = an.nnzL();
+    st->n_supernodes = (int64_t)an.sn_start.size() - 1; st->n_blocks = (int64_t)an.chunk_start.size() - 1;
+    st->fwd_levels = an.fwd.n_levels; st->bwd_levels = an.bwd.n_levels;
+    st->fwd_slots = an.fwd.n_slots; st->bwd_slots = an.bwd.n_slots; st->chk_slots = an.chk.n_slots;
+  }
+  return MI_OSQP_OK;
+}
+
+}  // extern "C"
