@@ -1,0 +1,128 @@
+// qp_solver.hpp -- header-only C++17 facade with the method set of the
+// reference's class QPSolver ([REF] /root/reference/src/osqp-wrapper.h:12-60),
+// implemented on the C-ABI of mi_osqp.h instead of google/osqp-cpp.
+//
+//   QPSolver(const QPConstraints&, const QPMatrixSparse& P)   [REF] :16-31
+//   void update(const QPConstraints&)                          [REF] :33-43  (throws std::invalid_argument)
+//   void setWarmStart(const QPVector&)                         [REF] :45-49
+//   std::pair<OsqpExitCode, QPVector> solve()                  [REF] :51-54
+//
+// The reference's types are Eigen types ([REF] src/utils.h:12,15;
+// src/constraints/constraint-builder.h:16).  Eigen is not part of this
+// repository, so the same data contract is expressed with plain containers:
+// CSC, column-major, `long long` indices, double values, +-1e30 = unbounded.
+// Where <Eigen/Sparse> is available, `from_eigen()` adapts the reference's own
+// objects without copying their layout assumptions.
+#pragma once
+
+#include <cassert>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../mi_osqp.h"
+
+namespace miosqp_ref {
+
+constexpr double INF = 1e30;                       // [REF] src/constraints/constraints.h:11
+
+struct QPMatrixSparse {                            // = Eigen::SparseMatrix<double, ColMajor, long long>
+  long long rows = 0, cols = 0;
+  std::vector<long long> outer;                    // cols+1 column pointers
+  std::vector<long long> inner;                    // row indices
+  std::vector<double> values;
+};
+using QPVector = std::vector<double>;              // = Eigen::VectorXd
+using QPConstraints = std::tuple<QPVector, QPMatrixSparse, QPVector>;   // <l, A, u>, [REF] constraint-builder.h:16
+
+enum class OsqpExitCode {                          // osqp-cpp's enum, consumed at [REF] src/gomp-solver.h:40,46-49,68,72,79
+  kOptimal, kPrimalInfeasible, kDualInfeasible, kOptimalInaccurate, kPrimalInfeasibleInaccurate,
+  kDualInfeasibleInaccurate, kMaxIterations, kInterrupted, kTimeLimitReached, kNonConvex, kUnknown
+};
+using ExitCode = OsqpExitCode;                     // [REF] src/utils.h:11
+inline std::string ToString(OsqpExitCode c) { return mi_osqp_exit_code_name(static_cast<int64_t>(c)); }
+
+#if __has_include(<Eigen/Sparse>)
+}  // namespace miosqp_ref
+#include <Eigen/Sparse>
+namespace miosqp_ref {
+template <class EigenSparse>
+inline QPMatrixSparse from_eigen(const EigenSparse &M_) {
+  Eigen::SparseMatrix<double, Eigen::ColMajor, long long> M = M_;
+  M.makeCompressed();
+  QPMatrixSparse r;
+  r.rows = M.rows(); r.cols = M.cols();
+  r.outer.assign(M.outerIndexPtr(), M.outerIndexPtr() + M.cols() + 1);
+  r.inner.assign(M.innerIndexPtr(), M.innerIndexPtr() + M.nonZeros());
+  r.values.assign(M.valuePtr(), M.valuePtr() + M.nonZeros());
+  return r;
+}
+#endif
+
+class QPSolver {
+ public:
+  // `verbose` mirrors settings.verbose = true of the reference (log lines only).
+  QPSolver(const QPConstraints &c, const QPMatrixSparse &P, bool verbose = true,
+           const mi_osqp_settings *custom = nullptr) {
+    const auto &[l, A, u] = c;
+    if (verbose)
+      std::cout << l.size() << ", " << u.size() << ", " << A.cols << ", " << A.rows << ", " << P.rows << ", "
+                << P.cols << std::endl;                                     // [REF] :19
+    mi_osqp_settings s;
+    mi_osqp_default_settings(&s);
+    if (custom) s = *custom;
+    s.verbose = verbose;
+    int rc = MI_OSQP_ERR_INVALID_DATA;
+    if ((long long)l.size() == A.rows && (long long)u.size() == A.rows && P.rows == A.cols && P.cols == A.cols)
+      rc = mi_osqp_setup(&h_, A.cols, A.rows, reinterpret_cast<const int64_t *>(P.outer.data()),
+                         reinterpret_cast<const int64_t *>(P.inner.data()), P.values.data(), nullptr /* q = 0, [REF] :22 */,
+                         reinterpret_cast<const int64_t *>(A.outer.data()), reinterpret_cast<const int64_t *>(A.inner.data()),
+                         A.values.data(), l.data(), u.data(), &s);
+    status_ = rc;
+    assert(rc == MI_OSQP_OK);                                              // [REF] :30 (assert only)
+    n_ = A.cols;
+  }
+  ~QPSolver() { mi_osqp_free(h_); }
+  QPSolver(const QPSolver &) = delete;
+  QPSolver &operator=(const QPSolver &) = delete;
+
+  void update(const QPConstraints &qp_constraints) {
+    const auto &[low, A, upp] = qp_constraints;
+    int rc = mi_osqp_update_A(h_, reinterpret_cast<const int64_t *>(A.outer.data()),
+                              reinterpret_cast<const int64_t *>(A.inner.data()), A.values.data());
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));      // [REF] :36-38
+    rc = mi_osqp_update_bounds(h_, low.data(), upp.data());
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));      // [REF] :40-42
+  }
+
+  void setWarmStart(const QPVector &primal_vector) {
+    int rc = (long long)primal_vector.size() == n_ ? mi_osqp_warm_start_x(h_, primal_vector.data())
+                                                   : (int)MI_OSQP_ERR_INVALID_DATA;
+    std::cout << "STATUS: " << (rc == MI_OSQP_OK ? "OK" : mi_osqp_error_name(rc)) << std::endl;   // [REF] :47
+    assert(rc == MI_OSQP_OK);
+  }
+
+  std::pair<OsqpExitCode, QPVector> solve() {
+    mi_osqp_info info{};
+    QPVector x(n_);
+    int rc = mi_osqp_solve(h_, &info);
+    if (rc != MI_OSQP_OK) return {OsqpExitCode::kUnknown, x};
+    mi_osqp_get_primal(h_, x.data());
+    last_ = info;
+    return {static_cast<OsqpExitCode>(info.exit_code), x};
+  }
+
+  int setup_status() const { return status_; }
+  const mi_osqp_info &last_info() const { return last_; }
+
+ private:
+  mi_osqp_solver *h_ = nullptr;
+  long long n_ = 0;
+  int status_ = 0;
+  mi_osqp_info last_{};
+};
+
+}  // namespace miosqp_ref

@@ -1,0 +1,257 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C-ABI, against the
+oracle on identical (P, q, A, l, u) and identical settings.
+
+Tolerance (BASELINE.json north_star): primal solutions within 1e-6 (inf-norm) at
+the same ADMM tolerance; we additionally require the same exit code and the same
+iteration count, which holds because both sides run the same algorithm with the
+same deterministic rho schedule (differences are fp64 round-off, ~1e-12)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import osqp_solver_amd as M
+from oracle import oracle as O
+from oracle.kkt_check import kkt_residuals, sym_from_any
+from osqp_solver_amd import problems as PR
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_X = 1e-6
+ST2EXIT = {1: 0, -3: 1, -4: 2, 2: 3, 3: 4, 4: 5, -2: 6, -7: 9, -10: 10}
+
+
+def _oracle_batch(pr, idx, **settings):
+    res = []
+    for b in idx:
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, None if pr["q"] is None else pr["q"][b], A, pr["l"][b], pr["u"][b], **settings)
+        st, x = o.solve()
+        res.append((st, x, o.info(), o))
+    return res
+
+
+def _compare(info, x, ref, idx):
+    for k, b in enumerate(idx):
+        st, xo, io, _ = ref[k]
+        assert info[b].status_val == st, (b, info[b].status_val, st)
+        assert info[b].exit_code == ST2EXIT[st]
+        assert info[b].iter == io.iter, (b, info[b].iter, io.iter)
+        assert info[b].rho_updates == io.rho_updates
+        if np.any(np.isnan(xo)):
+            assert np.all(np.isnan(x[b]))
+        else:
+            assert np.max(np.abs(x[b] - xo)) <= TOL_X, (b, np.max(np.abs(x[b] - xo)))
+            assert abs(info[b].pri_res - io.pri_res) <= 1e-6 * (1 + abs(io.pri_res))
+            assert abs(info[b].obj_val - io.obj_val) <= 1e-6 * (1 + abs(io.obj_val))
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4])
+@pytest.mark.parametrize("eps", [1e-3, 1e-8])
+def test_config3_small_batch_matches_oracle(tile, eps, monkeypatch):
+    monkeypatch.setenv("MI_OSQP_TILE", str(tile))
+    B = 10                                        # not a multiple of 4: ragged last tile
+    pr = PR.random_box_qp(B, n=96, mg=64, nnz_per_row=6)
+    kw = dict(eps_abs=eps, eps_rel=eps)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
+    assert s.stats()["tile"] == tile
+    info = s.solve()
+    _compare(info, s.primal(), _oracle_batch(pr, range(B), **kw), range(B))
+    # duals too
+    y = s.dual()
+    for b, (_, _, _, o) in enumerate(_oracle_batch(pr, range(2), **kw)):
+        assert np.max(np.abs(y[b] - o.y)) <= 1e-5
+
+
+def test_config3_full_size_pattern_small_batch():
+    pr = PR.random_box_qp(6)                       # n=512, m=1024 like the headline config
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    info = s.solve()
+    _compare(info, s.primal(), _oracle_batch(pr, range(6)), range(6))
+
+
+def test_golden_fixtures_through_c_abi(qp_fixtures):
+    for name, d in qp_fixtures.items():
+        s = M.QPSolver((d["l"], sp.csc_matrix(d["A"]), d["u"]), sp.csc_matrix(d["P"]), q=d["q"],
+                       eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+        code, x = s.solve()
+        assert M.EXIT_NAMES[code] == d["status"], name
+        if d["x"] is not None:
+            np.testing.assert_allclose(x, d["x"], atol=2e-6, err_msg=name)
+            np.testing.assert_allclose(s.dual(), d["y"], atol=2e-5, err_msg=name)
+        else:
+            assert np.all(np.isnan(x)), name
+
+
+def test_exit_codes_and_nan_solution(qp_fixtures):
+    for name in ("primal_infeasible", "dual_infeasible"):
+        d = qp_fixtures[name]
+        s = M.QPSolver((d["l"], sp.csc_matrix(d["A"]), d["u"]), sp.csc_matrix(d["P"]), q=d["q"])
+        o = O.OracleQPSolver(d["P"], d["q"], d["A"], d["l"], d["u"])
+        st, _ = o.solve()
+        code, x = s.solve()
+        assert code == ST2EXIT[st] and M.EXIT_NAMES[code] == d["status"]
+        assert s.info().iter == o.info().iter and np.all(np.isnan(x))
+    d = qp_fixtures["generic_30x40"]
+    kw = dict(eps_abs=1e-12, eps_rel=1e-12, max_iter=30)
+    s = M.QPSolver((d["l"], sp.csc_matrix(d["A"]), d["u"]), sp.csc_matrix(d["P"]), q=d["q"], **kw)
+    o = O.OracleQPSolver(d["P"], d["q"], d["A"], d["l"], d["u"], **kw)
+    st, xo = o.solve()
+    code, x = s.solve()
+    assert code == ST2EXIT[st] and s.info().iter == 30 and np.max(np.abs(x - xo)) <= TOL_X
+
+
+def test_gomp_config2_qpsolver_call_sequence():
+    """BASELINE config 2 through the reference's call pattern
+    ([REF] src/gomp-solver.h:61-88): ctor, setWarmStart, solve, update, solve."""
+    D, W = 6, 50
+    P, (l, A, u), warm = PR.gomp_qp(D, W, np.zeros(D), np.array([np.pi, 0, 0, 0, 0, 0]))
+    s = M.QPSolver((l, A, u), P)
+    o = O.OracleQPSolver(P, None, A, l, u)
+    s.setWarmStart(warm); o.set_warm_start(warm)
+    code, x = s.solve(); st, xo = o.solve()
+    assert code == ST2EXIT[st] and s.info().iter == o.info().iter
+    assert np.max(np.abs(x - xo)) <= TOL_X
+    # SQP-style update: same pattern, perturbed values and tightened bounds, warm-started re-solve
+    A2 = A.copy(); A2.data = A2.data * (1.0 + 0.01 * np.cos(np.arange(A2.nnz)))
+    l2 = np.where(np.abs(l) < 1e29, l * 0.95, l); u2 = np.where(np.abs(u) < 1e29, u * 0.95, u)
+    s.update((l2, A2, u2)); o.update(l2, A2, u2)
+    code, x = s.solve(); st, xo = o.solve()
+    assert code == ST2EXIT[st] and s.info().iter == o.info().iter
+    assert np.max(np.abs(x - xo)) <= TOL_X
+    with pytest.raises(ValueError):                # pattern change -> std::invalid_argument in the reference
+        A3 = A.tolil(); A3[0, 5] = 1.0
+        s.update((l, A3.tocsc(), u))
+    with pytest.raises(ValueError):
+        s.update((u + 1.0, A, l))
+
+
+def test_gomp_batch_config4_shape_small():
+    pr = PR.gomp_batch(5, 7, 20)
+    s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
+    s.warm_start_x(pr["warm"])
+    info = s.solve()
+    ref = []
+    for b in range(5):
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, None, A, pr["l"][b], pr["u"][b])
+        o.set_warm_start(pr["warm"][b])
+        st, x = o.solve()
+        ref.append((st, x, o.info(), o))
+    _compare(info, s.primal(), ref, range(5))
+
+
+def test_warm_second_solve_and_reset_are_reproducible():
+    pr = PR.random_box_qp(8, n=64, mg=48, nnz_per_row=4)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    i1 = s.solve(); x1 = s.primal()
+    i2 = s.solve(); x2 = s.primal()                # warm: continues from x, z, y, rho (osqp warm_start=1)
+    ref = _oracle_batch(pr, range(8))
+    for b, (_, _, _, o) in enumerate(ref):
+        st, xo = o.solve()
+        assert i2[b].iter == o.info().iter and np.max(np.abs(x2[b] - xo)) <= TOL_X
+    s.reset()
+    i3 = s.solve(); x3 = s.primal()
+    assert [i.iter for i in i3] == [i.iter for i in i1]
+    np.testing.assert_array_equal(x1, x3)           # deterministic reductions: bitwise repeatable
+
+
+def test_ops_spmv_and_kkt_solve():
+    import torch
+    B = 9
+    pr = PR.random_box_qp(B, n=96, mg=64, nnz_per_row=6)
+    n, m = pr["n"], pr["m"]
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], scaling=0)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((B, n)); y = rng.standard_normal((B, m))
+    tx, ty = torch.tensor(x, device="cuda"), torch.tensor(y, device="cuda")
+    Px = torch.empty(B, n, dtype=torch.float64, device="cuda"); Aty = torch.empty_like(Px)
+    Ax = torch.empty(B, m, dtype=torch.float64, device="cuda")
+    s.spmv_device(tx, ty, Px, Aty, Ax)
+    for b in range(B):
+        P, A = PR.qp_matrices(pr, b)
+        Pf = sym_from_any(P)
+        np.testing.assert_allclose(Px[b].cpu().numpy(), Pf @ x[b], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Aty[b].cpu().numpy(), A.T @ y[b], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(Ax[b].cpu().numpy(), A @ x[b], rtol=0, atol=1e-12)
+    # KKT solve with scaling on, against the oracle's independent factor
+    s2 = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    rhs = rng.standard_normal((B, n + m))
+    trhs = torch.tensor(rhs, device="cuda"); sol = torch.empty_like(trhs)
+    s2.kkt_solve_device(trhs, sol)
+    for b in range(B):
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, pr["q"][b], A, pr["l"][b], pr["u"][b])
+        ref = o.kkt_solve(rhs[b])
+        assert np.max(np.abs(sol[b].cpu().numpy() - ref)) <= 1e-9 * np.max(np.abs(ref))
+
+
+def test_device_resident_io_matches_host_io():
+    import torch
+    B = 12
+    pr = PR.random_box_qp(B, n=64, mg=48, nnz_per_row=4)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    l2, u2 = pr["l"] * 0.8, pr["u"] * 0.7
+    s.update_bounds(l2, u2)
+    ih = s.solve(); xh = s.primal()
+    s2 = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    s2.update_bounds_device(torch.tensor(l2, device="cuda"), torch.tensor(u2, device="cuda"))
+    xd = torch.empty(B, pr["n"], dtype=torch.float64, device="cuda")
+    st = torch.empty(B, dtype=torch.int32, device="cuda"); it = torch.empty_like(st)
+    s2.solve_device(xd, st, it)
+    np.testing.assert_array_equal(xd.cpu().numpy(), xh)
+    assert it.cpu().tolist() == [i.iter for i in ih] and st.cpu().tolist() == [i.status_val for i in ih]
+    # and the oracle on the updated bounds
+    prn = dict(pr, l=l2, u=u2)
+    _compare(ih, xh, _oracle_batch(prn, range(4)), range(4))
+    with pytest.raises(M.MiOsqpError):
+        s2.update_bounds_device(torch.tensor(u2 + 1, device="cuda"), torch.tensor(l2, device="cuda"))
+
+
+def test_headline_config_properties_full_size():
+    """BASELINE config 3 at full size (B=1024, n=512, m=1024): size-independent
+    properties for every QP + oracle parity on a sample."""
+    B = 1024
+    pr = PR.random_box_qp(B)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    info = s.solve()
+    x, y = s.primal(), s.dual()
+    assert all(i.status_val == 1 for i in info)
+    for b in range(B):
+        P, A = PR.qp_matrices(pr, b)
+        Pf = sym_from_any(P)
+        Ax = A @ x[b]
+        viol = max(np.max(pr["l"][b] - Ax), np.max(Ax - pr["u"][b]), 0.0)
+        # ||z - Ax|| >= bound violation, and termination enforced pri_res < eps_prim
+        assert viol <= info[b].pri_res + 1e-12
+        assert info[b].pri_res <= 1e-3 + 1e-3 * max(np.max(np.abs(Ax)), 1.0) * 2
+        Pxv, Aty = Pf @ x[b], A.T @ y[b]
+        dres = np.max(np.abs(Pxv + pr["q"][b] + Aty))
+        assert abs(dres - info[b].dua_res) <= 1e-9 * (1 + dres)         # reported residual is the true one
+        assert dres <= 1e-3 + 1e-3 * max(np.max(np.abs(Pxv)), np.max(np.abs(Aty)), np.max(np.abs(pr["q"][b])))
+        assert info[b].iter % 25 == 0 and 25 <= info[b].iter <= 4000
+    sample = [0, 1, 2, 3, 511, 1023]
+    _compare(info, x, _oracle_batch(pr, sample), sample)
+    st = s.stats()
+    assert st["tile"] == 4 and st["n_tiles"] == 256
+
+
+def test_cpp_facade_example_runs(tmp_path):
+    exe = tmp_path / "solver_example"
+    libdir = os.path.join(ROOT, "osqp-solver_amd")
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "solver_example.cpp"),
+           "-o", str(exe), "-L" + libdir, "-lmi_osqp", "-Wl,-rpath," + libdir]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "3, 3, 2, 3, 2, 2" and "STATUS: OK" in lines[1]
+    assert lines[2] == "kOptimal" and "update refused" in lines[-1]
+    x = [float(v) for v in lines[3].split()[2:4]]
+    # q = 0: minimise 1/2 x'Px on x0+x1=1, 0<=x<=0.7 -> x = (0.3, 0.7) by the same active set
+    P = np.array([[4.0, 1], [1, 2]]); A = np.array([[1.0, 1], [1, 0], [0, 1]])
+    o = O.OracleQPSolver(P, None, A, [1, 0, 0], [1, 0.7, 0.7]); o.set_warm_start([0.5, 0.5])
+    _, xo = o.solve()
+    assert np.max(np.abs(np.array(x) - xo)) <= 2e-6

@@ -1,0 +1,54 @@
+"""CPU: host logic of the product -- ordering, symbolic + left-looking LDL',
+Ruiz scaling, and the DEVICE schedules replayed sequentially on the host
+(mi_osqp_debug_host_kkt_solve) -- against the oracle's independent factor."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import osqp_solver_amd as M
+from oracle import oracle as O
+from osqp_solver_amd import problems as PR
+
+
+def _cases():
+    pr = PR.random_box_qp(1, n=64, mg=48, nnz_per_row=4)
+    P, A = PR.qp_matrices(pr, 0)
+    yield "box64", P, A, pr["l"][0], pr["u"][0]
+    pr = PR.random_box_qp(1)
+    P, A = PR.qp_matrices(pr, 0)
+    yield "config3", P, A, pr["l"][0], pr["u"][0]
+    P, (l, A, u), _ = PR.gomp_qp(6, 50, np.zeros(6), np.ones(6))
+    yield "gomp6x50", P, A, l, u
+    P, (l, A, u), _ = PR.gomp_qp(3, 5, np.zeros(3), np.ones(3))
+    yield "gomp3x5", P, A, l, u
+    # degenerate shapes: one variable / one row; diagonal KKT; empty P
+    yield "1x1", sp.csc_matrix([[2.0]]), sp.csc_matrix([[1.0]]), np.array([-1.0]), np.array([1.0])
+    yield "diag", sp.eye(5).tocsc(), sp.eye(5).tocsc(), -np.ones(5), np.ones(5)
+    yield "emptyP", sp.csc_matrix((4, 4)), sp.csc_matrix(np.vstack([np.eye(4), np.ones((1, 4))])), -np.ones(5), np.ones(5)
+    # dense-ish: one big supernode, exercises multi-chunk phase B
+    rng = np.random.default_rng(3)
+    G = rng.standard_normal((40, 40)); Pd = sp.csc_matrix(np.triu(G @ G.T + np.eye(40)))
+    yield "dense40", Pd, sp.csc_matrix(rng.standard_normal((30, 40))), -np.ones(30), np.ones(30)
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+@pytest.mark.parametrize("scaling", [10, 0])
+def test_schedule_replay_matches_direct_and_oracle(case, scaling):
+    name, P, A, l, u = case
+    n, m = A.shape[1], A.shape[0]
+    rhs = np.random.default_rng(5).standard_normal(n + m)
+    s_sched, s_direct, st = M.debug_host_kkt_solve(P, A, l, u, rhs, scaling=scaling)
+    scale = np.max(np.abs(s_direct))
+    assert np.max(np.abs(s_sched - s_direct)) <= 1e-8 * scale, name
+    o = O.OracleQPSolver(P, None, A, l, u, scaling=scaling)
+    ref = o.kkt_solve(rhs)
+    assert np.max(np.abs(ref - s_direct)) <= 1e-8 * np.max(np.abs(ref)), name
+    assert st["nnz_L"] >= st["nnz_KKT"] - st["N"] and st["fwd_levels"] >= 1
+    assert st["fwd_slots"] >= st["nnz_L"] and st["bwd_slots"] >= st["nnz_L"]
+
+
+def test_nonconvex_is_refused():
+    P = sp.csc_matrix(-np.eye(3)); A = sp.eye(3).tocsc()
+    with pytest.raises(M.MiOsqpError) as e:
+        M.debug_host_kkt_solve(P, A, -np.ones(3), np.ones(3), np.ones(6))
+    assert e.value.code == 4
