@@ -154,11 +154,7 @@ def main():
                            "bytes_per_qp_iteration": ab["per_qp_iter"]}
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle as O
-            cores = os.cpu_count() or 1
-            try:
-                cores = len(os.sched_getaffinity(0))
-            except Exception:
-                pass
+            cores = M.host_cores()             # min(affinity, cgroup quota): the box shows 256 CPUs, grants ~16
             sample = int(min(B, max(32, 8 * cores)))
             r = O.batch_solve(pr["P"], pr["Px"][:sample], pr["q"][:sample], pr["A"], pr["Ax"][:sample],
                               pr["l"][:sample], pr["u"][:sample], threads=cores, native=True)

@@ -10,6 +10,16 @@ import os
 
 import numpy as np
 
+# torch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Whichever is
+# loaded first wins for the whole process, and torch cannot initialise on top of
+# the system one -- so when torch is installed it must be imported before
+# libmi_osqp.so is dlopen'ed.  torch is plumbing here (device tensors, streams,
+# torch.distributed); the library itself does not need it.
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    torch = None
+
 from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -103,6 +113,29 @@ def lib():
                                                    C.POINTER(Settings), C.c_int64, dp, dp, dp, C.POINTER(Stats)]
         _LIB = L
     return _LIB
+
+
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(round(int(quota) / int(period)))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, int(round(q / p))))
+    except Exception:
+        pass
+    return n
 
 
 def default_settings(**kw):

@@ -40,10 +40,28 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// cores this process may use: min(hardware threads, cgroup CPU quota); the GPU
+// boxes expose 256 logical CPUs but grant a quota of ~16
 static int host_threads() {
+  static int cached = 0;
+  if (cached) return cached;
   const char *e = getenv("MI_OSQP_HOST_THREADS");
-  int t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-  return std::max(1, std::min(t, 128));
+  int t = (int)std::thread::hardware_concurrency();
+  if (e) t = atoi(e);
+  else {
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64]; long long period = 0;
+      if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0)
+        t = std::min<long long>(t, std::max<long long>(1, (atoll(q) + period / 2) / period));
+      fclose(f);
+    }
+    long long q1 = -1, p1 = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lld", &q1) != 1) q1 = -1; fclose(f); }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lld", &p1) != 1) p1 = 0; fclose(f); }
+    if (q1 > 0 && p1 > 0) t = std::min<long long>(t, std::max<long long>(1, (q1 + p1 / 2) / p1));
+  }
+  cached = std::max(1, std::min(t, 128));
+  return cached;
 }
 
 template <class F>
