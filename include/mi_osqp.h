@@ -185,6 +185,10 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y,
 /* One KKT solve per QP with the current factor: sol = K^-1 rhs, [B][n+m]
  * (row E7: permute, level-scheduled L solve, D^-1, L' solve, un-permute). */
 int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol, void *stream);
+/* Row E13 as an op: rebuild every QP's KKT factor ON THE DEVICE from the current
+ * scaled data and rho vector (batched block LDL'), scatter it into the solve
+ * schedules.  solve() calls the same kernel for the QPs whose rho changed. */
+int mi_osqp_batch_refactor_device(mi_osqp_batch *h);
 /* average duration (ms) of the last `iterate` launches measured with HIP events
  * on the launch stream, and their count (bench.py's roofline leg). */
 int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launches);
@@ -200,6 +204,15 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m,
                                  int64_t tile, const double *rhs /*[n+m], scaled space*/,
                                  double *sol_schedule /*[n+m]*/, double *sol_direct /*[n+m]*/,
                                  mi_osqp_stats *st);
+
+/* Host interpreter of the DEVICE block refactorisation (row E13) against the
+ * host left-looking factor: max relative differences of L and D^-1, and
+ * counts[4] = {blocks, triples, storage doubles per QP, levels}. */
+int mi_osqp_debug_host_block_factor(int64_t n, int64_t m,
+                                    const int64_t *P_colptr, const int64_t *P_rowidx, const double *P_val,
+                                    const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                                    const double *l, const double *u, const mi_osqp_settings *settings,
+                                    double *max_rel_diff_L, double *max_rel_diff_Dinv, int64_t *counts);
 
 #ifdef __cplusplus
 }

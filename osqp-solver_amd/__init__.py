@@ -96,6 +96,7 @@ def lib():
         L.mi_osqp_batch_update_bounds_device.argtypes = [vp, vp, vp, vp]
         L.mi_osqp_batch_solve_device.argtypes = [vp, vp, vp, vp, vp]
         L.mi_osqp_batch_reset.argtypes = [vp]
+        L.mi_osqp_batch_refactor_device.argtypes = [vp]
         L.mi_osqp_batch_last_solve_stats.argtypes = [vp, ip, ip, dp, dp, ip]
         L.mi_osqp_batch_spmv.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.mi_osqp_batch_kkt_solve.argtypes = [vp, vp, vp, vp]
@@ -111,6 +112,8 @@ def lib():
         L.mi_osqp_free.argtypes = [vp]; L.mi_osqp_free.restype = None
         L.mi_osqp_debug_host_kkt_solve.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
                                                    C.POINTER(Settings), C.c_int64, dp, dp, dp, C.POINTER(Stats)]
+        L.mi_osqp_debug_host_block_factor.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
+                                                      C.POINTER(Settings), dp, dp, ip]
         _LIB = L
     return _LIB
 
@@ -252,6 +255,9 @@ class BatchSolver:
     def reset(self):
         _chk(lib().mi_osqp_batch_reset(self._h), "reset")
 
+    def refactor_device(self):
+        _chk(lib().mi_osqp_batch_refactor_device(self._h), "refactor_device")
+
     def last_solve_stats(self):
         it, ln, rc = C.c_int64(), C.c_int64(), C.c_int64()
         ds, rs = C.c_double(), C.c_double()
@@ -336,3 +342,21 @@ def debug_host_kkt_solve(P, A, l, u, rhs, **settings):
                                         C.byref(s), 1, _dp(rhs), _dp(sol_s), _dp(sol_d), C.byref(st))
     _chk(rc, "debug_host_kkt_solve")
     return sol_s, sol_d, st.as_dict()
+
+
+def debug_host_block_factor(P, A, l, u, **settings):
+    """Host-only: replay the device block refactorisation and compare with the host
+    left-looking factor.  Returns (max rel diff L, max rel diff Dinv, counts dict)."""
+    L = lib()
+    P, A = _csc(P), _csc(A)
+    n, m = A.shape[1], A.shape[0]
+    s = default_settings(**settings)
+    Pp, Pi, Px = _i64(P.indptr), _i64(P.indices), _f64(P.data)
+    Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), _f64(A.data)
+    l, u = _f64(l), _f64(u)
+    dL, dD = C.c_double(), C.c_double()
+    cnt = (C.c_int64 * 4)()
+    rc = L.mi_osqp_debug_host_block_factor(n, m, _ip(Pp), _ip(Pi), _dp(Px), _ip(Ap), _ip(Ai), _dp(Ax), _dp(l), _dp(u),
+                                           C.byref(s), C.byref(dL), C.byref(dD), cnt)
+    _chk(rc, "debug_host_block_factor")
+    return dL.value, dD.value, dict(blocks=cnt[0], triples=cnt[1], storage=cnt[2], levels=cnt[3])

@@ -36,6 +36,20 @@ struct KernelArgs {
   int iter_budget;
 };
 
+// device block refactorisation (row E13); tables are host_core.hpp BlockFactor
+struct FactorArgs {
+  int n, m, N, B, nnzP, nnzK, pa_len, n_levels, force_all;
+  uint32_t storage, fwd_slots, bwd_slots;
+  const uint32_t *blk, *lvl, *utask, *tri, *dtask, *ttask, *asm_dst, *asm_src;
+  const int32_t *fwd_srcblk, *bwd_srcblk;
+  const double *pa_val, *l, *u, *dscal;
+  double *rho_vec, *rho_inv, *Lblk, *Dl, *dinv_scratch, *fwd_val, *bwd_val, *dinv;
+  int *iscal, *npos;
+  double sigma;
+};
+hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
+size_t factor_lds_bytes(int BT, int threads);
+
 hipError_t launch_admm(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                        const double *x, const double *y, double *Px, double *Aty, double *Ax);

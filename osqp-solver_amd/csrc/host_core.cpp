@@ -226,6 +226,7 @@ static void build_tri_schedules(Analysis &an) {
         for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0) L = std::max(L, lev[chunk_of[j]] + 1); }
       lev[c] = L; maxlev = std::max(maxlev, L);
     }
+    an.chunk_lev = lev;
     std::vector<LevelWork> lw(maxlev + 1);
     for (int c = 0; c < nch; c++) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
@@ -296,6 +297,107 @@ static void build_chk_schedule(Analysis &an) {
     }
   lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
   pack_schedule(lw, an.chk);
+}
+
+// ------------------------------------------------ block factor (device refactor)
+
+static void build_block_factor(Analysis &an) {
+  BlockFactor &bf = an.bf;
+  bf = BlockFactor();
+  const int N = an.N, nch = (int)an.chunk_start.size() - 1;
+  std::vector<int> chunk_of(N);
+  for (int c = 0; c < nch; c++) for (int j = an.chunk_start[c]; j < an.chunk_start[c + 1]; j++) chunk_of[j] = c;
+  auto cw = [&](int c) { return an.chunk_start[c + 1] - an.chunk_start[c]; };
+  // blocks of every chunk column, sorted by row chunk (diagonal block first)
+  std::vector<std::vector<std::pair<int, uint32_t>>> colblk(nch);   // (I, block id)
+  std::vector<std::vector<std::pair<int, uint32_t>>> rowlist(nch);  // per row chunk: (K, block id) with K < I
+  std::vector<int> mark(nch, -1);
+  for (int J = 0; J < nch; J++) {
+    std::vector<int> rows{J};
+    mark[J] = J;
+    for (int col = an.chunk_start[J]; col < an.chunk_start[J + 1]; col++)
+      for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
+        int I = chunk_of[an.Li[p]];
+        if (mark[I] != J) { mark[I] = J; rows.push_back(I); }
+      }
+    std::sort(rows.begin(), rows.end());
+    for (int I : rows) {
+      uint32_t id = (uint32_t)bf.n_blocks();
+      uint32_t h = (uint32_t)cw(I), w = (uint32_t)cw(J);
+      bf.blk.insert(bf.blk.end(), {bf.storage, (uint32_t)an.chunk_start[I], (uint32_t)an.chunk_start[J], (h << 8) | w});
+      bf.storage += h * w;
+      colblk[J].push_back({I, id});
+      if (I != J) rowlist[I].push_back({J, id});
+    }
+  }
+  auto find_blk = [&](int I, int J) -> uint32_t {
+    const auto &v = colblk[J];
+    auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(I, 0u));
+    return it->second;
+  };
+  auto pos_of = [&](int r, int c) -> uint32_t {      // permuted (row >= col) -> storage position
+    int I = chunk_of[r], J = chunk_of[c];
+    uint32_t id = find_blk(I, J);
+    uint32_t off = bf.blk[4 * id], h = bf.blk[4 * id + 3] >> 8;
+    return off + (uint32_t)(c - an.chunk_start[J]) * h + (uint32_t)(r - an.chunk_start[I]);
+  };
+  // levels over chunk columns (= forward levels of the chunks)
+  int nlev = 0;
+  for (int c = 0; c < nch; c++) nlev = std::max(nlev, an.chunk_lev[c] + 1);
+  bf.n_levels = nlev;
+  std::vector<std::vector<int>> cols_of_level(nlev);
+  for (int c = 0; c < nch; c++) cols_of_level[an.chunk_lev[c]].push_back(c);
+  for (int L = 0; L < nlev; L++) {
+    uint32_t u0 = (uint32_t)(bf.utask.size() / 4), d0 = (uint32_t)bf.dtask.size(), t0 = (uint32_t)(bf.ttask.size() / 2);
+    struct UT { uint32_t id, tb, te; };
+    std::vector<UT> uts;
+    for (int J : cols_of_level[L]) {
+      const auto &rj = rowlist[J];
+      for (const auto &[I, id] : colblk[J]) {
+        uint32_t tb = (uint32_t)(bf.tri.size() / 2);
+        if (I == J) {
+          for (const auto &[K, bid] : rj) bf.tri.insert(bf.tri.end(), {bid, bid});
+        } else {
+          const auto &ri = rowlist[I];
+          size_t a = 0, b = 0;
+          while (a < ri.size() && b < rj.size()) {
+            if (ri[a].first < rj[b].first) a++;
+            else if (ri[a].first > rj[b].first) b++;
+            else { bf.tri.insert(bf.tri.end(), {ri[a].second, rj[b].second}); a++; b++; }
+          }
+        }
+        uint32_t te = (uint32_t)(bf.tri.size() / 2);
+        if (te > tb) uts.push_back({id, tb, te});
+        if (I == J) bf.dtask.push_back(id);
+        else bf.ttask.insert(bf.ttask.end(), {id, colblk[J][0].second});
+      }
+    }
+    std::stable_sort(uts.begin(), uts.end(), [](const UT &a, const UT &b) { return a.te - a.tb > b.te - b.tb; });
+    for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.te, 0u});
+    bf.lvl.insert(bf.lvl.end(), {u0, (uint32_t)(bf.utask.size() / 4), d0, (uint32_t)bf.dtask.size(), t0, (uint32_t)(bf.ttask.size() / 2)});
+  }
+  // assembly map: natural KKT entry -> (storage position, value source)
+  const int n = an.n, m = an.m, nnzK = an.nnzK();
+  bf.asm_dst.assign(nnzK, 0); bf.asm_src.assign(nnzK, 0);
+  std::vector<int> colOfK(nnzK);
+  for (int j = 0; j < N; j++) for (int k = an.Kp[j]; k < an.Kp[j + 1]; k++) colOfK[k] = j;
+  for (int e = 0; e < nnzK; e++) {
+    int a = an.pinv[an.Ki[e]], b = an.pinv[colOfK[e]];
+    bf.asm_dst[e] = pos_of(std::max(a, b), std::min(a, b));
+  }
+  for (int k = 0; k < an.Pp[n]; k++) bf.asm_src[an.PtoK[k]] = ((uint32_t)(an.PisDiag[k] ? ASM_P_SIGMA : ASM_P) << 29) | (uint32_t)k;
+  for (int pos : an.sigmaOnlyK) bf.asm_src[pos] = (uint32_t)ASM_SIGMA << 29;
+  for (int k = 0; k < an.Ap[n]; k++) bf.asm_src[an.AtoK[k]] = ((uint32_t)ASM_A << 29) | (uint32_t)k;
+  for (int r = 0; r < m; r++) bf.asm_src[an.rhotoK[r]] = ((uint32_t)ASM_NEG_RHOINV << 29) | (uint32_t)r;
+  // canonical L entry -> storage position, and the schedule maps composed with it
+  bf.lpos.assign(an.nnzL(), 0);
+  for (int j = 0; j < N; j++) for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) bf.lpos[p] = (int32_t)pos_of(an.Li[p], j);
+  auto compose = [&](const Schedule &s, std::vector<int32_t> &out) {
+    out.resize(s.src.size());
+    for (size_t k = 0; k < s.src.size(); k++) out[k] = s.src[k] >= 0 ? bf.lpos[s.src[k]] : -1;
+  };
+  compose(an.fwd, an.fwd_srcblk);
+  compose(an.bwd, an.bwd_srcblk);
 }
 
 // --------------------------------------------------------------------- analyze
@@ -390,6 +492,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   an.chunk_start.push_back(N);
   build_tri_schedules(an);
   build_chk_schedule(an);
+  build_block_factor(an);
   return MI_OSQP_OK;
 }
 
@@ -608,6 +711,68 @@ void replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs
   for (int k = 0; k < N; k++) xs[k] *= qp.Dlinv[k];
   replay(an.bwd, qp.Lx.data(), xs.data(), true, nullptr);
   for (int k = 0; k < N; k++) sol[an.perm[k]] = xs[k];
+}
+
+int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric &qp, QPNumeric &out) {
+  const BlockFactor &bf = an.bf;
+  const int n = an.n, N = an.N;
+  std::vector<double> S(bf.storage, 0.0), D(N, 0.0);
+  for (int e = 0; e < an.nnzK(); e++) {
+    uint32_t kind = bf.asm_src[e] >> 29, idx = bf.asm_src[e] & 0x1FFFFFFFu;
+    double v = 0.0;
+    switch (kind) {
+      case ASM_P: v = qp.Pv[idx]; break;
+      case ASM_P_SIGMA: v = qp.Pv[idx] + st.sigma; break;
+      case ASM_SIGMA: v = st.sigma; break;
+      case ASM_A: v = qp.Av[idx]; break;
+      default: v = -qp.rho_inv[idx]; break;
+    }
+    S[bf.asm_dst[e]] = v;
+  }
+  auto B = [&](uint32_t id, uint32_t &off, uint32_t &r0, uint32_t &c0, uint32_t &h, uint32_t &w) {
+    off = bf.blk[4 * id]; r0 = bf.blk[4 * id + 1]; c0 = bf.blk[4 * id + 2]; h = bf.blk[4 * id + 3] >> 8; w = bf.blk[4 * id + 3] & 255u;
+  };
+  int positive = 0;
+  for (int L = 0; L < bf.n_levels; L++) {
+    const uint32_t *lv = &bf.lvl[6 * L];
+    for (uint32_t t = lv[0]; t < lv[1]; t++) {
+      uint32_t off, r0, c0, h, w; B(bf.utask[4 * t], off, r0, c0, h, w);
+      for (uint32_t q = bf.utask[4 * t + 1]; q < bf.utask[4 * t + 2]; q++) {
+        uint32_t ao, ar, ac, ah, aw, bo, br, bc, bh, bw;
+        B(bf.tri[2 * q], ao, ar, ac, ah, aw); B(bf.tri[2 * q + 1], bo, br, bc, bh, bw);
+        for (uint32_t j = 0; j < w; j++) for (uint32_t i = 0; i < h; i++) {
+          double acc = 0.0;
+          for (uint32_t k = 0; k < aw; k++) acc += S[ao + k * ah + i] * D[ac + k] * S[bo + k * bh + j];
+          S[off + j * h + i] -= acc;
+        }
+      }
+    }
+    for (uint32_t t = lv[2]; t < lv[3]; t++) {
+      uint32_t off, r0, c0, h, w; B(bf.dtask[t], off, r0, c0, h, w);
+      for (uint32_t j = 0; j < w; j++) {
+        double d = S[off + j * h + j];
+        if (d == 0.0) return MI_OSQP_ERR_NONCONVEX;
+        if (d > 0.0) positive++;
+        D[c0 + j] = d;
+        for (uint32_t i = j + 1; i < h; i++) S[off + j * h + i] /= d;
+        for (uint32_t k = j + 1; k < w; k++) for (uint32_t i = k; i < h; i++) S[off + k * h + i] -= S[off + j * h + i] * d * S[off + j * h + k];
+      }
+    }
+    for (uint32_t t = lv[4]; t < lv[5]; t++) {
+      uint32_t off, r0, c0, h, w, doff, dr, dc, dh, dw;
+      B(bf.ttask[2 * t], off, r0, c0, h, w); B(bf.ttask[2 * t + 1], doff, dr, dc, dh, dw);
+      for (uint32_t i = 0; i < h; i++)
+        for (uint32_t j = 0; j < w; j++) {
+          double v = S[off + j * h + i];
+          for (uint32_t k = 0; k < j; k++) v -= S[off + k * h + i] * D[c0 + k] * S[doff + k * dh + j];
+          S[off + j * h + i] = v / D[c0 + j];
+        }
+    }
+  }
+  out.Lx.resize(an.nnzL()); out.Dl = D; out.Dlinv.resize(N);
+  for (int p = 0; p < an.nnzL(); p++) out.Lx[p] = S[bf.lpos[p]];
+  for (int j = 0; j < N; j++) out.Dlinv[j] = 1.0 / D[j];
+  return positive == n ? MI_OSQP_OK : MI_OSQP_ERR_NONCONVEX;
 }
 
 void replay_spmv(const Analysis &an, const QPNumeric &qp, const double *x, const double *y,

@@ -50,6 +50,28 @@ struct Schedule {
   size_t n_taskB() const { return taskB.size() / 4; }
 };
 
+// Block form of the factor for the DEVICE refactorisation (row E13): L is cut
+// into dense blocks B(I,J) = L[rows of chunk I, cols of chunk J] (column-major,
+// h_I x w_J, zero padded), processed per chunk-column level:
+//   U  B(I,J) -= sum_K B(I,K) D_K B(J,K)^T      (pull: one wave owns one target block)
+//   D  LDL' of the diagonal block B(J,J)
+//   T  B(I,J) <- B(I,J) (L_JJ D_J)^-T
+struct BlockFactor {
+  uint32_t storage = 0;               // doubles per QP of block storage
+  std::vector<uint32_t> blk;          // 4/block: off, c0 of row chunk, c0 of col chunk, (h << 8) | w
+  std::vector<uint32_t> lvl;          // 6/level: u_begin,u_end, d_begin,d_end, t_begin,t_end
+  std::vector<uint32_t> utask;        // 4/task : block id, tri_begin, tri_end, 0
+  std::vector<uint32_t> tri;          // 2/triple: block (I,K), block (J,K)
+  std::vector<uint32_t> dtask;        // diagonal block ids
+  std::vector<uint32_t> ttask;        // 2/task : block id, diagonal block id
+  std::vector<uint32_t> asm_dst;      // per natural KKT entry: position in block storage
+  std::vector<uint32_t> asm_src;      // per natural KKT entry: (kind << 29) | index
+  std::vector<int32_t> lpos;          // canonical L entry -> position in block storage
+  int n_levels = 0;
+  size_t n_blocks() const { return blk.size() / 4; }
+};
+enum { ASM_P = 0, ASM_P_SIGMA = 1, ASM_SIGMA = 2, ASM_A = 3, ASM_NEG_RHOINV = 4 };
+
 struct Analysis {
   int n = 0, m = 0, N = 0;
   // triu(P) and A patterns (CSC, 32-bit on our side)
@@ -66,7 +88,10 @@ struct Analysis {
   std::vector<int> Lp, Li, Rp, Rj, Rpos, etree;
   std::vector<int> sn_start;       // supernode boundaries
   std::vector<int> chunk_start;    // <=16-column chunks (phase-B blocks)
+  std::vector<int> chunk_lev;      // forward level of every chunk
   Schedule fwd, bwd, chk;
+  BlockFactor bf;
+  std::vector<int32_t> fwd_srcblk, bwd_srcblk;   // fwd/bwd slot -> block-storage position (-1 = zero)
   int nnzL() const { return Lp.empty() ? 0 : Lp.back(); }
   int nnzK() const { return Kp.empty() ? 0 : Kp.back(); }
 };
@@ -101,6 +126,9 @@ int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector
 void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
 // sequential interpreter of the device schedules (tests only; see mi_osqp.h)
 void replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
+// host interpreter of the device block factorisation (tests only): fills Lx/Dlinv
+// of `out` from qp's scaled data and rho vector exactly as factor_kernel does
+int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric &qp, QPNumeric &out);
 // combined value array the check-SpMV schedule indexes: [P triu | A]
 void replay_spmv(const Analysis &an, const QPNumeric &qp, const double *x, const double *y,
                  double *Px, double *Aty, double *Ax);

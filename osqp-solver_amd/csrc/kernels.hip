@@ -523,6 +523,230 @@ __global__ __launch_bounds__(1024) void warm_start_kernel(KernelArgs a, const do
   for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
 
+// ------------------------------------------- device refactorisation (row E13)
+// Block left-looking LDL' on the chunk structure (host_core.hpp BlockFactor).
+// One workgroup per tile; lane = (row i of a <=16-row block, QP b).  Per level of
+// chunk columns:  U (pull updates, one wave per target block, the scaled source
+// block B*D staged in wave-private LDS and read back as broadcasts),
+// D (LDL' of the diagonal block inside one wave), T (row-wise triangular solve).
+// The result is scattered straight into the forward/backward schedule order.
+
+#define MI_BS(k, b, j) ((((k) * BT + (b)) << 4) + (j))
+// order LDS traffic of one wave (lanes exchange data through wave-private LDS)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int BT>
+__device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, const double *Dl, double *Ss,
+                                           uint32_t t, int lane) {
+  const uint4 ut = reinterpret_cast<const uint4 *>(a.utask)[t];
+  const uint4 tb = reinterpret_cast<const uint4 *>(a.blk)[ut.x];
+  const uint32_t off = tb.x, h = tb.w >> 8, w = tb.w & 255u;
+  const int i = lane / BT, b = lane % BT;
+  const bool row_ok = (uint32_t)i < h && lane < MI_CHUNK * BT;
+  double acc[MI_CHUNK];
+#pragma unroll
+  for (int j = 0; j < MI_CHUNK; j++) acc[j] = (row_ok && (uint32_t)j < w) ? Lb[((size_t)off + j * h + i) * BT + b] : 0.0;
+  for (uint32_t q = ut.y; q < ut.z; q++) {
+    const uint2 tr = reinterpret_cast<const uint2 *>(a.tri)[q];
+    const uint4 ba = reinterpret_cast<const uint4 *>(a.blk)[tr.x];
+    const uint4 bb = reinterpret_cast<const uint4 *>(a.blk)[tr.y];
+    const uint32_t ah = ba.w >> 8, aw = ba.w & 255u, bh = bb.w >> 8, kc0 = ba.z;
+    // stage (B .* d) : lane (j, b) provides row j of B
+    const bool brow = (uint32_t)i < bh && lane < MI_CHUNK * BT;
+    for (uint32_t k = 0; k < aw; k++) {
+      double v = 0.0;
+      if (brow) v = Lb[((size_t)bb.x + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b];
+      if (lane < MI_CHUNK * BT) Ss[MI_BS(k, b, i)] = v;
+    }
+    wave_sync();
+    for (uint32_t k = 0; k < aw; k++) {
+      const double av = ((uint32_t)i < ah && lane < MI_CHUNK * BT) ? Lb[((size_t)ba.x + k * ah + i) * BT + b] : 0.0;
+      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(k, b, 0)]);
+#pragma unroll
+      for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
+        const double2 bv = bs[j2];
+        acc[2 * j2] = fma(-av, bv.x, acc[2 * j2]);
+        acc[2 * j2 + 1] = fma(-av, bv.y, acc[2 * j2 + 1]);
+      }
+    }
+    wave_sync();
+  }
+  if (row_ok) {
+#pragma unroll
+    for (int j = 0; j < MI_CHUNK; j++) if ((uint32_t)j < w) Lb[((size_t)off + j * h + i) * BT + b] = acc[j];
+  }
+}
+
+template <int BT>
+__device__ __forceinline__ void fct_diag(const FactorArgs &a, double *Lb, double *Dl, double *dinv, double *Ss,
+                                         uint32_t t, int lane, int &npos) {
+  const uint4 tb = reinterpret_cast<const uint4 *>(a.blk)[a.dtask[t]];
+  const uint32_t off = tb.x, c0 = tb.z, w = tb.w & 255u;
+  const int i = lane / BT, b = lane % BT;
+  const bool ok = (uint32_t)i < w && lane < MI_CHUNK * BT;
+  if (lane < MI_CHUNK * BT) {
+#pragma unroll
+    for (int k = 0; k < MI_CHUNK; k++) Ss[MI_BS(k, b, i)] = (ok && (uint32_t)k < w) ? Lb[((size_t)off + k * w + i) * BT + b] : 0.0;
+  }
+  wave_sync();
+  for (uint32_t j = 0; j < w; j++) {
+    const double d = Ss[MI_BS(j, b, j)];
+    const double di = 1.0 / d;
+    double lij = 0.0;
+    if (ok && (uint32_t)i > j) { lij = Ss[MI_BS(j, b, i)] * di; Ss[MI_BS(j, b, i)] = lij; }
+    if (ok && (uint32_t)i == j) {
+      Dl[((size_t)c0 + j) * BT + b] = d; dinv[((size_t)c0 + j) * BT + b] = di;
+      if (d > 0.0) npos++;
+    }
+    wave_sync();
+    if (ok && (uint32_t)i > j) {
+      const double ld = lij * d;
+      for (uint32_t k = j + 1; k <= (uint32_t)i; k++) Ss[MI_BS(k, b, i)] -= ld * Ss[MI_BS(j, b, k)];
+    }
+    wave_sync();
+  }
+  if (ok) {
+    for (uint32_t k = 0; k < (uint32_t)i; k++) Lb[((size_t)off + k * w + i) * BT + b] = Ss[MI_BS(k, b, i)];
+  }
+}
+
+template <int BT>
+__device__ __forceinline__ void fct_trsm(const FactorArgs &a, double *Lb, const double *Dl, const double *dinv,
+                                         double *Ss, uint32_t t, int lane) {
+  const uint2 tt = reinterpret_cast<const uint2 *>(a.ttask)[t];
+  const uint4 tb = reinterpret_cast<const uint4 *>(a.blk)[tt.x];
+  const uint4 db = reinterpret_cast<const uint4 *>(a.blk)[tt.y];
+  const uint32_t off = tb.x, h = tb.w >> 8, w = tb.w & 255u, c0 = tb.z;
+  const int i = lane / BT, b = lane % BT;
+  // stage the diagonal block: Ss(k, b, j) = L_JJ[j,k] (strictly lower)
+  if (lane < MI_CHUNK * BT) {
+    for (uint32_t k = 0; k < w; k++)
+      Ss[MI_BS(k, b, i)] = ((uint32_t)i < w && (uint32_t)i > k) ? Lb[((size_t)db.x + k * w + i) * BT + b] : 0.0;
+  }
+  wave_sync();
+  if ((uint32_t)i < h && lane < MI_CHUNK * BT) {
+    double ld[MI_CHUNK];
+#pragma unroll
+    for (int j = 0; j < MI_CHUNK; j++) {
+      if ((uint32_t)j < w) {
+        double v = Lb[((size_t)off + j * h + i) * BT + b];
+#pragma unroll
+        for (int k = 0; k < j; k++) v = fma(-ld[k], Ss[MI_BS(k, b, j)], v);
+        ld[j] = v;                                           // = l_ij * d_j
+        Lb[((size_t)off + j * h + i) * BT + b] = v * dinv[((size_t)c0 + j) * BT + b];
+      }
+    }
+  }
+  wave_sync();
+}
+
+template <int BT>
+__global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int m = a.m, N = a.N;
+  int *iscal = a.iscal + (size_t)tile * IS_COUNT * BT;
+  const int flag = a.force_all ? (tile * BT + b < a.B) : iscal[IS_NEED_REFACTOR * BT + b];
+  if (!__syncthreads_or(flag)) return;
+  double *Ss = smem + (size_t)wave * MI_CHUNK * MI_CHUNK * BT;
+  double *Lb = a.Lblk + (size_t)tile * a.storage * BT;
+  double *Dl = a.Dl + (size_t)tile * N * BT;
+  double *dinv = a.dinv + (size_t)tile * N * BT;
+  double *rho_vec = a.rho_vec + (size_t)tile * m * BT, *rho_inv = a.rho_inv + (size_t)tile * m * BT;
+  const double *lo = a.l + (size_t)tile * m * BT, *up = a.u + (size_t)tile * m * BT;
+  const double rho = a.dscal[((size_t)tile * DS_COUNT + DS_RHO) * BT + b];
+  // ---- rho vector of the QPs being refactored ([EXT] osqp_update_rho)
+  if (flag && !a.force_all) {
+    for (int e = tid; e < m * BT; e += nthr) {
+      const double l = lo[e], u = up[e];
+      double rv;
+      if (l < -MI_INFTY * MI_MIN_SCALING && u > MI_INFTY * MI_MIN_SCALING) rv = MI_RHO_MIN;
+      else if (u - l < 1e-4) rv = 1e3 * rho;
+      else rv = rho;
+      rho_vec[e] = rv; rho_inv[e] = 1.0 / rv;
+    }
+  }
+  for (size_t e = tid; e < (size_t)a.storage * BT; e += nthr) Lb[e] = 0.0;
+  __syncthreads();
+  // ---- assemble the permuted KKT into block storage
+  {
+    const double *pav = a.pa_val + (size_t)tile * a.pa_len * BT;
+    for (int e = tid; e < a.nnzK * BT; e += nthr) {
+      const int k = e / BT;
+      const uint32_t src = a.asm_src[k], kind = src >> 29, idx = src & 0x1FFFFFFFu;
+      double v;
+      if (kind == 0) v = pav[(size_t)idx * BT + b];
+      else if (kind == 1) v = pav[(size_t)idx * BT + b] + a.sigma;
+      else if (kind == 2) v = a.sigma;
+      else if (kind == 3) v = pav[((size_t)a.nnzP + idx) * BT + b];
+      else v = -rho_inv[(size_t)idx * BT + b];
+      Lb[(size_t)a.asm_dst[k] * BT + b] = v;
+    }
+  }
+  __syncthreads();
+  int npos = 0;
+  double *dnew = a.dinv_scratch + (size_t)tile * N * BT;
+  for (int L = 0; L < a.n_levels; L++) {
+    const uint32_t *lv = a.lvl + 6 * L;
+    if (lv[1] > lv[0]) {
+      for (uint32_t t = lv[0] + wave; t < lv[1]; t += nw) fct_update<BT>(a, Lb, Dl, Ss, t, lane);
+      __syncthreads();
+    }
+    for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
+    __syncthreads();
+    if (lv[5] > lv[4]) {
+      for (uint32_t t = lv[4] + wave; t < lv[5]; t += nw) fct_trsm<BT>(a, Lb, Dl, dnew, Ss, t, lane);
+      __syncthreads();
+    }
+  }
+  // ---- inertia: positive pivots of QP b summed over the workgroup (each pivot counted by one lane)
+  {
+    __shared__ int s_npos[4];
+    if (tid < 4) s_npos[tid] = 0;
+    __syncthreads();
+    if (npos) atomicAdd(&s_npos[b], npos);
+    __syncthreads();
+    if (tid < BT) a.npos[(size_t)tile * BT + b] = s_npos[b];
+  }
+  // ---- scatter into the solve schedules (only the refactored QPs)
+  if (flag) {
+    double *fv = a.fwd_val + (size_t)tile * a.fwd_slots * BT, *bv = a.bwd_val + (size_t)tile * a.bwd_slots * BT;
+    for (size_t e = tid; e < (size_t)a.fwd_slots * BT; e += nthr) {
+      const int32_t mp = a.fwd_srcblk[e / BT];
+      fv[e] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+    }
+    for (size_t e = tid; e < (size_t)a.bwd_slots * BT; e += nthr) {
+      const int32_t mp = a.bwd_srcblk[e / BT];
+      bv[e] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+    }
+    for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
+  }
+  __syncthreads();
+  if (tid < BT) iscal[IS_NEED_REFACTOR * BT + b] = 0;
+}
+
+template <int BT>
+static hipError_t launch_factor_t(const FactorArgs &a, int tiles, int threads, hipStream_t st) {
+  const size_t lds = factor_lds_bytes(BT, threads);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<BT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(factor_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a);
+  return hipGetLastError();
+}
+size_t factor_lds_bytes(int BT, int threads) { return (size_t)(threads / 64) * MI_CHUNK * MI_CHUNK * BT * sizeof(double); }
+hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st) {
+  switch (BT) {
+    case 1: return launch_factor_t<1>(a, tiles, threads, st);
+    case 2: return launch_factor_t<2>(a, tiles, threads, st);
+    default: return launch_factor_t<4>(a, tiles, threads, st);
+  }
+}
+
 // ------------------------------------------------- layout / upload kernels
 
 // dst[tile][i][b] = src[q][i]   (q = ids ? ids[j] : j)

@@ -126,7 +126,13 @@ struct mi_osqp_batch {
   DevBuf<double> fwd_val, bwd_val, chk_val, dinv, x, z, y, q, l, u, rho_vec, rho_inv, Dsc, Dsc_inv, Esc, Esc_inv;
   DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out;
   DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
-  DevBuf<int> iscal, tile_iter, flag;
+  DevBuf<int> iscal, tile_iter, flag, npos;
+  // device refactorisation (BlockFactor tables + scratch)
+  DevBuf<uint32_t> bf_blk, bf_lvl, bf_utask, bf_tri, bf_dtask, bf_ttask, bf_asm_dst, bf_asm_src;
+  DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
+  DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
+  bool host_rho_stale = false, host_refactor = false;
+  int *h_npos = nullptr;
   DevBuf<double> stage; DevBuf<int> ids;
   int *h_iscal = nullptr;     // pinned
   double *h_dscal = nullptr;  // pinned
@@ -140,6 +146,7 @@ struct mi_osqp_batch {
   ~mi_osqp_batch() {
     if (h_iscal) (void)hipHostFree(h_iscal);
     if (h_dscal) (void)hipHostFree(h_dscal);
+    if (h_npos) (void)hipHostFree(h_npos);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -183,6 +190,22 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.check_termination = (int)s.check_termination; a.rho_interval = (int)s.adaptive_rho_interval;
   a.max_iter = (int)s.max_iter; a.scaled_termination = (int)s.scaled_termination; a.scaling = s.scaling ? 1 : 0;
   a.adaptive_rho = (int)s.adaptive_rho; a.iter_budget = (int)s.max_iter;
+  return a;
+}
+
+static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
+  FactorArgs a{};
+  const Analysis &an = h->an;
+  a.n = an.n; a.m = an.m; a.N = an.N; a.B = h->B; a.nnzP = an.Pp[an.n]; a.nnzK = an.nnzK();
+  a.pa_len = an.Pp[an.n] + an.Ap[an.n]; a.n_levels = an.bf.n_levels; a.force_all = force_all;
+  a.storage = an.bf.storage; a.fwd_slots = an.fwd.n_slots; a.bwd_slots = an.bwd.n_slots;
+  a.blk = h->bf_blk.p; a.lvl = h->bf_lvl.p; a.utask = h->bf_utask.p; a.tri = h->bf_tri.p; a.dtask = h->bf_dtask.p;
+  a.ttask = h->bf_ttask.p; a.asm_dst = h->bf_asm_dst.p; a.asm_src = h->bf_asm_src.p;
+  a.fwd_srcblk = h->fwd_srcblk.p; a.bwd_srcblk = h->bwd_srcblk.p;
+  a.pa_val = h->pa_val.p; a.l = h->l.p; a.u = h->u.p; a.dscal = h->dscal.p;
+  a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
+  a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
+  a.sigma = h->st.sigma;
   return a;
 }
 
@@ -263,6 +286,7 @@ static int upload_problem(mi_osqp_batch *h, const std::vector<int> &ids, bool wi
     if (!pa.empty()) {
       HIPCHK(hipMemcpyAsync(h->stage.p, pa.data(), pa.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
       HIPCHK(launch_scatter(h->stage.p, h->chk_val.p, h->chk.src.p, h->ids.p, nq, nnzP + nnzA, an.chk.n_slots, h->BT, h->stream));
+      HIPCHK(launch_interleave(h->stage.p, h->pa_val.p, h->ids.p, nq, nnzP + nnzA, h->BT, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
     }
     if ((rc = up(n, h->q.p, [&](int q) -> const std::vector<double> & { return h->qp[q].q; }))) return rc;
@@ -320,6 +344,21 @@ static int sync_bounds_to_host(mi_osqp_batch *h) {
     }
   }
   h->host_bounds_stale = false;
+  return 0;
+}
+
+// after device-side rho updates the host mirrors (rho, rho_vec) lag behind
+static int sync_rho_to_host(mi_osqp_batch *h) {
+  if (!h->host_rho_stale) return 0;
+  int rc = sync_bounds_to_host(h);
+  if (rc) return rc;
+  size_t dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
+  for (int q = 0; q < h->B; q++) {
+    double r = h->h_dscal[(size_t)(q / h->BT) * DS_COUNT * h->BT + DS_RHO * h->BT + q % h->BT];
+    if (r != h->qp[q].rho) apply_rho(h->an, h->qp[q], r);
+  }
+  h->host_rho_stale = false;
   return 0;
 }
 
@@ -387,6 +426,18 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->tile_iter.alloc(h->ntiles)) || (rc = h->flag.alloc(4))) return rc;
+  {
+    const BlockFactor &bf = an.bf;
+    if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_utask.upload(bf.utask)) ||
+        (rc = h->bf_tri.upload(bf.tri)) || (rc = h->bf_dtask.upload(bf.dtask)) || (rc = h->bf_ttask.upload(bf.ttask)) ||
+        (rc = h->bf_asm_dst.upload(bf.asm_dst)) || (rc = h->bf_asm_src.upload(bf.asm_src)) ||
+        (rc = h->fwd_srcblk.upload(an.fwd_srcblk)) || (rc = h->bwd_srcblk.upload(an.bwd_srcblk))) return rc;
+    if ((rc = h->pa_val.alloc((size_t)(an.Pp[n] + an.Ap[n]) * T)) || (rc = h->pa_val.zero(h->stream)) ||
+        (rc = h->Lblk.alloc((size_t)bf.storage * T)) || (rc = h->Dl.alloc((size_t)an.N * T)) || (rc = h->Dl.zero(h->stream)) ||
+        (rc = h->dinv_scratch.alloc((size_t)an.N * T)) || (rc = h->npos.alloc(T))) return rc;
+    HIPCHK(hipHostMalloc((void **)&h->h_npos, T * sizeof(int)));
+    h->host_refactor = getenv("MI_OSQP_HOST_REFACTOR") != nullptr;
+  }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
   HIPCHK(hipHostMalloc((void **)&h->h_iscal, (size_t)IS_COUNT * T * sizeof(int)));
@@ -492,7 +543,18 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
       if (!t[IS_DONE * BT + qi % BT]) all_done = false;
       if (t[IS_NEED_REFACTOR * BT + qi % BT]) ref.push_back(qi);
     }
-    if (!ref.empty()) {
+    if (!ref.empty() && !h->host_refactor) {
+      // row E13 on the device: rho vector, KKT assembly, block LDL', scatter into the schedules
+      double tr = now_s();
+      FactorArgs fa = make_factor_args(h, 0);
+      HIPCHK(launch_factor(fa, BT, h->ntiles, h->threads, h->stream));
+      HIPCHK(hipMemcpyAsync(h->h_npos, h->npos.p, (size_t)h->ntiles * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      for (int qi : ref) if (h->h_npos[qi] != h->an.n) { g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX; }
+      h->host_rho_stale = true;
+      h->last_refactors += (int64_t)ref.size();
+      h->last_refactor_s += now_s() - tr;
+    } else if (!ref.empty()) {
       double tr = now_s();
       HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
       for (int qi : ref) {
@@ -663,6 +725,7 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
     h->qp[q].rho = h->h_dscal[(size_t)(q / h->BT) * DS_COUNT * h->BT + DS_RHO * h->BT + q % h->BT];
     set_rho_vec(h->an, h->st, h->qp[q]);
   }
+  h->host_rho_stale = false;
   return MI_OSQP_OK;
 }
 
@@ -684,6 +747,7 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
   const Analysis &an = h->an;
   int m = an.m, B = h->B, rc;
   for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  if ((rc = sync_rho_to_host(h))) return rc;
   h->host_bounds_stale = false;   // host copy becomes authoritative
   std::vector<int> changed;
   for (int q = 0; q < B; q++) {
@@ -734,7 +798,7 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
   int n = an.n, B = h->B, nnzA = an.Ap[n], rc;
   for (int j = 0; j <= n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
   for (int k = 0; k < nnzA; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
-  if ((rc = sync_bounds_to_host(h))) return rc;
+  if ((rc = sync_bounds_to_host(h)) || (rc = sync_rho_to_host(h))) return rc;
   std::vector<std::vector<double>> works(host_threads());
   std::atomic<int> fail{0};
   const int CH = 128;
@@ -756,6 +820,16 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
     for (int qi = c0; qi < c1; qi++) std::vector<double>().swap(h->qp[qi].Lx);
   }
   return snapshot(h);
+}
+
+int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  FactorArgs fa = make_factor_args(h, 1);
+  HIPCHK(launch_factor(fa, h->BT, h->ntiles, h->threads, h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_npos, h->npos.p, (size_t)h->ntiles * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int q = 0; q < h->B; q++) if (h->h_npos[q] != h->an.n) return MI_OSQP_ERR_NONCONVEX;
+  return MI_OSQP_OK;
 }
 
 int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, double *d_Px, double *d_Aty, double *d_Ax,
@@ -838,6 +912,34 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const 
     st->n_supernodes = (int64_t)an.sn_start.size() - 1; st->n_blocks = (int64_t)an.chunk_start.size() - 1;
     st->fwd_levels = an.fwd.n_levels; st->bwd_levels = an.bwd.n_levels;
     st->fwd_slots = an.fwd.n_slots; st->bwd_slots = an.bwd.n_slots; st->chk_slots = an.chk.n_slots;
+  }
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_debug_host_block_factor(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const double *Pv,
+                                    const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l,
+                                    const double *u, const mi_osqp_settings *settings, double *dL, double *dD,
+                                    int64_t *counts) {
+  Settings s = to_settings(settings);
+  if (validate_settings(s)) return MI_OSQP_ERR_INVALID_SETTINGS;
+  Analysis an;
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, an);
+  if (rc) return rc;
+  QPNumeric Q, R;
+  load_qp(an, s, Pv, nullptr, Av, l, u, Q);
+  if (s.scaling) scale_qp(an, s, Q);
+  set_rho_vec(an, s, Q);
+  std::vector<double> w;
+  if ((rc = factor_qp(an, s, Q, w))) return rc;
+  if ((rc = replay_block_factor(an, s, Q, R))) return rc;
+  double mL = 0.0, sL = 1e-300, mD = 0.0;
+  for (size_t k = 0; k < Q.Lx.size(); k++) { mL = std::max(mL, std::fabs(Q.Lx[k] - R.Lx[k])); sL = std::max(sL, std::fabs(Q.Lx[k])); }
+  for (size_t k = 0; k < Q.Dlinv.size(); k++) mD = std::max(mD, std::fabs(Q.Dlinv[k] - R.Dlinv[k]) / std::fabs(Q.Dlinv[k]));
+  if (dL) *dL = mL / sL;
+  if (dD) *dD = mD;
+  if (counts) {
+    counts[0] = (int64_t)an.bf.n_blocks(); counts[1] = (int64_t)an.bf.tri.size() / 2;
+    counts[2] = an.bf.storage; counts[3] = an.bf.n_levels;
   }
   return MI_OSQP_OK;
 }
