@@ -52,3 +52,13 @@ def test_nonconvex_is_refused():
     with pytest.raises(M.MiOsqpError) as e:
         M.debug_host_kkt_solve(P, A, -np.ones(3), np.ones(3), np.ones(6))
     assert e.value.code == 4
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_block_factor_replay_matches_left_looking(case):
+    """The DEVICE refactorisation tables (BlockFactor), interpreted on the host,
+    reproduce the host left-looking LDL' (row E13 vs E5)."""
+    name, P, A, l, u = case
+    dL, dD, cnt = M.debug_host_block_factor(P, A, l, u)
+    assert dL <= 1e-10 and dD <= 1e-9, (name, dL, dD)
+    assert cnt["blocks"] >= 1 and cnt["storage"] >= 1
