@@ -9,9 +9,9 @@ namespace miosqp {
 
 // device view of one host_core.hpp Schedule (index arrays are shared by all tiles)
 struct SchedDev {
-  const uint32_t *lvl, *taskA, *outA, *taskB, *outB, *idx;
-  int n_levels;
-  uint32_t n_slots;
+  const uint32_t *lvl, *step, *outA, *taskB, *outB, *idx;
+  int n_levels, nw;
+  uint32_t n_slots, zero_step;
 };
 
 // per-QP double scalars, laid out [tile][DS_COUNT][BT]

@@ -150,28 +150,17 @@ struct LevelWork { std::vector<RowWork> rowsA; std::vector<BlockWork> blocksB; }
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch) {
+void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw) {
   sch = Schedule();
   sch.n_levels = (int)levels.size();
-  auto emit = [&](const std::vector<const RowWork *> &rows, int T, int S) {
-    uint32_t base = sch.n_slots;
-    sch.n_slots += 64u * (uint32_t)S;
-    sch.idx.resize(sch.n_slots, 0u);
-    sch.src.resize(sch.n_slots, -1);
-    uint32_t out_base = (uint32_t)sch.outA.size();
-    int per = 64 / T;
-    for (int g = 0; g < per; g++) sch.outA.push_back(g < (int)rows.size() ? rows[g]->row : kNoRow);
-    for (int g = 0; g < (int)rows.size(); g++) {
-      const auto &ent = rows[g]->ent;
-      for (int e = 0; e < (int)ent.size(); e++) {
-        uint32_t slot = base + (uint32_t)(e / T) * 64u + (uint32_t)(g * T + e % T);
-        sch.idx[slot] = ent[e].first; sch.src[slot] = ent[e].second;
-      }
-    }
-    sch.taskA.insert(sch.taskA.end(), {base, (uint32_t)S, (uint32_t)ilog2(T), out_base});
-  };
-  for (const LevelWork &lw : levels) {
-    uint32_t a_begin = (uint32_t)sch.n_taskA();
+  sch.nw = nw;
+  // a unit = work that must stay on one wave, in order
+  struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; };
+  struct Unit { std::vector<StepSpec> steps; };
+  std::vector<std::vector<std::vector<Unit>>> per_level_wave(levels.size());
+  for (size_t L = 0; L < levels.size(); L++) {
+    const LevelWork &lw = levels[L];
+    std::vector<Unit> units;
     std::vector<const RowWork *> longs;
     std::vector<std::vector<const RowWork *>> byT(7);
     for (const RowWork &rw : lw.rowsA) {
@@ -181,18 +170,82 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch) {
     }
     std::stable_sort(longs.begin(), longs.end(),
                      [](const RowWork *a, const RowWork *b) { return a->ent.size() > b->ent.size(); });
-    for (const RowWork *rw : longs) emit({rw}, 64, ((int)rw->ent.size() + 63) / 64);
+    // long rows: rpt rows share a wave (T = 64/rpt lanes each) so that the level needs <= nw long units
+    int rpt = 1;
+    while (rpt < 8 && (int)longs.size() > nw * rpt) rpt <<= 1;
+    for (size_t i = 0; i < longs.size(); i += rpt) {
+      std::vector<const RowWork *> grp(longs.begin() + i, longs.begin() + std::min(longs.size(), i + rpt));
+      int T = 64 / rpt, S = 0;
+      for (const RowWork *r : grp) S = std::max(S, ((int)r->ent.size() + T - 1) / T);
+      Unit u;
+      for (int st = 0; st < S; st++) u.steps.push_back({ilog2(T), st == S - 1, grp, st * T});
+      units.push_back(std::move(u));
+    }
     for (int lt = 6; lt >= 0; lt--) {
       int T = 1 << lt, per = 64 / T;
       const auto &v = byT[lt];
       for (size_t i = 0; i < v.size(); i += per) {
         std::vector<const RowWork *> grp(v.begin() + i, v.begin() + std::min(v.size(), i + per));
-        emit(grp, T, 1);
+        Unit u;
+        u.steps.push_back({lt, true, grp, 0});
+        units.push_back(std::move(u));
       }
     }
-    uint32_t a_end = (uint32_t)sch.n_taskA();
+    // longest-processing-time assignment of units to waves
+    std::vector<size_t> order(units.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
+    std::vector<int> load(nw, 0);
+    per_level_wave[L].assign(nw, {});
+    for (size_t k : order) {
+      int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+      load[w] += (int)units[k].steps.size();
+      per_level_wave[L][w].push_back(std::move(units[k]));
+    }
+  }
+  // emit phase-A steps, wave by wave inside each level
+  for (size_t L = 0; L < levels.size(); L++) {
+    uint32_t level_steps = 0;
+    std::vector<uint32_t> ranges;
+    for (int w = 0; w < nw; w++) {
+      uint32_t begin = sch.n_steps;
+      for (const Unit &u : per_level_wave[L][w])
+        for (const StepSpec &st : u.steps) {
+          uint32_t stepno = sch.n_steps++;
+          uint32_t base = stepno * 64u;
+          sch.idx.resize((size_t)sch.n_steps * 64, 0u);
+          sch.src.resize((size_t)sch.n_steps * 64, -1);
+          int T = 1 << st.lt;
+          for (int g = 0; g < (int)st.rows.size(); g++) {
+            const auto &ent = st.rows[g]->ent;
+            for (int e = st.first_entry; e < std::min<int>((int)ent.size(), st.first_entry + T); e++) {
+              uint32_t slot = base + (uint32_t)(g * T + (e - st.first_entry));
+              sch.idx[slot] = ent[e].first; sch.src[slot] = ent[e].second;
+            }
+          }
+          uint32_t ob = 0;
+          if (st.flush) {
+            ob = (uint32_t)sch.outA.size();
+            for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
+          }
+          sch.step.push_back((uint32_t)st.lt | ((uint32_t)st.flush << 3) | (ob << 4));
+          level_steps++;
+        }
+      ranges.push_back(begin); ranges.push_back(sch.n_steps);
+    }
+    sch.lvl.insert(sch.lvl.end(), ranges.begin(), ranges.end());
+    sch.lvl.insert(sch.lvl.end(), {0u, 0u, level_steps});    // b_begin/b_end patched below
+  }
+  // one all-zero step: the branch-free prefetch reads it in place of steps past the end of a range
+  sch.zero_step = sch.n_steps++;
+  sch.idx.resize((size_t)sch.n_steps * 64, 0u);
+  sch.src.resize((size_t)sch.n_steps * 64, -1);
+  sch.step.push_back(0u);
+  sch.n_slots = sch.n_steps * 64u;
+  // phase-B block tasks: slots after all phase-A steps
+  for (size_t L = 0; L < levels.size(); L++) {
     uint32_t b_begin = (uint32_t)sch.n_taskB();
-    for (const BlockWork &bw : lw.blocksB) {
+    for (const BlockWork &bw : levels[L].blocksB) {
       int r = (int)bw.rows.size();
       if (r < 2) continue;
       uint32_t base = sch.n_slots;
@@ -205,13 +258,13 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch) {
       for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < r ? bw.rows[i] : kNoRow);
       sch.taskB.insert(sch.taskB.end(), {base, (uint32_t)r, out_base, 0u});
     }
-    uint32_t b_end = (uint32_t)sch.n_taskB();
-    sch.lvl.insert(sch.lvl.end(), {a_begin, a_end, b_begin, b_end});
+    size_t o = L * sch.lvl_stride() + 2 * (size_t)nw;
+    sch.lvl[o] = b_begin; sch.lvl[o + 1] = (uint32_t)sch.n_taskB();
   }
 }
 }  // namespace
 
-static void build_tri_schedules(Analysis &an) {
+static void build_tri_schedules(Analysis &an, int nw) {
   int N = an.N;
   int nch = (int)an.chunk_start.size() - 1;
   std::vector<int> chunk_of(N);
@@ -243,7 +296,7 @@ static void build_tri_schedules(Analysis &an) {
       }
       if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
-    pack_schedule(lw, an.fwd);
+    pack_schedule(lw, an.fwd, nw);
   }
   // ---- backward: columns descending, sources are rows j > column
   {
@@ -271,13 +324,13 @@ static void build_tri_schedules(Analysis &an) {
       }
       if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
-    pack_schedule(lw, an.bwd);
+    pack_schedule(lw, an.bwd, nw);
   }
 }
 
 // check-SpMV: rows 0..n-1 = P x, n..2n-1 = A' y, 2n..2n+m-1 = A x; gather vector
 // is [x ; y]; values come from the combined array [P triu | A].
-static void build_chk_schedule(Analysis &an) {
+static void build_chk_schedule(Analysis &an, int nw) {
   int n = an.n, m = an.m, nnzP = an.Pp[n];
   std::vector<LevelWork> lw(3);
   std::vector<RowWork> px(n), aty(n), ax(m);
@@ -296,7 +349,7 @@ static void build_chk_schedule(Analysis &an) {
       ax[r].ent.push_back({(uint32_t)c, nnzP + k});
     }
   lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
-  pack_schedule(lw, an.chk);
+  pack_schedule(lw, an.chk, nw);
 }
 
 // ------------------------------------------------ block factor (device refactor)
@@ -403,7 +456,8 @@ static void build_block_factor(Analysis &an) {
 // --------------------------------------------------------------------- analyze
 
 int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an) {
+            const int64_t *Ai, Analysis &an, int nwaves) {
+  if (nwaves < 1 || nwaves > 16) return MI_OSQP_ERR_INVALID_SETTINGS;
   if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
   int n = (int)n64, m = (int)m64, N = n + m;
   an = Analysis();
@@ -490,8 +544,8 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
     for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) an.chunk_start.push_back(c);
   an.chunk_start.push_back(N);
-  build_tri_schedules(an);
-  build_chk_schedule(an);
+  build_tri_schedules(an, nwaves);
+  build_chk_schedule(an, nwaves);
   build_block_factor(an);
   return MI_OSQP_OK;
 }
@@ -667,25 +721,31 @@ void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs
 }
 
 static void replay(const Schedule &s, const double *canon, double *xs, bool subtract, double *out) {
+  const size_t stride = s.lvl_stride();
   for (int L = 0; L < s.n_levels; L++) {
-    const uint32_t *lv = &s.lvl[4 * L];
-    for (uint32_t t = lv[0]; t < lv[1]; t++) {
-      const uint32_t *tk = &s.taskA[4 * t];
-      uint32_t base = tk[0], S = tk[1], T = 1u << tk[2], ob = tk[3];
-      for (uint32_t g = 0; g < 64 / T; g++) {
-        uint32_t row = s.outA[ob + g];
-        if (row == kNoRow) continue;
-        double acc = 0.0;
-        for (uint32_t st = 0; st < S; st++)
-          for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) {
-            uint32_t slot = base + st * 64 + ln;
-            double v = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
-            acc += v * xs[s.idx[slot]];
+    const uint32_t *lv = &s.lvl[L * stride];
+    for (int w = 0; w < s.nw; w++) {
+      double acc[64];
+      for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
+      for (uint32_t st = lv[2 * w]; st < lv[2 * w + 1]; st++) {
+        const uint32_t d = s.step[st], lt = d & 7u, flush = (d >> 3) & 1u, ob = d >> 4, T = 1u << lt;
+        for (uint32_t ln = 0; ln < 64; ln++) {
+          uint32_t slot = st * 64 + ln;
+          double v = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
+          acc[ln] += v * xs[s.idx[slot]];
+        }
+        if (flush) {
+          for (uint32_t g = 0; g < 64 / T; g++) {
+            double sum = 0.0;
+            for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[ln];
+            uint32_t row = s.outA[ob + g];
+            if (row != kNoRow) { if (subtract) xs[row] -= sum; else out[row] = sum; }
           }
-        if (subtract) xs[row] -= acc; else out[row] = acc;
+          for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
+        }
       }
     }
-    for (uint32_t t = lv[2]; t < lv[3]; t++) {
+    for (uint32_t t = lv[2 * s.nw]; t < lv[2 * s.nw + 1]; t++) {
       const uint32_t *tk = &s.taskB[4 * t];
       uint32_t base = tk[0], r = tk[1], ob = tk[2];
       double acc[kChunk];

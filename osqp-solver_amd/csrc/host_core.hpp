@@ -32,21 +32,27 @@ struct Settings {
 int validate_settings(const Settings &s);   // 0 ok
 
 // One pull-schedule: every target row t gets  xs[t] -= sum_k val[k] * xs[idx[k]].
-// Phase A ("row tasks"): a wave task covers 64 lanes x S steps; groups of T lanes
-// (T a power of two) own one target row and are reduced by a butterfly.
+// Phase A is emitted as per-wave STEP PROGRAMS: for every level each of the nw
+// waves of the workgroup owns one contiguous range of wave-steps (64 lanes x 1
+// slot each).  A step carries (lt, flush, out_base): groups of T = 2^lt lanes
+// accumulate one target row; on a flush step the groups are reduced and applied
+// to the 64/T rows listed at out_base.  Long rows span several steps (flush on
+// the last), short rows are one flush step each.  Because a wave's steps of a
+// level are contiguous in slot space, its values stream from HBM and can be
+// prefetched across the level barrier.
 // Phase B ("block tasks"): the dense in-block triangle of a <=16-row chunk of a
 // supernode, solved column-by-column inside one wave.
 struct Schedule {
-  int n_levels = 0;
-  std::vector<uint32_t> lvl;    // 4/level: a_begin, a_end, b_begin, b_end (task indices)
-  std::vector<uint32_t> taskA;  // 4/task : slot_base, S, log2T, out_base
-  std::vector<uint32_t> outA;   // target rows per task (64/T each), kNoRow = none
+  int n_levels = 0, nw = 0;
+  std::vector<uint32_t> lvl;    // per level, stride 2*nw+3: (step_begin, step_end) per wave, b_begin, b_end, n_steps_in_level
+  std::vector<uint32_t> step;   // per wave-step: lt | flush << 3 | out_base << 4
+  std::vector<uint32_t> outA;   // target rows of flush steps (64/T each), kNoRow = none
   std::vector<uint32_t> taskB;  // 4/task : slot_base, r, out_base, 0
   std::vector<uint32_t> outB;   // kChunk rows per block task, processing order
   std::vector<uint32_t> idx;    // per slot: gather index into the LDS vector
   std::vector<int32_t> src;     // per slot: canonical value index, -1 = structural zero
-  uint32_t n_slots = 0;
-  size_t n_taskA() const { return taskA.size() / 4; }
+  uint32_t n_slots = 0, n_steps = 0, zero_step = 0;   // zero_step: an all-zero padding step (prefetch filler)
+  size_t lvl_stride() const { return 2 * (size_t)nw + 3; }
   size_t n_taskB() const { return taskB.size() / 4; }
 };
 
@@ -98,8 +104,10 @@ struct Analysis {
 
 // E1 (pattern part), E4, E5-symbolic and the schedules.  Returns 0 or an error
 // code of include/mi_osqp.h.
+// `nwaves` = waves per workgroup the device kernels will run with (the phase-A
+// step programs are laid out per wave).
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an);
+            const int64_t *Ai, Analysis &an, int nwaves = 8);
 
 // Per-QP numeric state kept on the host (needed for rescaling and refactors).
 struct QPNumeric {

@@ -52,94 +52,301 @@ __device__ __forceinline__ void load_bt(const double *__restrict__ p, double (&o
   }
 }
 
+// buffer (SRSRC) loads: wave-uniform base in SGPRs + a 32-bit per-lane offset + a
+// scalar step offset, so the deep prefetch below costs no 64-bit address VGPRs
+typedef unsigned int mi_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int mi_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t mi_rsrc;
+__device__ __forceinline__ mi_rsrc make_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+template <int BT>
+__device__ __forceinline__ void buf_load_bt(mi_rsrc r, uint32_t voff, uint32_t soff, double (&o)[BT]) {
+  if constexpr (BT == 1) {
+    const mi_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    o[0] = __hiloint2double((int)t.y, (int)t.x);
+  } else if constexpr (BT == 2) {
+    const mi_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    o[0] = __hiloint2double((int)t.y, (int)t.x); o[1] = __hiloint2double((int)t.w, (int)t.z);
+  } else {
+    const mi_u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const mi_u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0);
+    o[0] = __hiloint2double((int)t0.y, (int)t0.x); o[1] = __hiloint2double((int)t0.w, (int)t0.z);
+    o[2] = __hiloint2double((int)t1.y, (int)t1.x); o[3] = __hiloint2double((int)t1.w, (int)t1.z);
+  }
+}
+
 __device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
+
+// DPP move of a double (both halves); invalid source lanes read 0
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+#define DPP_XOR1 0xB1       /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E       /* quad_perm [2,3,0,1] */
+#define DPP_SHL(n) (0x100 + (n))   /* row_shl:n -- lane i reads lane i+n of its 16-lane row */
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic but NOT for its
+// outstanding global loads, so register prefetches stay in flight across it
+// (a __syncthreads() would drain vmcnt to 0).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ----------------------------------------------------------------- row tasks
-// SUB = true : xs[row] -= acc   (triangular solves, vector in LDS)
-// SUB = false: out[row] = acc   (SpMV for residuals; out in global memory)
+// Reduce acc[] over aligned groups of T = 2^lt lanes and apply it to the target
+// row.  The BT per-QP partial sums are "transposed" across lanes on the way
+// (after log2(BT) steps every lane carries ONE QP's partial sum), then summed
+// toward the first lanes of the group with DPP row shifts; only the two
+// cross-row steps (16, 32) use ds_bpermute.
+// SUB = true : xs[row] -= sum (triangular solves) ; false: out[row] = sum (SpMV)
 template <int BT, bool SUB>
-__device__ __forceinline__ void run_taskA(const SchedDev &s, const double *__restrict__ vals,
-                                          double *xs, double *out, uint32_t t, int lane) {
-  const uint4 tk = reinterpret_cast<const uint4 *>(s.taskA)[t];
-  const uint32_t base = tk.x, S = tk.y, lt = tk.z, ob = tk.w;
-  double acc[BT];
+__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t ob, const SchedDev &s,
+                                             double *xs, double *out, int lane) {
+  double *base = SUB ? xs : out;
+  if (lt == 0) {
+    const uint32_t row = s.outA[ob + (uint32_t)lane];
+    if (row != MI_NOROW) {
+      double *dst = base + (size_t)row * BT;
 #pragma unroll
-  for (int b = 0; b < BT; b++) acc[b] = 0.0;
-  uint32_t slot = base + (uint32_t)lane;
-#pragma unroll 4
-  for (uint32_t st = 0; st < S; st++, slot += 64u) {
-    const uint32_t gi = s.idx[slot];
-    double v[BT], xv[BT];
-    load_bt<BT>(vals + (size_t)slot * BT, v);
-    load_bt<BT>(xs + (size_t)gi * BT, xv);
-#pragma unroll
-    for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
+      for (int b = 0; b < BT; b++) { if (SUB) dst[b] -= acc[b]; else dst[b] = acc[b]; }
+    }
+    return;
   }
-  const int T = 1 << lt;
-  for (int off = 1; off < T; off <<= 1) {
-#pragma unroll
-    for (int b = 0; b < BT; b++) acc[b] += shfl_xor_d(acc[b], off);
+  const uint32_t T = 1u << lt;
+  double kp;
+  int q;            // QP this lane ends up carrying
+  uint32_t nwr;     // number of writer lanes at the start of each group
+  if constexpr (BT == 4) {
+    const bool o0 = lane & 1;
+    const double s0 = o0 ? acc[0] : acc[2], s1 = o0 ? acc[1] : acc[3];
+    double k0 = o0 ? acc[2] : acc[0], k1 = o0 ? acc[3] : acc[1];
+    k0 += dpp_d<DPP_XOR1>(s0); k1 += dpp_d<DPP_XOR1>(s1);
+    if (lt == 1) {                       // groups of 2 lanes: even lane owns QPs 0,1 ; odd lane QPs 2,3
+      const uint32_t row = s.outA[ob + ((uint32_t)lane >> 1)];
+      if (row != MI_NOROW) {
+        double *dst = base + (size_t)row * BT + (o0 ? 2 : 0);
+        if (SUB) { dst[0] -= k0; dst[1] -= k1; } else { dst[0] = k0; dst[1] = k1; }
+      }
+      return;
+    }
+    const bool o1 = lane & 2;
+    const double sd = o1 ? k0 : k1;
+    kp = o1 ? k1 : k0;
+    kp += dpp_d<DPP_XOR2>(sd);
+    q = (o0 ? 2 : 0) + (o1 ? 1 : 0);
+    nwr = 4;
+    if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
+    if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
+  } else if constexpr (BT == 2) {
+    const bool o0 = lane & 1;
+    const double sd = o0 ? acc[0] : acc[1];
+    kp = o0 ? acc[1] : acc[0];
+    kp += dpp_d<DPP_XOR1>(sd);
+    q = o0 ? 1 : 0;
+    nwr = 2;
+    if (lt > 1) kp += dpp_d<DPP_SHL(2)>(kp);
+    if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
+    if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
+  } else {
+    kp = acc[0];
+    q = 0;
+    nwr = 1;
+    kp += dpp_d<DPP_SHL(1)>(kp);
+    if (lt > 1) kp += dpp_d<DPP_SHL(2)>(kp);
+    if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
+    if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
   }
-  if ((lane & (T - 1)) == 0) {
+  if (lt > 4) kp += shfl_down_d(kp, 16);
+  if (lt > 5) kp += shfl_down_d(kp, 32);
+  if (((uint32_t)lane & (T - 1)) < nwr) {
     const uint32_t row = s.outA[ob + ((uint32_t)lane >> lt)];
     if (row != MI_NOROW) {
-      double *dst = (SUB ? xs : out) + (size_t)row * BT;
-#pragma unroll
-      for (int b = 0; b < BT; b++) {
-        if (SUB) dst[b] -= acc[b]; else dst[b] = acc[b];
-      }
+      double *dst = base + (size_t)row * BT + q;
+      if (SUB) *dst -= kp; else *dst = kp;
     }
   }
 }
 
-// dense in-chunk triangle (<=16 rows) solved inside one wave: lane = (i, b);
-// for p = 0..r-2 the finished value of local row p is broadcast and every lane
-// i > p subtracts L[p->i] * v (structural zeros are stored as 0).
-template <int BT>
-__device__ __forceinline__ void run_taskB(const SchedDev &s, const double *__restrict__ vals,
-                                          double *xs, uint32_t t, int lane) {
-  const uint4 tk = reinterpret_cast<const uint4 *>(s.taskB)[t];
-  const uint32_t base = tk.x, r = tk.y, ob = tk.z;
+// ---- phase A: per-wave step programs -------------------------------------------
+// A wave's steps of one level are contiguous; the first PF of them are prefetched
+// into registers (values + gather indices), later ones are loaded on the fly.
+#define MI_NORANGE 0xFFFFFFFFu
+// prefetch depth in wave-steps: 15 covers a 450-entry row on 32 lanes (the dense
+// chunks of BASELINE config 3) and is what fits 256 VGPRs at BT = 4
+#ifndef MI_PFV
+#define MI_PFV 15
+#endif
+template <int BT, int PF>
+struct PrefA { double v[PF][BT]; uint32_t gi[PF]; uint32_t desc; uint32_t begin, end; };
+
+struct ValSrc { mi_rsrc vals, idx; };     // one tile's value stream + the shared gather indices
+
+template <int BT, int PF>
+__device__ __forceinline__ void prefetch_steps(const SchedDev &s, const ValSrc &vs, uint32_t begin,
+                                               uint32_t end, int lane, PrefA<BT, PF> &p) {
+  p.begin = begin; p.end = end;
+  const uint32_t n = end - begin;
+  p.desc = ((uint32_t)lane < n) ? s.step[begin + (uint32_t)lane] : 0u;     // lane st holds the descriptor of step st
+  const uint32_t vo = (uint32_t)lane * (uint32_t)(BT * 8), io = (uint32_t)lane * 4u;
+  // branch-free: steps past the end read the schedule's all-zero padding step
+  // (value 0, gather index 0); the step number is wave-uniform -> scalar offsets
+#pragma unroll
+  for (int st = 0; st < PF; st++) {
+    const uint32_t stepno = (uint32_t)st < n ? begin + (uint32_t)st : s.zero_step;
+    p.gi[st] = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, io, stepno * 256u, 0);
+    buf_load_bt<BT>(vs.vals, vo, stepno * (uint32_t)(64 * BT * 8), p.v[st]);
+  }
+}
+
+template <int BT, int PF, bool SUB>
+__device__ __forceinline__ void consume_steps(const SchedDev &s, const ValSrc &vs, double *xs,
+                                              double *out, const PrefA<BT, PF> &p, int lane) {
+  const uint32_t n = p.end - p.begin;
+  double acc[BT];
+#pragma unroll
+  for (int b = 0; b < BT; b++) acc[b] = 0.0;
+#pragma unroll
+  for (int st = 0; st < PF; st++) {
+    // steps past the end carry value 0 / index 0 / descriptor 0: harmless, no branch
+    double xv[BT];
+    load_bt<BT>(xs + (size_t)p.gi[st] * BT, xv);
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[b] = fma(p.v[st][b], xv[b], acc[b]);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)p.desc, st);
+    if (d & 8u) {
+      reduce_write<BT, SUB>(acc, d & 7u, d >> 4, s, xs, out, lane);
+#pragma unroll
+      for (int b = 0; b < BT; b++) acc[b] = 0.0;
+    }
+    if ((st & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the LDS gathers in flight (registers)
+  }
+  const uint32_t vo = (uint32_t)lane * (uint32_t)(BT * 8), io = (uint32_t)lane * 4u;
+  for (uint32_t st = PF; st < n; st++) {
+    const uint32_t stepno = p.begin + st;
+    const uint32_t gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, io, stepno * 256u, 0);
+    double v[BT], xv[BT];
+    buf_load_bt<BT>(vs.vals, vo, stepno * (uint32_t)(64 * BT * 8), v);
+    load_bt<BT>(xs + (size_t)gi * BT, xv);
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
+    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.step[stepno]);
+    if (d & 8u) {
+      reduce_write<BT, SUB>(acc, d & 7u, d >> 4, s, xs, out, lane);
+#pragma unroll
+      for (int b = 0; b < BT; b++) acc[b] = 0.0;
+    }
+  }
+}
+
+// ---- phase B: dense in-chunk triangle (<=16 rows) solved inside one wave: lane =
+// (i, b); for p = 0..r-2 the finished value of local row p is broadcast and every
+// lane i > p subtracts L[p->i] * v (structural zeros are stored as 0).  The 15
+// values per lane are prefetched into the SAME register buffer as phase-A steps
+// (a wave never holds both): element k lives in v[k / BT][k % BT].
+template <int BT, int PF>
+__device__ __forceinline__ void prefetch_B(const SchedDev &s, const ValSrc &vs, uint32_t t, int lane,
+                                           PrefA<BT, PF> &p) {
+  static_assert(PF * BT >= MI_CHUNK - 1, "prefetch buffer too small for a block task");
+  const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  const uint32_t base = s.taskB[4 * tu], r = s.taskB[4 * tu + 1];
+  p.begin = MI_NORANGE - 1u - tu;            // tag: "holds block task tu"
+  p.end = s.taskB[4 * tu + 2];               // out_base
+  const bool active = lane < MI_CHUNK * BT;
+  const uint32_t vo = active ? (uint32_t)lane * 8u : 0u;
+#pragma unroll
+  for (int k = 0; k < MI_CHUNK - 1; k++) {
+    // rows past r read the all-zero padding step instead (no branch); lanes >= 16*BT hold junk that is never used
+    const uint32_t sl = (uint32_t)k + 1 < r ? base + (uint32_t)k * MI_CHUNK : s.zero_step * 64u;
+    const mi_u32x2 tt = __builtin_amdgcn_raw_buffer_load_b64(vs.vals, vo, sl * (uint32_t)(BT * 8), 0);
+    p.v[k / BT][k % BT] = __hiloint2double((int)tt.y, (int)tt.x);
+  }
+}
+
+template <int BT, int PF>
+__device__ __forceinline__ void consume_B(const SchedDev &s, double *xs, const PrefA<BT, PF> &p, int lane) {
   const int i = lane / BT, b = lane % BT;
   const bool active = lane < MI_CHUNK * BT;
   uint32_t row = MI_NOROW;
-  if (active) row = s.outB[ob + i];
+  if (active) row = s.outB[p.end + i];
   const bool valid = row != MI_NOROW;
   double acc = valid ? xs[(size_t)row * BT + b] : 0.0;
-  double lv[MI_CHUNK - 1];
 #pragma unroll
-  for (int p = 0; p < MI_CHUNK - 1; p++)
-    lv[p] = (active && (uint32_t)p + 1 < r) ? vals[((size_t)base + p * MI_CHUNK + i) * BT + b] : 0.0;
-#pragma unroll
-  for (int p = 0; p < MI_CHUNK - 1; p++) {
-    const double v = shfl_d(acc, p * BT + b);
-    acc = fma(-lv[p], v, acc);
+  for (int k = 0; k < MI_CHUNK - 1; k++) {
+    const double v = shfl_d(acc, k * BT + b);
+    acc = fma(-p.v[k / BT][k % BT], v, acc);
   }
   if (valid) xs[(size_t)row * BT + b] = acc;
 }
 
-template <int BT>
-__device__ __forceinline__ void run_tri(const SchedDev &s, const double *__restrict__ vals, double *xs,
-                                        int wave, int nw, int lane) {
-  for (int L = 0; L < s.n_levels; L++) {
-    const uint4 lv = reinterpret_cast<const uint4 *>(s.lvl)[L];
-    if (lv.y > lv.x) {
-      for (uint32_t t = lv.x + wave; t < lv.y; t += nw) run_taskA<BT, true>(s, vals, xs, nullptr, t, lane);
-      __syncthreads();
+// Level loop of one triangular solve, software-pipelined across the barriers:
+// every wave keeps ONE register buffer that always holds its next piece of work
+// (a phase-A step range or a phase-B block task).  Values do not depend on the
+// solve vector, so their loads are issued right after the previous piece was
+// consumed and stay in flight across the LDS-only barriers.
+template <int BT, int PF>
+__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs,
+                                        int wave, int lane) {
+  const int nw = s.nw;
+  const uint32_t stride = 2u * (uint32_t)nw + 3u;
+  const int nph = 2 * s.n_levels;                         // phase 2L = A of level L, 2L+1 = B of level L
+  PrefA<BT, PF> pa; pa.begin = MI_NORANGE; pa.end = 0; pa.desc = 0;
+  // issue the loads of this wave's first piece of work at or after phase ph0
+  auto prefetch_next = [&](int ph0) {
+    for (int ph = ph0; ph < nph; ph++) {
+      const uint32_t *lv = s.lvl + (size_t)(ph >> 1) * stride;
+      if (!(ph & 1)) {
+        const uint32_t rb = lv[2 * wave], re = lv[2 * wave + 1];
+        if (re > rb) { prefetch_steps<BT, PF>(s, vals, rb, re, lane, pa); return; }
+      } else {
+        const uint32_t t = lv[2 * nw] + (uint32_t)wave;
+        if (t < lv[2 * nw + 1]) { prefetch_B<BT, PF>(s, vals, t, lane, pa); return; }
+      }
     }
-    if (lv.w > lv.z) {
-      for (uint32_t t = lv.z + wave; t < lv.w; t += nw) run_taskB<BT>(s, vals, xs, t, lane);
-      __syncthreads();
+  };
+  prefetch_next(0);
+  for (int ph = 0; ph < nph; ph++) {
+    const uint32_t *lv = s.lvl + (size_t)(ph >> 1) * stride;
+    bool consumed = false;
+    if (!(ph & 1)) {
+      if (lv[2 * nw + 2] == 0) continue;                  // level without phase A (uniform)
+      const uint32_t rb = lv[2 * wave], re = lv[2 * wave + 1];
+      if (re > rb) { consume_steps<BT, PF, true>(s, vals, xs, nullptr, pa, lane); consumed = true; }
+    } else {
+      const uint32_t b0 = lv[2 * nw], b1 = lv[2 * nw + 1];
+      if (b1 <= b0) continue;                             // level without phase B (uniform)
+      for (uint32_t t = b0 + (uint32_t)wave; t < b1; t += (uint32_t)nw) {
+        if (pa.begin != MI_NORANGE - 1u - t) prefetch_B<BT, PF>(s, vals, t, lane, pa);   // only a wave's 2nd+ task of a level
+        consume_B<BT, PF>(s, xs, pa, lane);
+        consumed = true;
+      }
     }
+    if (consumed) {
+      __builtin_amdgcn_sched_barrier(0);                  // keep the refill behind the consumption (one buffer)
+      prefetch_next(ph + 1);
+    }
+    lds_barrier();
   }
 }
 
-template <int BT>
-__device__ __forceinline__ void run_spmv(const SchedDev &s, const double *__restrict__ vals, double *xs,
-                                         double *out, int wave, int nw, int lane, int lvl0, int lvl1) {
-  const uint32_t t0 = s.lvl[4 * lvl0], t1 = s.lvl[4 * (lvl1 - 1) + 1];
-  for (uint32_t t = t0 + wave; t < t1; t += nw) run_taskA<BT, false>(s, vals, xs, out, t, lane);
+// SpMV with the same step programs (levels lvl0..lvl1-1 of the check schedule, no barriers)
+template <int BT, int PF>
+__device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc &vals, double *xs,
+                                         double *out, int wave, int lane, int lvl0, int lvl1) {
+  const uint32_t stride = 2u * (uint32_t)s.nw + 3u;
+  PrefA<BT, PF> pa;
+  for (int L = lvl0; L < lvl1; L++) {
+    const uint32_t *lv = s.lvl + (size_t)L * stride;
+    const uint32_t rb = lv[2 * wave], re = lv[2 * wave + 1];
+    if (re > rb) {
+      prefetch_steps<BT, PF>(s, vals, rb, re, lane, pa);
+      consume_steps<BT, PF, false>(s, vals, xs, out, pa, lane);
+    }
+  }
 }
 
 // --------------------------------------------------------- block reductions
@@ -185,6 +392,7 @@ struct TilePtrs {
   const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
   double *dx, *dy, *out1, *out2, *dscal;
   int *iscal;
+  ValSrc vfwd, vbwd, vchk;
 };
 
 template <int BT>
@@ -204,24 +412,27 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile)
   p.out1 = a.out1 + t * (2 * n + m) * BT; p.out2 = a.out2 + t * (2 * n + m) * BT;
   p.dscal = a.dscal + t * DS_COUNT * BT;
   p.iscal = a.iscal + t * IS_COUNT * BT;
+  p.vfwd.vals = make_rsrc(p.fwd_val, a.fwd.n_slots * (uint32_t)(BT * 8)); p.vfwd.idx = make_rsrc(a.fwd.idx, a.fwd.n_slots * 4u);
+  p.vbwd.vals = make_rsrc(p.bwd_val, a.bwd.n_slots * (uint32_t)(BT * 8)); p.vbwd.idx = make_rsrc(a.bwd.idx, a.bwd.n_slots * 4u);
+  p.vchk.vals = make_rsrc(p.chk_val, a.chk.n_slots * (uint32_t)(BT * 8)); p.vchk.idx = make_rsrc(a.chk.idx, a.chk.n_slots * 4u);
   return p;
 }
 
 // K solve on the LDS vector: fwd levels, D^-1, bwd levels (row E7)
-template <int BT>
+template <int BT, int PF>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
                                               int tid, int nthr, int wave, int nw, int lane) {
-  run_tri<BT>(a.fwd, p.fwd_val, xs, wave, nw, lane);
+  run_tri<BT, PF>(a.fwd, p.vfwd, xs, wave, lane);
   for (int e = tid; e < a.N * BT; e += nthr) xs[e] *= p.dinv[e];
   __syncthreads();
-  run_tri<BT>(a.bwd, p.bwd_val, xs, wave, nw, lane);
+  run_tri<BT, PF>(a.bwd, p.vbwd, xs, wave, lane);
 }
 
-template <int BT>
-__global__ __launch_bounds__(1024) void admm_kernel(KernelArgs a) {
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void admm_kernel(KernelArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
   const int n = a.n, m = a.m, N = a.N;
   double *xs = smem;
@@ -257,7 +468,7 @@ __global__ __launch_bounds__(1024) void admm_kernel(KernelArgs a) {
     }
     __syncthreads();
     // ---- E7
-    kkt_solve_lds<BT>(a, p, xs, tid, nthr, wave, nw, lane);
+    kkt_solve_lds<BT, MI_PFV>(a, p, xs, tid, nthr, wave, nw, lane);
     // ---- E8-E10 (run_tri ends with a barrier)
     for (int e = tid; e < n * BT; e += nthr) {
       const int i = e / BT;
@@ -284,7 +495,7 @@ __global__ __launch_bounds__(1024) void admm_kernel(KernelArgs a) {
       for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
       for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
       __syncthreads();
-      run_spmv<BT>(a.chk, p.chk_val, xs, p.out1, wave, nw, lane, 0, 3);
+      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
       __syncthreads();
       // residual vectors and the norms termination + rho estimate need
       double mx[14];
@@ -338,7 +549,7 @@ __global__ __launch_bounds__(1024) void admm_kernel(KernelArgs a) {
         si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
       }
       __syncthreads();
-      run_spmv<BT>(a.chk, p.chk_val, xs, p.out2, wave, nw, lane, 0, 3);
+      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3);
       __syncthreads();
       for (int e = tid; e < n * BT; e += nthr) {
         const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
@@ -458,13 +669,13 @@ __global__ __launch_bounds__(1024) void admm_kernel(KernelArgs a) {
 // ---------------------------------------------------------- standalone ops
 
 // Px, A'y, Ax for QP-major x[B][n], y[B][m]  (rows E11 / E14)
-template <int BT>
-__global__ __launch_bounds__(1024) void spmv_kernel(KernelArgs a, const double *__restrict__ gx,
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__restrict__ gx,
                                                     const double *__restrict__ gy, double *gPx,
                                                     double *gAty, double *gAx) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   const int n = a.n, m = a.m;
   const int qp = tile * BT + b;
   double *xs = smem;
@@ -472,7 +683,7 @@ __global__ __launch_bounds__(1024) void spmv_kernel(KernelArgs a, const double *
   for (int e = tid; e < n * BT; e += nthr) xs[e] = (qp < a.B && gx) ? gx[(size_t)qp * n + e / BT] : 0.0;
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = (qp < a.B && gy) ? gy[(size_t)qp * m + e / BT] : 0.0;
   __syncthreads();
-  run_spmv<BT>(a.chk, p.chk_val, xs, p.out1, wave, nw, lane, 0, 3);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
   __syncthreads();
   if (qp < a.B) {
     if (gPx) for (int e = tid; e < n * BT; e += nthr) gPx[(size_t)qp * n + e / BT] = p.out1[e];
@@ -482,11 +693,11 @@ __global__ __launch_bounds__(1024) void spmv_kernel(KernelArgs a, const double *
 }
 
 // sol = K^-1 rhs for QP-major rhs[B][N]  (row E7)
-template <int BT>
-__global__ __launch_bounds__(1024) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   const int N = a.N;
   const int qp = tile * BT + b;
   double *xs = smem;
@@ -496,17 +707,17 @@ __global__ __launch_bounds__(1024) void kkt_solve_kernel(KernelArgs a, const dou
     xs[(size_t)a.pinv[i] * BT + b] = qp < a.B ? rhs[(size_t)qp * N + i] : 0.0;
   }
   __syncthreads();
-  kkt_solve_lds<BT>(a, p, xs, tid, nthr, wave, nw, lane);
+  kkt_solve_lds<BT, MI_PFV>(a, p, xs, tid, nthr, wave, nw, lane);
   if (qp < a.B)
     for (int e = tid; e < N * BT; e += nthr) { const int i = e / BT; sol[(size_t)qp * N + i] = xs[(size_t)a.pinv[i] * BT + b]; }
 }
 
 // warm start (row E14): x <- Dinv .* x0 ; z <- A x   (QP-major x0[B][n])
-template <int BT>
-__global__ __launch_bounds__(1024) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   const int n = a.n, m = a.m;
   const int qp = tile * BT + b;
   double *xs = smem;
@@ -518,7 +729,7 @@ __global__ __launch_bounds__(1024) void warm_start_kernel(KernelArgs a, const do
   }
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
   __syncthreads();
-  run_spmv<BT>(a.chk, p.chk_val, xs, p.out1, wave, nw, lane, 2, 3);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3);
   __syncthreads();
   for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
@@ -647,7 +858,7 @@ template <int BT>
 __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   const int m = a.m, N = a.N;
   int *iscal = a.iscal + (size_t)tile * IS_COUNT * BT;
   const int flag = a.force_all ? (tile * BT + b < a.B) : iscal[IS_NEED_REFACTOR * BT + b];
@@ -804,69 +1015,36 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
 
 // --------------------------------------------------------------- launchers
 
-template <int BT>
-static hipError_t launch_admm_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&admm_kernel<BT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(admm_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a);
-  return hipGetLastError();
-}
+// all iterate kernels are built for <= 512 threads per workgroup (256 VGPRs per lane
+// hold the 16-step prefetch buffer); the host clamps `threads` accordingly
+#define MI_DISPATCH(KERNEL, ...)                                                                   \
+  do {                                                                                             \
+    hipError_t e_;                                                                                 \
+    auto go = [&](auto kern) -> hipError_t {                                                       \
+      e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e_ != hipSuccess) return e_;                                                             \
+      hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, __VA_ARGS__);                  \
+      return hipGetLastError();                                                                    \
+    };                                                                                             \
+    if (threads > 512) return hipErrorInvalidValue;                                                \
+    if (BT == 1) return go(&KERNEL<1, 512>);                                                       \
+    if (BT == 2) return go(&KERNEL<2, 512>);                                                       \
+    return go(&KERNEL<4, 512>);                                                                    \
+  } while (0)
+
 hipError_t launch_admm(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
-  switch (BT) {
-    case 1: return launch_admm_t<1>(a, tiles, threads, lds, st);
-    case 2: return launch_admm_t<2>(a, tiles, threads, lds, st);
-    default: return launch_admm_t<4>(a, tiles, threads, lds, st);
-  }
-}
-template <int BT>
-static hipError_t launch_spmv_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st,
-                                const double *x, const double *y, double *Px, double *Aty, double *Ax) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_kernel<BT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(spmv_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a, x, y, Px, Aty, Ax);
-  return hipGetLastError();
+  MI_DISPATCH(admm_kernel, a);
 }
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                        const double *x, const double *y, double *Px, double *Aty, double *Ax) {
-  switch (BT) {
-    case 1: return launch_spmv_t<1>(a, tiles, threads, lds, st, x, y, Px, Aty, Ax);
-    case 2: return launch_spmv_t<2>(a, tiles, threads, lds, st, x, y, Px, Aty, Ax);
-    default: return launch_spmv_t<4>(a, tiles, threads, lds, st, x, y, Px, Aty, Ax);
-  }
-}
-template <int BT>
-static hipError_t launch_kkt_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st,
-                               const double *rhs, double *sol) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_solve_kernel<BT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kkt_solve_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a, rhs, sol);
-  return hipGetLastError();
+  MI_DISPATCH(spmv_kernel, a, x, y, Px, Aty, Ax);
 }
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                             const double *rhs, double *sol) {
-  switch (BT) {
-    case 1: return launch_kkt_t<1>(a, tiles, threads, lds, st, rhs, sol);
-    case 2: return launch_kkt_t<2>(a, tiles, threads, lds, st, rhs, sol);
-    default: return launch_kkt_t<4>(a, tiles, threads, lds, st, rhs, sol);
-  }
-}
-template <int BT>
-static hipError_t launch_warm_t(const KernelArgs &a, int tiles, int threads, size_t lds, hipStream_t st, const double *x0) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&warm_start_kernel<BT>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(warm_start_kernel<BT>, dim3(tiles), dim3(threads), lds, st, a, x0);
-  return hipGetLastError();
+  MI_DISPATCH(kkt_solve_kernel, a, rhs, sol);
 }
 hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st, const double *x0) {
-  switch (BT) {
-    case 1: return launch_warm_t<1>(a, tiles, threads, lds, st, x0);
-    case 2: return launch_warm_t<2>(a, tiles, threads, lds, st, x0);
-    default: return launch_warm_t<4>(a, tiles, threads, lds, st, x0);
-  }
+  MI_DISPATCH(warm_start_kernel, a, x0);
 }
 
 static inline unsigned nblk(size_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }

@@ -98,25 +98,25 @@ struct DevBuf {
 };
 
 struct SchedBufs {
-  DevBuf<uint32_t> lvl, taskA, outA, taskB, outB, idx;
+  DevBuf<uint32_t> lvl, step, outA, taskB, outB, idx;
   DevBuf<int32_t> src;
   int upload(const Schedule &s) {
     int rc;
-    if ((rc = lvl.upload(s.lvl)) || (rc = taskA.upload(s.taskA)) || (rc = outA.upload(s.outA)) ||
+    if ((rc = lvl.upload(s.lvl)) || (rc = step.upload(s.step)) || (rc = outA.upload(s.outA)) ||
         (rc = taskB.upload(s.taskB)) || (rc = outB.upload(s.outB)) || (rc = idx.upload(s.idx)) ||
         (rc = src.upload(s.src))) return rc;
     return 0;
   }
   SchedDev view(const Schedule &s) const {
-    SchedDev d; d.lvl = lvl.p; d.taskA = taskA.p; d.outA = outA.p; d.taskB = taskB.p; d.outB = outB.p; d.idx = idx.p;
-    d.n_levels = s.n_levels; d.n_slots = s.n_slots; return d;
+    SchedDev d; d.lvl = lvl.p; d.step = step.p; d.outA = outA.p; d.taskB = taskB.p; d.outB = outB.p; d.idx = idx.p;
+    d.n_levels = s.n_levels; d.nw = s.nw; d.n_slots = s.n_slots; d.zero_step = s.zero_step; return d;
   }
 };
 
 struct mi_osqp_batch {
   Settings st;
   Analysis an;
-  int B = 0, BT = 1, ntiles = 0, threads = 1024, device = 0;
+  int B = 0, BT = 1, ntiles = 0, threads = 512, device = 0;
   size_t lds = 0;
   std::vector<QPNumeric> qp;
   bool host_bounds_stale = false;
@@ -390,7 +390,11 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if (h->st.adaptive_rho && !h->st.adaptive_rho_interval)   // deterministic "auto" (upstream non-PROFILING rule)
     h->st.adaptive_rho_interval = h->st.check_termination ? 4 * h->st.check_termination : 100;
   for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
-  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an);
+  {
+    const char *eth = getenv("MI_OSQP_THREADS");
+    h->threads = eth ? std::max(64, std::min(512, atoi(eth) / 64 * 64)) : 512;
+  }
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64);
   if (rc) return rc;
   const Analysis &an = h->an;
   h->B = (int)B;
@@ -404,8 +408,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
   // ---- tile shape
-  const char *et = getenv("MI_OSQP_TILE"), *eth = getenv("MI_OSQP_THREADS");
-  h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 1024;
+  const char *et = getenv("MI_OSQP_TILE");
   int BT = B >= 768 ? 4 : (B >= 384 ? 2 : 1);
   if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
   const size_t lds_cap = 160 * 1024;
