@@ -7,11 +7,11 @@ namespace miosqp {
 
 #define MI_CHUNK 16
 
-// device view of one host_core.hpp Schedule (index arrays are shared by all tiles)
+// device view of one host_core.hpp Schedule (tables are shared by all tiles)
 struct SchedDev {
-  const uint32_t *lvl, *step, *outA, *taskB, *outB, *idx;
-  int n_levels, nw;
-  uint32_t n_slots, zero_step;
+  const uint32_t *phase, *step, *idxw;
+  int n_phases, nw, sb;
+  uint32_t n_steps, phys_steps, zero_step, n_slots;
 };
 
 // per-QP double scalars, laid out [tile][DS_COUNT][BT]
@@ -34,12 +34,14 @@ struct KernelArgs {
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
   int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;
   int iter_budget;
+  int chk_lvl[4];                       // first phase of the P x / A'y / A x levels of the check schedule (+ end)
 };
 
 // device block refactorisation (row E13); tables are host_core.hpp BlockFactor
 struct FactorArgs {
   int n, m, N, B, nnzP, nnzK, pa_len, n_levels, force_all;
-  uint32_t storage, fwd_slots, bwd_slots;
+  uint32_t storage;
+  SchedDev fwd, bwd;
   const uint32_t *blk, *lvl, *utask, *tri, *dtask, *ttask, *asm_dst, *asm_src;
   const int32_t *fwd_srcblk, *bwd_srcblk;
   const double *pa_val, *l, *u, *dscal;
@@ -59,7 +61,7 @@ hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads
                              const double *x0);
 hipError_t launch_interleave(const double *src, double *dst, const int *ids, int nq, int len, int BT, hipStream_t st);
 hipError_t launch_scatter(const double *src, double *dst, const int *map, const int *ids, int nq, int srclen,
-                          int slots, int BT, hipStream_t st);
+                          const SchedDev &sd, int BT, hipStream_t st);
 hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st);
 hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
 hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,

@@ -150,16 +150,22 @@ struct LevelWork { std::vector<RowWork> rowsA; std::vector<BlockWork> blocksB; }
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw) {
+void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt) {
   sch = Schedule();
   sch.n_levels = (int)levels.size();
-  sch.nw = nw;
+  sch.nw = nw; sch.bt = bt; sch.sb = (kChunk - 1 + bt - 1) / bt;
   // a unit = work that must stay on one wave, in order
   struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; };
   struct Unit { std::vector<StepSpec> steps; };
-  std::vector<std::vector<std::vector<Unit>>> per_level_wave(levels.size());
+  // step 0 is the all-zero padding step: empty ranges point at it
+  sch.zero_step = 0; sch.n_steps = 1;
+  sch.idx.assign(64, 0u); sch.src.assign(64, -1); sch.step.push_back(0u);
+  struct PhaseRec { int kind; std::vector<uint32_t> wave; };   // wave: 4 per wave
+  std::vector<PhaseRec> phases;
+  std::vector<std::vector<const BlockWork *>> level_blocks(levels.size());
   for (size_t L = 0; L < levels.size(); L++) {
     const LevelWork &lw = levels[L];
+    sch.level_first_phase.push_back((int)phases.size());
     std::vector<Unit> units;
     std::vector<const RowWork *> longs;
     std::vector<std::vector<const RowWork *>> byT(7);
@@ -191,80 +197,109 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw) 
         units.push_back(std::move(u));
       }
     }
-    // longest-processing-time assignment of units to waves
-    std::vector<size_t> order(units.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
-    std::vector<int> load(nw, 0);
-    per_level_wave[L].assign(nw, {});
-    for (size_t k : order) {
-      int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-      load[w] += (int)units[k].steps.size();
-      per_level_wave[L][w].push_back(std::move(units[k]));
-    }
-  }
-  // emit phase-A steps, wave by wave inside each level
-  for (size_t L = 0; L < levels.size(); L++) {
-    uint32_t level_steps = 0;
-    std::vector<uint32_t> ranges;
-    for (int w = 0; w < nw; w++) {
-      uint32_t begin = sch.n_steps;
-      for (const Unit &u : per_level_wave[L][w])
-        for (const StepSpec &st : u.steps) {
-          uint32_t stepno = sch.n_steps++;
-          uint32_t base = stepno * 64u;
-          sch.idx.resize((size_t)sch.n_steps * 64, 0u);
-          sch.src.resize((size_t)sch.n_steps * 64, -1);
-          int T = 1 << st.lt;
-          for (int g = 0; g < (int)st.rows.size(); g++) {
-            const auto &ent = st.rows[g]->ent;
-            for (int e = st.first_entry; e < std::min<int>((int)ent.size(), st.first_entry + T); e++) {
-              uint32_t slot = base + (uint32_t)(g * T + (e - st.first_entry));
-              sch.idx[slot] = ent[e].first; sch.src[slot] = ent[e].second;
+    if (!units.empty()) {
+      // longest-processing-time assignment of units to waves
+      std::vector<size_t> order(units.size());
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
+      std::vector<int> load(nw, 0);
+      std::vector<std::vector<size_t>> mine(nw);
+      for (size_t k : order) {
+        int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[w] += (int)units[k].steps.size();
+        mine[w].push_back(k);
+      }
+      PhaseRec ph; ph.kind = 0;
+      for (int w = 0; w < nw; w++) {
+        uint32_t begin = sch.n_steps;
+        for (size_t k : mine[w])
+          for (const StepSpec &st : units[k].steps) {
+            uint32_t stepno = sch.n_steps++;
+            uint32_t base = stepno * 64u;
+            sch.idx.resize((size_t)sch.n_steps * 64, 0u);
+            sch.src.resize((size_t)sch.n_steps * 64, -1);
+            int T = 1 << st.lt;
+            for (int g = 0; g < (int)st.rows.size(); g++) {
+              const auto &ent = st.rows[g]->ent;
+              for (int e = st.first_entry; e < std::min<int>((int)ent.size(), st.first_entry + T); e++) {
+                uint32_t slot = base + (uint32_t)(g * T + (e - st.first_entry));
+                sch.idx[slot] = ent[e].first; sch.src[slot] = ent[e].second;
+              }
             }
+            uint32_t ob = 0;
+            if (st.flush) {
+              ob = (uint32_t)sch.outA.size();
+              for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
+            }
+            sch.step.push_back((uint32_t)st.lt | ((uint32_t)st.flush << 3) | (ob << 4));
           }
-          uint32_t ob = 0;
-          if (st.flush) {
-            ob = (uint32_t)sch.outA.size();
-            for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
-          }
-          sch.step.push_back((uint32_t)st.lt | ((uint32_t)st.flush << 3) | (ob << 4));
-          level_steps++;
-        }
-      ranges.push_back(begin); ranges.push_back(sch.n_steps);
+        uint32_t end = sch.n_steps;
+        if (end == begin) begin = end = sch.zero_step;
+        ph.wave.insert(ph.wave.end(), {begin, end, 0u, 0u});
+      }
+      phases.push_back(std::move(ph));
     }
-    sch.lvl.insert(sch.lvl.end(), ranges.begin(), ranges.end());
-    sch.lvl.insert(sch.lvl.end(), {0u, 0u, level_steps});    // b_begin/b_end patched below
+    // block tasks: at most one per wave per B phase
+    std::vector<const BlockWork *> blks;
+    for (const BlockWork &bw : lw.blocksB) if (bw.rows.size() >= 2) blks.push_back(&bw);
+    level_blocks[L] = blks;
+    for (size_t i = 0; i < blks.size(); i += nw) {
+      PhaseRec ph; ph.kind = 1;
+      for (int w = 0; w < nw; w++) {
+        if (i + w < blks.size()) ph.wave.insert(ph.wave.end(), {0xFFFFFFFFu, (uint32_t)(i + w), (uint32_t)L, 0u});   // patched below
+        else ph.wave.insert(ph.wave.end(), {sch.zero_step, sch.zero_step, 0u, 0u});
+      }
+      phases.push_back(std::move(ph));
+    }
   }
-  // one all-zero step: the branch-free prefetch reads it in place of steps past the end of a range
-  sch.zero_step = sch.n_steps++;
-  sch.idx.resize((size_t)sch.n_steps * 64, 0u);
-  sch.src.resize((size_t)sch.n_steps * 64, -1);
-  sch.step.push_back(0u);
+  sch.level_first_phase.push_back((int)phases.size());
+  // logical slots / physical steps of the block tasks (after all A steps)
   sch.n_slots = sch.n_steps * 64u;
-  // phase-B block tasks: slots after all phase-A steps
-  for (size_t L = 0; L < levels.size(); L++) {
-    uint32_t b_begin = (uint32_t)sch.n_taskB();
-    for (const BlockWork &bw : levels[L].blocksB) {
-      int r = (int)bw.rows.size();
-      if (r < 2) continue;
+  std::vector<std::vector<uint32_t>> task_of(levels.size());
+  for (size_t L = 0; L < levels.size(); L++)
+    for (const BlockWork *bw : level_blocks[L]) {
+      uint32_t task = sch.n_taskB++;
+      task_of[L].push_back(task);
+      int r = (int)bw->rows.size();
       uint32_t base = sch.n_slots;
-      sch.n_slots += (uint32_t)(kChunk * (r - 1));
-      sch.idx.resize(sch.n_slots, 0u);
+      sch.n_slots += (uint32_t)(kChunk * (kChunk - 1));
       sch.src.resize(sch.n_slots, -1);
       for (int p = 0; p < r - 1; p++)
-        for (int i = p + 1; i < r; i++) sch.src[base + p * kChunk + i] = bw.tri[p * r + i];
-      uint32_t out_base = (uint32_t)sch.outB.size();
-      for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < r ? bw.rows[i] : kNoRow);
-      sch.taskB.insert(sch.taskB.end(), {base, (uint32_t)r, out_base, 0u});
+        for (int i = p + 1; i < r; i++) sch.src[base + p * kChunk + i] = bw->tri[p * r + i];
+      for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < r ? bw->rows[i] : kNoRow);
     }
-    size_t o = L * sch.lvl_stride() + 2 * (size_t)nw;
-    sch.lvl[o] = b_begin; sch.lvl[o + 1] = (uint32_t)sch.n_taskB();
+  // device index words
+  sch.idxw.assign((size_t)sch.phys_steps() * 64, 0xFFFF0000u);
+  for (uint32_t st = 0; st < sch.n_steps; st++) {
+    const uint32_t d = sch.step[st], lt = d & 7u, flush = (d >> 3) & 1u, ob = d >> 4;
+    for (uint32_t ln = 0; ln < 64; ln++) {
+      uint32_t row = 0xFFFFu;
+      if (flush) { uint32_t r = sch.outA[ob + (ln >> lt)]; row = r == kNoRow ? 0xFFFFu : r; }
+      sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
+    }
+  }
+  for (uint32_t task = 0; task < sch.n_taskB; task++)
+    for (int i = 0; i < kChunk; i++)
+      for (int b = 0; b < bt; b++) {
+        uint32_t r = sch.outB[task * kChunk + i];
+        sch.idxw[(size_t)(sch.n_steps + task * sch.sb) * 64 + i * bt + b] = (r == kNoRow ? 0xFFFFu : r) << 16;
+      }
+  sch.n_phases = (int)phases.size();
+  for (PhaseRec &ph : phases) {
+    sch.phase.push_back((uint32_t)ph.kind);
+    for (int w = 0; w < nw; w++) {
+      uint32_t *e = &ph.wave[4 * w];
+      if (ph.kind == 1 && e[0] == 0xFFFFFFFFu) {
+        uint32_t task = task_of[e[2]][e[1]];
+        e[0] = sch.n_steps + task * (uint32_t)sch.sb; e[1] = e[0] + (uint32_t)sch.sb; e[2] = task * kChunk; e[3] = 1u;
+      }
+      sch.phase.insert(sch.phase.end(), e, e + 4);
+    }
   }
 }
 }  // namespace
 
-static void build_tri_schedules(Analysis &an, int nw) {
+static void build_tri_schedules(Analysis &an, int nw, int bt) {
   int N = an.N;
   int nch = (int)an.chunk_start.size() - 1;
   std::vector<int> chunk_of(N);
@@ -296,7 +331,7 @@ static void build_tri_schedules(Analysis &an, int nw) {
       }
       if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
-    pack_schedule(lw, an.fwd, nw);
+    pack_schedule(lw, an.fwd, nw, bt);
   }
   // ---- backward: columns descending, sources are rows j > column
   {
@@ -324,13 +359,13 @@ static void build_tri_schedules(Analysis &an, int nw) {
       }
       if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
-    pack_schedule(lw, an.bwd, nw);
+    pack_schedule(lw, an.bwd, nw, bt);
   }
 }
 
 // check-SpMV: rows 0..n-1 = P x, n..2n-1 = A' y, 2n..2n+m-1 = A x; gather vector
 // is [x ; y]; values come from the combined array [P triu | A].
-static void build_chk_schedule(Analysis &an, int nw) {
+static void build_chk_schedule(Analysis &an, int nw, int bt) {
   int n = an.n, m = an.m, nnzP = an.Pp[n];
   std::vector<LevelWork> lw(3);
   std::vector<RowWork> px(n), aty(n), ax(m);
@@ -349,7 +384,7 @@ static void build_chk_schedule(Analysis &an, int nw) {
       ax[r].ent.push_back({(uint32_t)c, nnzP + k});
     }
   lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
-  pack_schedule(lw, an.chk, nw);
+  pack_schedule(lw, an.chk, nw, bt);
 }
 
 // ------------------------------------------------ block factor (device refactor)
@@ -402,8 +437,9 @@ static void build_block_factor(Analysis &an) {
   for (int c = 0; c < nch; c++) cols_of_level[an.chunk_lev[c]].push_back(c);
   for (int L = 0; L < nlev; L++) {
     uint32_t u0 = (uint32_t)(bf.utask.size() / 4), d0 = (uint32_t)bf.dtask.size(), t0 = (uint32_t)(bf.ttask.size() / 2);
-    struct UT { uint32_t id, tb, te; };
+    struct UT { uint32_t id, tb, tm, te; };
     std::vector<UT> uts;
+    auto width_of = [&](uint32_t bid) { return bf.blk[4 * bid + 3] & 255u; };
     for (int J : cols_of_level[L]) {
       const auto &rj = rowlist[J];
       for (const auto &[I, id] : colblk[J]) {
@@ -420,13 +456,22 @@ static void build_block_factor(Analysis &an) {
           }
         }
         uint32_t te = (uint32_t)(bf.tri.size() / 2);
-        if (te > tb) uts.push_back({id, tb, te});
+        // rank-1 sources first (the device batches them 8 at a time)
+        std::vector<std::pair<uint32_t, uint32_t>> tl;
+        for (uint32_t q = tb; q < te; q++) tl.push_back({bf.tri[2 * q], bf.tri[2 * q + 1]});
+        std::stable_partition(tl.begin(), tl.end(), [&](const std::pair<uint32_t, uint32_t> &t) { return width_of(t.first) == 1; });
+        uint32_t tm = tb;
+        for (uint32_t q = tb; q < te; q++) {
+          bf.tri[2 * q] = tl[q - tb].first; bf.tri[2 * q + 1] = tl[q - tb].second;
+          if (width_of(tl[q - tb].first) == 1) tm = q + 1;
+        }
+        if (te > tb) uts.push_back({id, tb, tm, te});
         if (I == J) bf.dtask.push_back(id);
         else bf.ttask.insert(bf.ttask.end(), {id, colblk[J][0].second});
       }
     }
     std::stable_sort(uts.begin(), uts.end(), [](const UT &a, const UT &b) { return a.te - a.tb > b.te - b.tb; });
-    for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.te, 0u});
+    for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.tm, u.te});
     bf.lvl.insert(bf.lvl.end(), {u0, (uint32_t)(bf.utask.size() / 4), d0, (uint32_t)bf.dtask.size(), t0, (uint32_t)(bf.ttask.size() / 2)});
   }
   // assembly map: natural KKT entry -> (storage position, value source)
@@ -456,8 +501,8 @@ static void build_block_factor(Analysis &an) {
 // --------------------------------------------------------------------- analyze
 
 int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves) {
-  if (nwaves < 1 || nwaves > 16) return MI_OSQP_ERR_INVALID_SETTINGS;
+            const int64_t *Ai, Analysis &an, int nwaves, int bt) {
+  if (nwaves < 1 || nwaves > 16 || (bt != 1 && bt != 2 && bt != 4)) return MI_OSQP_ERR_INVALID_SETTINGS;
   if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
   int n = (int)n64, m = (int)m64, N = n + m;
   an = Analysis();
@@ -544,8 +589,8 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
     for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) an.chunk_start.push_back(c);
   an.chunk_start.push_back(N);
-  build_tri_schedules(an, nwaves);
-  build_chk_schedule(an, nwaves);
+  build_tri_schedules(an, nwaves, bt);
+  build_chk_schedule(an, nwaves, bt);
   build_block_factor(an);
   return MI_OSQP_OK;
 }
@@ -720,45 +765,58 @@ void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs
   for (int k = 0; k < N; k++) sol[an.perm[k]] = b[k];
 }
 
+size_t phys_index(const Schedule &s, uint32_t slot, int b) {
+  const uint32_t nA = s.n_steps * 64u;
+  if (slot < nA) return (size_t)slot * s.bt + b;
+  const uint32_t r = slot - nA, task = r / (kChunk * (kChunk - 1)), rem = r % (kChunk * (kChunk - 1));
+  const uint32_t k = rem / kChunk, i = rem % kChunk;
+  return ((size_t)(s.n_steps + task * s.sb + k / s.bt) * 64 + (size_t)i * s.bt + b) * s.bt + k % s.bt;
+}
+
+// sequential interpreter of one schedule (tests): walks the phase table exactly as the device does
 static void replay(const Schedule &s, const double *canon, double *xs, bool subtract, double *out) {
-  const size_t stride = s.lvl_stride();
-  for (int L = 0; L < s.n_levels; L++) {
-    const uint32_t *lv = &s.lvl[L * stride];
+  const size_t stride = s.phase_stride();
+  const uint32_t nA = s.n_steps * 64u;
+  for (int ph = 0; ph < s.n_phases; ph++) {
+    const uint32_t *pr = &s.phase[ph * stride];
+    const uint32_t kind = pr[0];
     for (int w = 0; w < s.nw; w++) {
-      double acc[64];
-      for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
-      for (uint32_t st = lv[2 * w]; st < lv[2 * w + 1]; st++) {
-        const uint32_t d = s.step[st], lt = d & 7u, flush = (d >> 3) & 1u, ob = d >> 4, T = 1u << lt;
-        for (uint32_t ln = 0; ln < 64; ln++) {
-          uint32_t slot = st * 64 + ln;
-          double v = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
-          acc[ln] += v * xs[s.idx[slot]];
-        }
-        if (flush) {
-          for (uint32_t g = 0; g < 64 / T; g++) {
-            double sum = 0.0;
-            for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[ln];
-            uint32_t row = s.outA[ob + g];
-            if (row != kNoRow) { if (subtract) xs[row] -= sum; else out[row] = sum; }
+      const uint32_t *e = pr + 1 + 4 * w;
+      if (kind == 0) {
+        double acc[64];
+        for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
+        for (uint32_t st = e[0]; st < e[1]; st++) {
+          const uint32_t d = s.step[st], lt = d & 7u, flush = (d >> 3) & 1u, ob = d >> 4, T = 1u << lt;
+          for (uint32_t ln = 0; ln < 64; ln++) {
+            uint32_t slot = st * 64 + ln;
+            double v = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
+            acc[ln] += v * xs[s.idx[slot]];
           }
-          for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
+          if (flush) {
+            for (uint32_t g = 0; g < 64 / T; g++) {
+              double sum = 0.0;
+              for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[ln];
+              uint32_t row = s.outA[ob + g];
+              if (row != kNoRow) { if (subtract) xs[row] -= sum; else out[row] = sum; }
+            }
+            for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
+          }
         }
-      }
-    }
-    for (uint32_t t = lv[2 * s.nw]; t < lv[2 * s.nw + 1]; t++) {
-      const uint32_t *tk = &s.taskB[4 * t];
-      uint32_t base = tk[0], r = tk[1], ob = tk[2];
-      double acc[kChunk];
-      for (uint32_t i = 0; i < r; i++) acc[i] = xs[s.outB[ob + i]];
-      for (uint32_t p = 0; p + 1 < r; p++) {
-        double v = acc[p];
-        for (uint32_t i = 0; i < r; i++) {
-          uint32_t slot = base + p * kChunk + i;
-          double lv2 = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
-          acc[i] -= lv2 * v;
+      } else if (e[3]) {
+        const uint32_t task = e[2] / kChunk, base = nA + task * (kChunk * (kChunk - 1));
+        double acc[kChunk];
+        uint32_t rows[kChunk];
+        for (int i = 0; i < kChunk; i++) { rows[i] = s.outB[e[2] + i]; acc[i] = rows[i] != kNoRow ? xs[rows[i]] : 0.0; }
+        for (int p = 0; p < kChunk - 1; p++) {
+          double v = acc[p];
+          for (int i = 0; i < kChunk; i++) {
+            uint32_t slot = base + p * kChunk + i;
+            double lv2 = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
+            acc[i] -= lv2 * v;
+          }
         }
+        for (int i = 0; i < kChunk; i++) if (rows[i] != kNoRow) xs[rows[i]] = acc[i];
       }
-      for (uint32_t i = 0; i < r; i++) xs[s.outB[ob + i]] = acc[i];
     }
   }
 }
@@ -797,7 +855,7 @@ int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric 
     const uint32_t *lv = &bf.lvl[6 * L];
     for (uint32_t t = lv[0]; t < lv[1]; t++) {
       uint32_t off, r0, c0, h, w; B(bf.utask[4 * t], off, r0, c0, h, w);
-      for (uint32_t q = bf.utask[4 * t + 1]; q < bf.utask[4 * t + 2]; q++) {
+      for (uint32_t q = bf.utask[4 * t + 1]; q < bf.utask[4 * t + 3]; q++) {
         uint32_t ao, ar, ac, ah, aw, bo, br, bc, bh, bw;
         B(bf.tri[2 * q], ao, ar, ac, ah, aw); B(bf.tri[2 * q + 1], bo, br, bc, bh, bw);
         for (uint32_t j = 0; j < w; j++) for (uint32_t i = 0; i < h; i++) {

@@ -32,28 +32,43 @@ struct Settings {
 int validate_settings(const Settings &s);   // 0 ok
 
 // One pull-schedule: every target row t gets  xs[t] -= sum_k val[k] * xs[idx[k]].
-// Phase A is emitted as per-wave STEP PROGRAMS: for every level each of the nw
-// waves of the workgroup owns one contiguous range of wave-steps (64 lanes x 1
-// slot each).  A step carries (lt, flush, out_base): groups of T = 2^lt lanes
-// accumulate one target row; on a flush step the groups are reduced and applied
-// to the 64/T rows listed at out_base.  Long rows span several steps (flush on
-// the last), short rows are one flush step each.  Because a wave's steps of a
-// level are contiguous in slot space, its values stream from HBM and can be
-// prefetched across the level barrier.
-// Phase B ("block tasks"): the dense in-block triangle of a <=16-row chunk of a
-// supernode, solved column-by-column inside one wave.
+//
+// The schedule is a flat list of PHASES separated by workgroup barriers; in every
+// phase each of the nw waves owns exactly one (possibly empty) contiguous range of
+// wave-steps (64 lanes, one slot per lane).  Two kinds of phase:
+//   A  row steps.  A step carries (lt, flush, out_base): groups of T = 2^lt lanes
+//      accumulate one target row; on a flush step the groups are reduced and
+//      applied to the 64/T rows listed at out_base.  Long rows span several steps
+//      (flush on the last one), short rows are one flush step each.
+//   B  the dense in-chunk triangle of a <=16-row chunk of a supernode, solved
+//      column by column inside ONE wave (lane = (row i, QP b)); its 15 values per
+//      lane are stored in the same step format (element k of lane (i,b) is
+//      component k % BT of step k / BT), so one prefetch routine serves both kinds.
+// A wave's steps of a phase are contiguous in memory: its values stream from HBM
+// and are prefetched, unconditionally, one phase ahead.
+//
+// Logical slots (what `src`, `idx` index): A steps: step*64 + lane; B tasks:
+// 64*n_steps + task*240 + k*16 + i.  Physical position of QP b's double inside a
+// tile: A: slot*BT + b ; B: ((n_steps + task*SB + k/BT)*64 + i*BT + b)*BT + k%BT
+// with SB = ceil(15/BT) steps per block task.
 struct Schedule {
-  int n_levels = 0, nw = 0;
-  std::vector<uint32_t> lvl;    // per level, stride 2*nw+3: (step_begin, step_end) per wave, b_begin, b_end, n_steps_in_level
-  std::vector<uint32_t> step;   // per wave-step: lt | flush << 3 | out_base << 4
+  int n_phases = 0, nw = 0, bt = 1, sb = 15;
+  std::vector<uint32_t> phase;  // per phase, stride 4*nw+1: kind(0=A,1=B) then per wave (begin, end, out_base, 0)
+  std::vector<int> level_first_phase;   // for replay/diagnostics: first phase of every level (+ end)
+  std::vector<uint32_t> step;   // per A step: lt | flush << 3 | out_base << 4
   std::vector<uint32_t> outA;   // target rows of flush steps (64/T each), kNoRow = none
-  std::vector<uint32_t> taskB;  // 4/task : slot_base, r, out_base, 0
   std::vector<uint32_t> outB;   // kChunk rows per block task, processing order
-  std::vector<uint32_t> idx;    // per slot: gather index into the LDS vector
-  std::vector<int32_t> src;     // per slot: canonical value index, -1 = structural zero
-  uint32_t n_slots = 0, n_steps = 0, zero_step = 0;   // zero_step: an all-zero padding step (prefetch filler)
-  size_t lvl_stride() const { return 2 * (size_t)nw + 3; }
-  size_t n_taskB() const { return taskB.size() / 4; }
+  std::vector<uint32_t> idx;    // per A slot: gather index into the LDS vector
+  std::vector<uint32_t> idxw;   // DEVICE index words, one per physical slot (phys_steps*64): low 16 bits = gather
+                                // index, high 16 bits = target row of the lane's group on flush steps / of lane
+                                // (i,b) in the first step of a block task (0xFFFF = none)
+  std::vector<int32_t> src;     // per logical slot: canonical value index, -1 = structural zero
+  uint32_t n_slots = 0;         // logical slots
+  uint32_t n_steps = 0;         // A steps (incl. the all-zero padding step `zero_step`)
+  uint32_t n_taskB = 0, zero_step = 0;
+  uint32_t phys_steps() const { return n_steps + n_taskB * (uint32_t)sb; }
+  size_t phase_stride() const { return 4 * (size_t)nw + 1; }
+  int n_levels = 0;
 };
 
 // Block form of the factor for the DEVICE refactorisation (row E13): L is cut
@@ -66,7 +81,7 @@ struct BlockFactor {
   uint32_t storage = 0;               // doubles per QP of block storage
   std::vector<uint32_t> blk;          // 4/block: off, c0 of row chunk, c0 of col chunk, (h << 8) | w
   std::vector<uint32_t> lvl;          // 6/level: u_begin,u_end, d_begin,d_end, t_begin,t_end
-  std::vector<uint32_t> utask;        // 4/task : block id, tri_begin, tri_end, 0
+  std::vector<uint32_t> utask;        // 4/task : block id, tri_begin, tri_mid, tri_end  ([begin,mid): rank-1 sources, i.e. 1-column chunks)
   std::vector<uint32_t> tri;          // 2/triple: block (I,K), block (J,K)
   std::vector<uint32_t> dtask;        // diagonal block ids
   std::vector<uint32_t> ttask;        // 2/task : block id, diagonal block id
@@ -104,10 +119,12 @@ struct Analysis {
 
 // E1 (pattern part), E4, E5-symbolic and the schedules.  Returns 0 or an error
 // code of include/mi_osqp.h.
-// `nwaves` = waves per workgroup the device kernels will run with (the phase-A
-// step programs are laid out per wave).
+// `nwaves` = waves per workgroup the device kernels will run with, `bt` = QPs per
+// tile (the step programs are laid out per wave; block tasks depend on bt).
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves = 8);
+            const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1);
+// physical position (in doubles, inside one tile) of QP b's value of a logical slot
+size_t phys_index(const Schedule &s, uint32_t slot, int b);
 
 // Per-QP numeric state kept on the host (needed for rescaling and refactors).
 struct QPNumeric {

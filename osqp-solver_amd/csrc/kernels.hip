@@ -92,25 +92,40 @@ __device__ __forceinline__ double dpp_d(double v) {
 #define DPP_XOR2 0x4E       /* quad_perm [2,3,0,1] */
 #define DPP_SHL(n) (0x100 + (n))   /* row_shl:n -- lane i reads lane i+n of its 16-lane row */
 
+// Schedule tables are read with wave-uniform addresses.  Going through the constant
+// address space makes them SMEM loads (lgkmcnt), so waiting for a table entry never
+// drains the vector-memory queue that holds the value prefetches (vmcnt is in-order).
+typedef const uint32_t __attribute__((address_space(4))) *mi_cptr;
+__device__ __forceinline__ mi_cptr as_const(const uint32_t *p) { return (mi_cptr)(uintptr_t)p; }
+
 // LDS-only workgroup barrier: waits for this wave's LDS traffic but NOT for its
 // outstanding global loads, so register prefetches stay in flight across it
 // (a __syncthreads() would drain vmcnt to 0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ----------------------------------------------------------------- row tasks
-// Reduce acc[] over aligned groups of T = 2^lt lanes and apply it to the target
-// row.  The BT per-QP partial sums are "transposed" across lanes on the way
-// (after log2(BT) steps every lane carries ONE QP's partial sum), then summed
-// toward the first lanes of the group with DPP row shifts; only the two
-// cross-row steps (16, 32) use ds_bpermute.
+// physical position (doubles inside one tile) of QP b's value of a logical slot
+// (host twin: host_core.cpp phys_index)
+__device__ __forceinline__ size_t phys_index(const SchedDev &s, uint32_t slot, int b, int BT) {
+  const uint32_t nA = s.n_steps * 64u;
+  if (slot < nA) return (size_t)slot * BT + b;
+  const uint32_t r = slot - nA, task = r / (MI_CHUNK * (MI_CHUNK - 1)), rem = r % (MI_CHUNK * (MI_CHUNK - 1));
+  const uint32_t k = rem / MI_CHUNK, i = rem % MI_CHUNK;
+  return ((size_t)(s.n_steps + task * s.sb + k / BT) * 64 + (size_t)i * BT + b) * BT + k % BT;
+}
+
+// ----------------------------------------------------------------- row steps
+// Reduce acc[] over aligned groups of T = 2^lt lanes and apply it to the group's
+// target row (`row`: every lane of a group carries it, 0xFFFF = none).  The BT
+// per-QP partial sums are "transposed" across lanes on the way (after log2(BT)
+// steps every lane carries ONE QP's partial sum), then summed toward the first
+// lanes of the group with DPP row shifts; only the two cross-row steps (16, 32)
+// use ds_bpermute.
 // SUB = true : xs[row] -= sum (triangular solves) ; false: out[row] = sum (SpMV)
 template <int BT, bool SUB>
-__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t ob, const SchedDev &s,
-                                             double *xs, double *out, int lane) {
-  double *base = SUB ? xs : out;
+__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t row, double *base, int lane) {
+  const bool has_row = row != 0xFFFFu;
   if (lt == 0) {
-    const uint32_t row = s.outA[ob + (uint32_t)lane];
-    if (row != MI_NOROW) {
+    if (has_row) {
       double *dst = base + (size_t)row * BT;
 #pragma unroll
       for (int b = 0; b < BT; b++) { if (SUB) dst[b] -= acc[b]; else dst[b] = acc[b]; }
@@ -127,8 +142,7 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
     double k0 = o0 ? acc[2] : acc[0], k1 = o0 ? acc[3] : acc[1];
     k0 += dpp_d<DPP_XOR1>(s0); k1 += dpp_d<DPP_XOR1>(s1);
     if (lt == 1) {                       // groups of 2 lanes: even lane owns QPs 0,1 ; odd lane QPs 2,3
-      const uint32_t row = s.outA[ob + ((uint32_t)lane >> 1)];
-      if (row != MI_NOROW) {
+      if (has_row) {
         double *dst = base + (size_t)row * BT + (o0 ? 2 : 0);
         if (SUB) { dst[0] -= k0; dst[1] -= k1; } else { dst[0] = k0; dst[1] = k1; }
       }
@@ -163,18 +177,20 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
   }
   if (lt > 4) kp += shfl_down_d(kp, 16);
   if (lt > 5) kp += shfl_down_d(kp, 32);
-  if (((uint32_t)lane & (T - 1)) < nwr) {
-    const uint32_t row = s.outA[ob + ((uint32_t)lane >> lt)];
-    if (row != MI_NOROW) {
-      double *dst = base + (size_t)row * BT + q;
-      if (SUB) *dst -= kp; else *dst = kp;
-    }
+  if (has_row && ((uint32_t)lane & (T - 1)) < nwr) {
+    double *dst = base + (size_t)row * BT + q;
+    if (SUB) *dst -= kp; else *dst = kp;
   }
 }
 
-// ---- phase A: per-wave step programs -------------------------------------------
-// A wave's steps of one level are contiguous; the first PF of them are prefetched
-// into registers (values + gather indices), later ones are loaded on the fly.
+// ---- per-wave step programs with register rotation --------------------------------
+// Every wave owns one contiguous step range per phase.  Its first PF steps live in a
+// register buffer; right after step st of the CURRENT phase has been consumed, the
+// same registers are refilled with step st of the wave's NEXT-phase range.  So about
+// PF steps per wave are in flight at any time, across the LDS-only barriers, and the
+// HBM pipe never drains between phases.  No vector load other than the stream itself
+// is issued on this path (in-order VMEM would make waiting for it drain the stream):
+// tables come through SMEM, target rows ride in the high half of the index word.
 #define MI_NORANGE 0xFFFFFFFFu
 // prefetch depth in wave-steps: 15 covers a 450-entry row on 32 lanes (the dense
 // chunks of BASELINE config 3) and is what fits 256 VGPRs at BT = 4
@@ -183,169 +199,144 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 #endif
 template <int BT, int PF>
 struct PrefA { double v[PF][BT]; uint32_t gi[PF]; uint32_t desc; uint32_t begin, end; };
+struct ValSrc { mi_rsrc vals, idx, step; };     // one tile's value stream + the shared index words / step table
 
-struct ValSrc { mi_rsrc vals, idx; };     // one tile's value stream + the shared gather indices
+template <int BT>
+__device__ __forceinline__ void load_step(const ValSrc &vs, uint32_t stepno, int lane, double (&v)[BT], uint32_t &gi) {
+  gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, (uint32_t)lane * 4u, stepno * 256u, 0);
+  buf_load_bt<BT>(vs.vals, (uint32_t)lane * (uint32_t)(BT * 8), stepno * (uint32_t)(64 * BT * 8), v);
+}
+// lane st gets the descriptor of step begin+st (0 past the end; block-task ranges lie
+// outside the step table, for which the buffer unit returns 0)
+__device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t begin, uint32_t n, int lane) {
+  const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(vs.step, (uint32_t)lane * 4u, begin * 4u, 0);
+  return (uint32_t)lane < n ? d : 0u;
+}
 
 template <int BT, int PF>
-__device__ __forceinline__ void prefetch_steps(const SchedDev &s, const ValSrc &vs, uint32_t begin,
-                                               uint32_t end, int lane, PrefA<BT, PF> &p) {
+__device__ __forceinline__ void prefetch_all(const SchedDev &s, const ValSrc &vs, uint32_t begin, uint32_t end, int lane,
+                                             PrefA<BT, PF> &p) {
   p.begin = begin; p.end = end;
   const uint32_t n = end - begin;
-  p.desc = ((uint32_t)lane < n) ? s.step[begin + (uint32_t)lane] : 0u;     // lane st holds the descriptor of step st
-  const uint32_t vo = (uint32_t)lane * (uint32_t)(BT * 8), io = (uint32_t)lane * 4u;
-  // branch-free: steps past the end read the schedule's all-zero padding step
-  // (value 0, gather index 0); the step number is wave-uniform -> scalar offsets
+  p.desc = load_desc(vs, begin, n, lane);
 #pragma unroll
-  for (int st = 0; st < PF; st++) {
-    const uint32_t stepno = (uint32_t)st < n ? begin + (uint32_t)st : s.zero_step;
-    p.gi[st] = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, io, stepno * 256u, 0);
-    buf_load_bt<BT>(vs.vals, vo, stepno * (uint32_t)(64 * BT * 8), p.v[st]);
-  }
+  for (int st = 0; st < PF; st++)   // steps past the end read the all-zero padding step: no branch
+    load_step<BT>(vs, (uint32_t)st < n ? begin + (uint32_t)st : s.zero_step, lane, p.v[st], p.gi[st]);
 }
 
 template <int BT, int PF, bool SUB>
-__device__ __forceinline__ void consume_steps(const SchedDev &s, const ValSrc &vs, double *xs,
-                                              double *out, const PrefA<BT, PF> &p, int lane) {
-  const uint32_t n = p.end - p.begin;
+__device__ __forceinline__ void consume_refill(const SchedDev &s, const ValSrc &vs, double *xs, double *out,
+                                               PrefA<BT, PF> &p, uint32_t nbegin, uint32_t nend, int lane) {
+  const uint32_t n = p.end - p.begin, nn = nend - nbegin;
+  const uint32_t dnext = load_desc(vs, nbegin, nn, lane);     // older than every refill below
+  double *base = SUB ? xs : out;
   double acc[BT];
 #pragma unroll
   for (int b = 0; b < BT; b++) acc[b] = 0.0;
 #pragma unroll
   for (int st = 0; st < PF; st++) {
-    // steps past the end carry value 0 / index 0 / descriptor 0: harmless, no branch
+    const uint32_t w = p.gi[st];
     double xv[BT];
-    load_bt<BT>(xs + (size_t)p.gi[st] * BT, xv);
+    load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
 #pragma unroll
     for (int b = 0; b < BT; b++) acc[b] = fma(p.v[st][b], xv[b], acc[b]);
     const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)p.desc, st);
     if (d & 8u) {
-      reduce_write<BT, SUB>(acc, d & 7u, d >> 4, s, xs, out, lane);
+      reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
 #pragma unroll
       for (int b = 0; b < BT; b++) acc[b] = 0.0;
     }
-    if ((st & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the LDS gathers in flight (registers)
+    // rotate: this slot now carries step st of the next phase
+    load_step<BT>(vs, (uint32_t)st < nn ? nbegin + (uint32_t)st : s.zero_step, lane, p.v[st], p.gi[st]);
+    __builtin_amdgcn_sched_barrier(0);     // keep {gather, fma, refill} of one step together: bounded live ranges
   }
-  const uint32_t vo = (uint32_t)lane * (uint32_t)(BT * 8), io = (uint32_t)lane * 4u;
+  // ranges longer than the buffer (rare): the tail is loaded on the fly
   for (uint32_t st = PF; st < n; st++) {
-    const uint32_t stepno = p.begin + st;
-    const uint32_t gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, io, stepno * 256u, 0);
     double v[BT], xv[BT];
-    buf_load_bt<BT>(vs.vals, vo, stepno * (uint32_t)(64 * BT * 8), v);
-    load_bt<BT>(xs + (size_t)gi * BT, xv);
+    uint32_t w;
+    load_step<BT>(vs, p.begin + st, lane, v, w);
+    load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
 #pragma unroll
     for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
-    const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)s.step[stepno]);
+    const uint32_t d = as_const(s.step)[p.begin + st];
     if (d & 8u) {
-      reduce_write<BT, SUB>(acc, d & 7u, d >> 4, s, xs, out, lane);
+      reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
 #pragma unroll
       for (int b = 0; b < BT; b++) acc[b] = 0.0;
     }
   }
+  p.begin = nbegin; p.end = nend; p.desc = dnext;
 }
 
-// ---- phase B: dense in-chunk triangle (<=16 rows) solved inside one wave: lane =
-// (i, b); for p = 0..r-2 the finished value of local row p is broadcast and every
-// lane i > p subtracts L[p->i] * v (structural zeros are stored as 0).  The 15
-// values per lane are prefetched into the SAME register buffer as phase-A steps
-// (a wave never holds both): element k lives in v[k / BT][k % BT].
+// ---- block tasks: the dense in-chunk triangle (<=16 rows) solved inside one wave:
+// lane = (i, b); for k = 0..14 the finished value of local row k is broadcast and
+// every lane i > k subtracts L[k->i] * v (structural zeros are stored as 0).  The 15
+// values per lane sit in the same register buffer (element k = v[k / BT][k % BT]); the
+// lane's target row rides in the first index word.
 template <int BT, int PF>
-__device__ __forceinline__ void prefetch_B(const SchedDev &s, const ValSrc &vs, uint32_t t, int lane,
-                                           PrefA<BT, PF> &p) {
+__device__ __forceinline__ void consume_B(double *xs, const PrefA<BT, PF> &p, int lane) {
   static_assert(PF * BT >= MI_CHUNK - 1, "prefetch buffer too small for a block task");
-  const uint32_t tu = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-  const uint32_t base = s.taskB[4 * tu], r = s.taskB[4 * tu + 1];
-  p.begin = MI_NORANGE - 1u - tu;            // tag: "holds block task tu"
-  p.end = s.taskB[4 * tu + 2];               // out_base
-  const bool active = lane < MI_CHUNK * BT;
-  const uint32_t vo = active ? (uint32_t)lane * 8u : 0u;
-#pragma unroll
-  for (int k = 0; k < MI_CHUNK - 1; k++) {
-    // rows past r read the all-zero padding step instead (no branch); lanes >= 16*BT hold junk that is never used
-    const uint32_t sl = (uint32_t)k + 1 < r ? base + (uint32_t)k * MI_CHUNK : s.zero_step * 64u;
-    const mi_u32x2 tt = __builtin_amdgcn_raw_buffer_load_b64(vs.vals, vo, sl * (uint32_t)(BT * 8), 0);
-    p.v[k / BT][k % BT] = __hiloint2double((int)tt.y, (int)tt.x);
-  }
-}
-
-template <int BT, int PF>
-__device__ __forceinline__ void consume_B(const SchedDev &s, double *xs, const PrefA<BT, PF> &p, int lane) {
-  const int i = lane / BT, b = lane % BT;
-  const bool active = lane < MI_CHUNK * BT;
-  uint32_t row = MI_NOROW;
-  if (active) row = s.outB[p.end + i];
-  const bool valid = row != MI_NOROW;
+  const int b = lane % BT;
+  const uint32_t row = lane < MI_CHUNK * BT ? p.gi[0] >> 16 : 0xFFFFu;
+  const bool valid = row != 0xFFFFu;
   double acc = valid ? xs[(size_t)row * BT + b] : 0.0;
+  // byte address of the broadcasting lane for ds_bpermute; kept opaque so that the 15
+  // per-step addresses are recomputed (one add) instead of living in 15 hoisted VGPRs
+  int baddr = b << 2;
+  asm volatile("" : "+v"(baddr));
 #pragma unroll
   for (int k = 0; k < MI_CHUNK - 1; k++) {
-    const double v = shfl_d(acc, k * BT + b);
-    acc = fma(-p.v[k / BT][k % BT], v, acc);
+    const int lo = __builtin_amdgcn_ds_bpermute(baddr + k * BT * 4, __double2loint(acc));
+    const int hi = __builtin_amdgcn_ds_bpermute(baddr + k * BT * 4, __double2hiint(acc));
+    acc = fma(-p.v[k / BT][k % BT], __hiloint2double(hi, lo), acc);
   }
   if (valid) xs[(size_t)row * BT + b] = acc;
 }
 
-// Level loop of one triangular solve, software-pipelined across the barriers:
-// every wave keeps ONE register buffer that always holds its next piece of work
-// (a phase-A step range or a phase-B block task).  Values do not depend on the
-// solve vector, so their loads are issued right after the previous piece was
-// consumed and stay in flight across the LDS-only barriers.
+// One triangular solve = walk the flat phase table.
 template <int BT, int PF>
-__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs,
-                                        int wave, int lane) {
-  const int nw = s.nw;
-  const uint32_t stride = 2u * (uint32_t)nw + 3u;
-  const int nph = 2 * s.n_levels;                         // phase 2L = A of level L, 2L+1 = B of level L
-  PrefA<BT, PF> pa; pa.begin = MI_NORANGE; pa.end = 0; pa.desc = 0;
-  // issue the loads of this wave's first piece of work at or after phase ph0
-  auto prefetch_next = [&](int ph0) {
-    for (int ph = ph0; ph < nph; ph++) {
-      const uint32_t *lv = s.lvl + (size_t)(ph >> 1) * stride;
-      if (!(ph & 1)) {
-        const uint32_t rb = lv[2 * wave], re = lv[2 * wave + 1];
-        if (re > rb) { prefetch_steps<BT, PF>(s, vals, rb, re, lane, pa); return; }
-      } else {
-        const uint32_t t = lv[2 * nw] + (uint32_t)wave;
-        if (t < lv[2 * nw + 1]) { prefetch_B<BT, PF>(s, vals, t, lane, pa); return; }
-      }
-    }
-  };
-  prefetch_next(0);
-  for (int ph = 0; ph < nph; ph++) {
-    const uint32_t *lv = s.lvl + (size_t)(ph >> 1) * stride;
-    bool consumed = false;
-    if (!(ph & 1)) {
-      if (lv[2 * nw + 2] == 0) continue;                  // level without phase A (uniform)
-      const uint32_t rb = lv[2 * wave], re = lv[2 * wave + 1];
-      if (re > rb) { consume_steps<BT, PF, true>(s, vals, xs, nullptr, pa, lane); consumed = true; }
+__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane) {
+  const uint32_t stride = 4u * (uint32_t)s.nw + 1u;
+  mi_cptr ph = as_const(s.phase);
+  PrefA<BT, PF> pa;
+  {
+    mi_cptr e = ph + 1 + 4 * wave;
+    prefetch_all<BT, PF>(s, vals, e[0], e[1], lane, pa);
+  }
+  for (int p = 0; p < s.n_phases; p++) {
+    mi_cptr pr = ph + (size_t)p * stride;
+    mi_cptr e = pr + 1 + 4 * wave;
+    const uint32_t kind = pr[0], has = e[3];
+    uint32_t nb = s.zero_step, ne = s.zero_step;
+    if (p + 1 < s.n_phases) { nb = e[stride]; ne = e[stride + 1]; }
+    if (kind == 0) {
+      consume_refill<BT, PF, true>(s, vals, xs, nullptr, pa, nb, ne, lane);
     } else {
-      const uint32_t b0 = lv[2 * nw], b1 = lv[2 * nw + 1];
-      if (b1 <= b0) continue;                             // level without phase B (uniform)
-      for (uint32_t t = b0 + (uint32_t)wave; t < b1; t += (uint32_t)nw) {
-        if (pa.begin != MI_NORANGE - 1u - t) prefetch_B<BT, PF>(s, vals, t, lane, pa);   // only a wave's 2nd+ task of a level
-        consume_B<BT, PF>(s, xs, pa, lane);
-        consumed = true;
-      }
-    }
-    if (consumed) {
-      __builtin_amdgcn_sched_barrier(0);                  // keep the refill behind the consumption (one buffer)
-      prefetch_next(ph + 1);
+      if (has) consume_B<BT, PF>(xs, pa, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      prefetch_all<BT, PF>(s, vals, nb, ne, lane, pa);
     }
     lds_barrier();
   }
 }
 
-// SpMV with the same step programs (levels lvl0..lvl1-1 of the check schedule, no barriers)
+// SpMV with the same step programs: phases [p0, p1) of the check schedule, no barriers
 template <int BT, int PF>
-__device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc &vals, double *xs,
-                                         double *out, int wave, int lane, int lvl0, int lvl1) {
-  const uint32_t stride = 2u * (uint32_t)s.nw + 3u;
+__device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc &vals, double *xs, double *out, int wave,
+                                         int lane, int p0, int p1) {
+  if (p1 <= p0) return;
+  const uint32_t stride = 4u * (uint32_t)s.nw + 1u;
+  mi_cptr ph = as_const(s.phase);
   PrefA<BT, PF> pa;
-  for (int L = lvl0; L < lvl1; L++) {
-    const uint32_t *lv = s.lvl + (size_t)L * stride;
-    const uint32_t rb = lv[2 * wave], re = lv[2 * wave + 1];
-    if (re > rb) {
-      prefetch_steps<BT, PF>(s, vals, rb, re, lane, pa);
-      consume_steps<BT, PF, false>(s, vals, xs, out, pa, lane);
-    }
+  {
+    mi_cptr e = ph + (size_t)p0 * stride + 1 + 4 * wave;
+    prefetch_all<BT, PF>(s, vals, e[0], e[1], lane, pa);
+  }
+  for (int p = p0; p < p1; p++) {
+    mi_cptr e = ph + (size_t)p * stride + 1 + 4 * wave;
+    uint32_t nb = s.zero_step, ne = s.zero_step;
+    if (p + 1 < p1) { nb = e[stride]; ne = e[stride + 1]; }
+    consume_refill<BT, PF, false>(s, vals, xs, out, pa, nb, ne, lane);
   }
 }
 
@@ -399,9 +390,9 @@ template <int BT>
 __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile) {
   TilePtrs<BT> p;
   const size_t n = a.n, m = a.m, N = a.N, t = tile;
-  p.fwd_val = a.fwd_val + t * a.fwd.n_slots * BT;
-  p.bwd_val = a.bwd_val + t * a.bwd.n_slots * BT;
-  p.chk_val = a.chk_val + t * a.chk.n_slots * BT;
+  p.fwd_val = a.fwd_val + t * a.fwd.phys_steps * 64 * BT;
+  p.bwd_val = a.bwd_val + t * a.bwd.phys_steps * 64 * BT;
+  p.chk_val = a.chk_val + t * a.chk.phys_steps * 64 * BT;
   p.dinv = a.dinv + t * N * BT;
   p.x = a.x + t * n * BT; p.z = a.z + t * m * BT; p.y = a.y + t * m * BT;
   p.q = a.q + t * n * BT; p.l = a.l + t * m * BT; p.u = a.u + t * m * BT;
@@ -412,9 +403,12 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile)
   p.out1 = a.out1 + t * (2 * n + m) * BT; p.out2 = a.out2 + t * (2 * n + m) * BT;
   p.dscal = a.dscal + t * DS_COUNT * BT;
   p.iscal = a.iscal + t * IS_COUNT * BT;
-  p.vfwd.vals = make_rsrc(p.fwd_val, a.fwd.n_slots * (uint32_t)(BT * 8)); p.vfwd.idx = make_rsrc(a.fwd.idx, a.fwd.n_slots * 4u);
-  p.vbwd.vals = make_rsrc(p.bwd_val, a.bwd.n_slots * (uint32_t)(BT * 8)); p.vbwd.idx = make_rsrc(a.bwd.idx, a.bwd.n_slots * 4u);
-  p.vchk.vals = make_rsrc(p.chk_val, a.chk.n_slots * (uint32_t)(BT * 8)); p.vchk.idx = make_rsrc(a.chk.idx, a.chk.n_slots * 4u);
+  p.vfwd.vals = make_rsrc(p.fwd_val, a.fwd.phys_steps * (uint32_t)(64 * BT * 8)); p.vfwd.idx = make_rsrc(a.fwd.idxw, a.fwd.phys_steps * 256u);
+  p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
+  p.vbwd.vals = make_rsrc(p.bwd_val, a.bwd.phys_steps * (uint32_t)(64 * BT * 8)); p.vbwd.idx = make_rsrc(a.bwd.idxw, a.bwd.phys_steps * 256u);
+  p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
+  p.vchk.vals = make_rsrc(p.chk_val, a.chk.phys_steps * (uint32_t)(64 * BT * 8)); p.vchk.idx = make_rsrc(a.chk.idxw, a.chk.phys_steps * 256u);
+  p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
   return p;
 }
 
@@ -495,7 +489,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(KernelArgs a) {
       for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
       for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
       __syncthreads();
-      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
+      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
       __syncthreads();
       // residual vectors and the norms termination + rho estimate need
       double mx[14];
@@ -549,7 +543,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(KernelArgs a) {
         si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
       }
       __syncthreads();
-      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3);
+      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
       __syncthreads();
       for (int e = tid; e < n * BT; e += nthr) {
         const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
@@ -683,7 +677,7 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
   for (int e = tid; e < n * BT; e += nthr) xs[e] = (qp < a.B && gx) ? gx[(size_t)qp * n + e / BT] : 0.0;
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = (qp < a.B && gy) ? gy[(size_t)qp * m + e / BT] : 0.0;
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
   __syncthreads();
   if (qp < a.B) {
     if (gPx) for (int e = tid; e < n * BT; e += nthr) gPx[(size_t)qp * n + e / BT] = p.out1[e];
@@ -729,7 +723,7 @@ __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const doub
   }
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[2], a.chk_lvl[3]);
   __syncthreads();
   for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
@@ -752,35 +746,71 @@ __device__ __forceinline__ void wave_sync() {
 template <int BT>
 __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, const double *Dl, double *Ss,
                                            uint32_t t, int lane) {
-  const uint4 ut = reinterpret_cast<const uint4 *>(a.utask)[t];
-  const uint4 tb = reinterpret_cast<const uint4 *>(a.blk)[ut.x];
-  const uint32_t off = tb.x, h = tb.w >> 8, w = tb.w & 255u;
+  mi_cptr ut = as_const(a.utask) + 4 * (size_t)t;
+  mi_cptr blk = as_const(a.blk);
+  mi_cptr tri = as_const(a.tri);
+  const uint32_t tid_blk = ut[0], q0 = ut[1], qm = ut[2], q1 = ut[3];
+  const uint32_t off = blk[4 * tid_blk], hw = blk[4 * tid_blk + 3], h = hw >> 8, w = hw & 255u;
   const int i = lane / BT, b = lane % BT;
-  const bool row_ok = (uint32_t)i < h && lane < MI_CHUNK * BT;
+  const bool inw = lane < MI_CHUNK * BT;
+  const bool row_ok = (uint32_t)i < h && inw;
   double acc[MI_CHUNK];
 #pragma unroll
   for (int j = 0; j < MI_CHUNK; j++) acc[j] = (row_ok && (uint32_t)j < w) ? Lb[((size_t)off + j * h + i) * BT + b] : 0.0;
-  for (uint32_t q = ut.y; q < ut.z; q++) {
-    const uint2 tr = reinterpret_cast<const uint2 *>(a.tri)[q];
-    const uint4 ba = reinterpret_cast<const uint4 *>(a.blk)[tr.x];
-    const uint4 bb = reinterpret_cast<const uint4 *>(a.blk)[tr.y];
-    const uint32_t ah = ba.w >> 8, aw = ba.w & 255u, bh = bb.w >> 8, kc0 = ba.z;
+  // ---- rank-1 sources (one-column chunks), 8 per batch: all operand loads of a batch
+  // are in flight together, the 8 scaled B columns go through wave-private LDS
+  constexpr int G = 8;
+  for (uint32_t q = q0; q < qm; q += G) {
+    double av[G], bv[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      av[g] = 0.0; bv[g] = 0.0;
+      if (q + g < qm) {
+        const uint32_t ia = tri[2 * (q + g)], ib = tri[2 * (q + g) + 1];
+        const uint32_t ao = blk[4 * ia], ah = blk[4 * ia + 3] >> 8, kc0 = blk[4 * ia + 2];
+        const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
+        if ((uint32_t)i < ah && inw) av[g] = Lb[((size_t)ao + i) * BT + b];
+        if ((uint32_t)i < bh && inw) bv[g] = Lb[((size_t)bo + i) * BT + b] * Dl[(size_t)kc0 * BT + b];
+      }
+    }
+    if (inw) {
+#pragma unroll
+      for (int g = 0; g < G; g++) Ss[MI_BS(g, b, i)] = bv[g];
+    }
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(g, b, 0)]);
+#pragma unroll
+      for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
+        const double2 bvv = bs[j2];
+        acc[2 * j2] = fma(-av[g], bvv.x, acc[2 * j2]);
+        acc[2 * j2 + 1] = fma(-av[g], bvv.y, acc[2 * j2 + 1]);
+      }
+    }
+    wave_sync();
+  }
+  // ---- general sources (width > 1)
+  for (uint32_t q = qm; q < q1; q++) {
+    const uint32_t ia = tri[2 * q], ib = tri[2 * q + 1];
+    const uint32_t ao = blk[4 * ia], ahw = blk[4 * ia + 3], ah = ahw >> 8, aw = ahw & 255u, kc0 = blk[4 * ia + 2];
+    const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
     // stage (B .* d) : lane (j, b) provides row j of B
-    const bool brow = (uint32_t)i < bh && lane < MI_CHUNK * BT;
+    const bool brow = (uint32_t)i < bh && inw;
     for (uint32_t k = 0; k < aw; k++) {
       double v = 0.0;
-      if (brow) v = Lb[((size_t)bb.x + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b];
-      if (lane < MI_CHUNK * BT) Ss[MI_BS(k, b, i)] = v;
+      if (brow) v = Lb[((size_t)bo + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b];
+      if (inw) Ss[MI_BS(k, b, i)] = v;
     }
     wave_sync();
     for (uint32_t k = 0; k < aw; k++) {
-      const double av = ((uint32_t)i < ah && lane < MI_CHUNK * BT) ? Lb[((size_t)ba.x + k * ah + i) * BT + b] : 0.0;
+      const double avk = ((uint32_t)i < ah && inw) ? Lb[((size_t)ao + k * ah + i) * BT + b] : 0.0;
       const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(k, b, 0)]);
 #pragma unroll
       for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
-        const double2 bv = bs[j2];
-        acc[2 * j2] = fma(-av, bv.x, acc[2 * j2]);
-        acc[2 * j2 + 1] = fma(-av, bv.y, acc[2 * j2 + 1]);
+        const double2 bvv = bs[j2];
+        acc[2 * j2] = fma(-avk, bvv.x, acc[2 * j2]);
+        acc[2 * j2 + 1] = fma(-avk, bvv.y, acc[2 * j2 + 1]);
       }
     }
     wave_sync();
@@ -925,14 +955,16 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag) {
-    double *fv = a.fwd_val + (size_t)tile * a.fwd_slots * BT, *bv = a.bwd_val + (size_t)tile * a.bwd_slots * BT;
-    for (size_t e = tid; e < (size_t)a.fwd_slots * BT; e += nthr) {
-      const int32_t mp = a.fwd_srcblk[e / BT];
-      fv[e] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+    double *fv = a.fwd_val + (size_t)tile * a.fwd.phys_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.phys_steps * 64 * BT;
+    for (size_t e = tid; e < (size_t)a.fwd.n_slots * BT; e += nthr) {
+      const uint32_t sl = (uint32_t)(e / BT);
+      const int32_t mp = a.fwd_srcblk[sl];
+      fv[phys_index(a.fwd, sl, b, BT)] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
     }
-    for (size_t e = tid; e < (size_t)a.bwd_slots * BT; e += nthr) {
-      const int32_t mp = a.bwd_srcblk[e / BT];
-      bv[e] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+    for (size_t e = tid; e < (size_t)a.bwd.n_slots * BT; e += nthr) {
+      const uint32_t sl = (uint32_t)(e / BT);
+      const int32_t mp = a.bwd_srcblk[sl];
+      bv[phys_index(a.bwd, sl, b, BT)] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
     }
     for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
   }
@@ -969,15 +1001,18 @@ __global__ void interleave_kernel(const double *__restrict__ src, double *dst, c
   const int q = ids ? ids[j] : j;
   dst[((size_t)(q / BT) * len + i) * BT + (q % BT)] = src[g];
 }
-// dst[tile][slot][b] = map[slot] >= 0 ? src[q][map[slot]] : 0
+// dst[tile][phys(slot, b)] = map[slot] >= 0 ? src[q][map[slot]] : 0   (logical slots -> physical layout)
 __global__ void scatter_kernel(const double *__restrict__ src, double *dst, const int *__restrict__ map,
-                               const int *ids, int nq, int srclen, int slots, int BT) {
+                               const int *ids, int nq, int srclen, SchedDev sd, int BT) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t slots = sd.n_slots;
   if (g >= (size_t)nq * slots) return;
-  const int j = (int)(g / slots), s = (int)(g % slots);
+  const int j = (int)(g / slots);
+  const uint32_t s = (uint32_t)(g % slots);
   const int q = ids ? ids[j] : j;
   const int mp = map[s];
-  dst[((size_t)(q / BT) * slots + s) * BT + (q % BT)] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
+  const size_t tile_doubles = (size_t)sd.phys_steps * 64 * BT;
+  dst[(size_t)(q / BT) * tile_doubles + phys_index(sd, s, q % BT, BT)] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
 }
 // dst[q][i] = src[tile][i][b]
 __global__ void deinterleave_kernel(const double *__restrict__ src, double *dst, int nq, int len, int BT) {
@@ -1055,9 +1090,9 @@ hipError_t launch_interleave(const double *src, double *dst, const int *ids, int
   return hipGetLastError();
 }
 hipError_t launch_scatter(const double *src, double *dst, const int *map, const int *ids, int nq, int srclen,
-                          int slots, int BT, hipStream_t st) {
-  if (!nq || !slots) return hipSuccess;
-  hipLaunchKernelGGL(scatter_kernel, dim3(nblk((size_t)nq * slots, 256)), dim3(256), 0, st, src, dst, map, ids, nq, srclen, slots, BT);
+                          const SchedDev &sd, int BT, hipStream_t st) {
+  if (!nq || !sd.n_slots) return hipSuccess;
+  hipLaunchKernelGGL(scatter_kernel, dim3(nblk((size_t)nq * sd.n_slots, 256)), dim3(256), 0, st, src, dst, map, ids, nq, srclen, sd, BT);
   return hipGetLastError();
 }
 hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st) {

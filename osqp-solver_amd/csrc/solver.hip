@@ -98,18 +98,18 @@ struct DevBuf {
 };
 
 struct SchedBufs {
-  DevBuf<uint32_t> lvl, step, outA, taskB, outB, idx;
+  DevBuf<uint32_t> phase, step, idxw;
   DevBuf<int32_t> src;
   int upload(const Schedule &s) {
     int rc;
-    if ((rc = lvl.upload(s.lvl)) || (rc = step.upload(s.step)) || (rc = outA.upload(s.outA)) ||
-        (rc = taskB.upload(s.taskB)) || (rc = outB.upload(s.outB)) || (rc = idx.upload(s.idx)) ||
-        (rc = src.upload(s.src))) return rc;
+    if ((rc = phase.upload(s.phase)) || (rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src))) return rc;
     return 0;
   }
   SchedDev view(const Schedule &s) const {
-    SchedDev d; d.lvl = lvl.p; d.step = step.p; d.outA = outA.p; d.taskB = taskB.p; d.outB = outB.p; d.idx = idx.p;
-    d.n_levels = s.n_levels; d.nw = s.nw; d.n_slots = s.n_slots; d.zero_step = s.zero_step; return d;
+    SchedDev d; d.phase = phase.p; d.step = step.p; d.idxw = idxw.p;
+    d.n_phases = s.n_phases; d.nw = s.nw; d.sb = s.sb;
+    d.n_steps = s.n_steps; d.phys_steps = s.phys_steps(); d.zero_step = s.zero_step; d.n_slots = s.n_slots;
+    return d;
   }
 };
 
@@ -190,6 +190,7 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.check_termination = (int)s.check_termination; a.rho_interval = (int)s.adaptive_rho_interval;
   a.max_iter = (int)s.max_iter; a.scaled_termination = (int)s.scaled_termination; a.scaling = s.scaling ? 1 : 0;
   a.adaptive_rho = (int)s.adaptive_rho; a.iter_budget = (int)s.max_iter;
+  for (int k = 0; k < 4; k++) a.chk_lvl[k] = h->an.chk.level_first_phase[k];
   return a;
 }
 
@@ -198,7 +199,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   const Analysis &an = h->an;
   a.n = an.n; a.m = an.m; a.N = an.N; a.B = h->B; a.nnzP = an.Pp[an.n]; a.nnzK = an.nnzK();
   a.pa_len = an.Pp[an.n] + an.Ap[an.n]; a.n_levels = an.bf.n_levels; a.force_all = force_all;
-  a.storage = an.bf.storage; a.fwd_slots = an.fwd.n_slots; a.bwd_slots = an.bwd.n_slots;
+  a.storage = an.bf.storage; a.fwd = h->fwd.view(an.fwd); a.bwd = h->bwd.view(an.bwd);
   a.blk = h->bf_blk.p; a.lvl = h->bf_lvl.p; a.utask = h->bf_utask.p; a.tri = h->bf_tri.p; a.dtask = h->bf_dtask.p;
   a.ttask = h->bf_ttask.p; a.asm_dst = h->bf_asm_dst.p; a.asm_src = h->bf_asm_src.p;
   a.fwd_srcblk = h->fwd_srcblk.p; a.bwd_srcblk = h->bwd_srcblk.p;
@@ -247,8 +248,8 @@ static int upload_factors(mi_osqp_batch *h, const std::vector<int> &ids) {
   HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (nnzL) {
     HIPCHK(hipMemcpyAsync(h->stage.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(launch_scatter(h->stage.p, h->fwd_val.p, h->fwd.src.p, h->ids.p, nq, nnzL, an.fwd.n_slots, h->BT, h->stream));
-    HIPCHK(launch_scatter(h->stage.p, h->bwd_val.p, h->bwd.src.p, h->ids.p, nq, nnzL, an.bwd.n_slots, h->BT, h->stream));
+    HIPCHK(launch_scatter(h->stage.p, h->fwd_val.p, h->fwd.src.p, h->ids.p, nq, nnzL, h->fwd.view(an.fwd), h->BT, h->stream));
+    HIPCHK(launch_scatter(h->stage.p, h->bwd_val.p, h->bwd.src.p, h->ids.p, nq, nnzL, h->bwd.view(an.bwd), h->BT, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
   std::vector<double> drows = gather_rows(ids, N, [&](int q) -> const std::vector<double> & { return h->qp[q].Dlinv; });
@@ -285,7 +286,7 @@ static int upload_problem(mi_osqp_batch *h, const std::vector<int> &ids, bool wi
     HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     if (!pa.empty()) {
       HIPCHK(hipMemcpyAsync(h->stage.p, pa.data(), pa.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      HIPCHK(launch_scatter(h->stage.p, h->chk_val.p, h->chk.src.p, h->ids.p, nq, nnzP + nnzA, an.chk.n_slots, h->BT, h->stream));
+      HIPCHK(launch_scatter(h->stage.p, h->chk_val.p, h->chk.src.p, h->ids.p, nq, nnzP + nnzA, h->chk.view(an.chk), h->BT, h->stream));
       HIPCHK(launch_interleave(h->stage.p, h->pa_val.p, h->ids.p, nq, nnzP + nnzA, h->BT, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -394,7 +395,24 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const char *eth = getenv("MI_OSQP_THREADS");
     h->threads = eth ? std::max(64, std::min(512, atoi(eth) / 64 * 64)) : 512;
   }
-  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64);
+  if (2 * (n + m) >= 65535) {
+    g_last_error = "KKT dimension too large for the LDS-resident solve vector / 16-bit gather indices";
+    return MI_OSQP_ERR_ALLOC;
+  }
+  // ---- tile shape (needed by the schedule layout)
+  // BT = 4 needs a single-copy register rotation the compiler does not give us yet (it spills); 2 is the default
+  int BT = B >= 384 ? 2 : 1;
+  {
+    const char *et = getenv("MI_OSQP_TILE");
+    if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
+  }
+  const size_t lds_cap = 160 * 1024;
+  while (BT > 1 && lds_bytes((int)(n + m), BT, h->threads) > lds_cap) BT /= 2;
+  if (lds_bytes((int)(n + m), BT, h->threads) > lds_cap) {
+    g_last_error = "KKT dimension too large for the LDS-resident solve vector (n+m <= ~20000 supported)";
+    return MI_OSQP_ERR_ALLOC;
+  }
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT);
   if (rc) return rc;
   const Analysis &an = h->an;
   h->B = (int)B;
@@ -407,23 +425,13 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_last_error = std::string("device is not gfx950: ") + prop.gcnArchName; return MI_OSQP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
-  // ---- tile shape
-  const char *et = getenv("MI_OSQP_TILE");
-  int BT = B >= 768 ? 4 : (B >= 384 ? 2 : 1);
-  if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
-  const size_t lds_cap = 160 * 1024;
-  while (BT > 1 && lds_bytes(an.N, BT, h->threads) > lds_cap) BT /= 2;
-  if (lds_bytes(an.N, BT, h->threads) > lds_cap) {
-    g_last_error = "KKT dimension too large for the LDS-resident solve vector (n+m <= ~20000 supported)";
-    return MI_OSQP_ERR_ALLOC;
-  }
   h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT); h->lds = lds_bytes(an.N, BT, h->threads);
   // ---- device arrays
   size_t T = (size_t)h->ntiles * BT;
   if ((rc = h->fwd.upload(an.fwd)) || (rc = h->bwd.upload(an.bwd)) || (rc = h->chk.upload(an.chk))) return rc;
   { std::vector<uint32_t> pv(an.pinv.begin(), an.pinv.end()); if ((rc = h->pinv.upload(pv))) return rc; }
 #define ALLOC(buf, len) if ((rc = h->buf.alloc((size_t)(len) * T)) || (rc = h->buf.zero(h->stream))) return rc
-  ALLOC(fwd_val, an.fwd.n_slots); ALLOC(bwd_val, an.bwd.n_slots); ALLOC(chk_val, an.chk.n_slots); ALLOC(dinv, an.N);
+  ALLOC(fwd_val, (size_t)an.fwd.phys_steps() * 64); ALLOC(bwd_val, (size_t)an.bwd.phys_steps() * 64); ALLOC(chk_val, (size_t)an.chk.phys_steps() * 64); ALLOC(dinv, an.N);
   ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
@@ -491,8 +499,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   s.n = n; s.m = m; s.N = an.N; s.batch = B; s.tile = BT; s.n_tiles = h->ntiles;
   s.nnz_P_triu = an.Pp[n]; s.nnz_A = nnzA; s.nnz_KKT = an.nnzK(); s.nnz_L = an.nnzL();
   s.n_supernodes = (int64_t)an.sn_start.size() - 1; s.n_blocks = (int64_t)an.chunk_start.size() - 1;
-  s.fwd_levels = an.fwd.n_levels; s.bwd_levels = an.bwd.n_levels;
-  s.fwd_slots = an.fwd.n_slots; s.bwd_slots = an.bwd.n_slots; s.chk_slots = an.chk.n_slots;
+  s.fwd_levels = an.fwd.n_phases; s.bwd_levels = an.bwd.n_phases;
+  s.fwd_slots = (int64_t)an.fwd.phys_steps() * 64; s.bwd_slots = (int64_t)an.bwd.phys_steps() * 64; s.chk_slots = (int64_t)an.chk.phys_steps() * 64;
   s.lds_bytes = (int64_t)h->lds; s.threads_per_block = h->threads;
   s.setup_seconds_host = t1 - t0; s.setup_seconds_factor = t_factor; s.setup_seconds_upload = t_upload;
   return MI_OSQP_OK;
@@ -913,8 +921,8 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const 
     st->n = n; st->m = m; st->N = an.N; st->batch = 1; st->tile = 1; st->n_tiles = 1;
     st->nnz_P_triu = an.Pp[n]; st->nnz_A = an.Ap[n]; st->nnz_KKT = an.nnzK(); st->nnz_L = an.nnzL();
     st->n_supernodes = (int64_t)an.sn_start.size() - 1; st->n_blocks = (int64_t)an.chunk_start.size() - 1;
-    st->fwd_levels = an.fwd.n_levels; st->bwd_levels = an.bwd.n_levels;
-    st->fwd_slots = an.fwd.n_slots; st->bwd_slots = an.bwd.n_slots; st->chk_slots = an.chk.n_slots;
+    st->fwd_levels = an.fwd.n_phases; st->bwd_levels = an.bwd.n_phases;
+    st->fwd_slots = (int64_t)an.fwd.phys_steps() * 64; st->bwd_slots = (int64_t)an.bwd.phys_steps() * 64; st->chk_slots = (int64_t)an.chk.phys_steps() * 64;
   }
   return MI_OSQP_OK;
 }
