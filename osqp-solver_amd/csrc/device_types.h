@@ -40,6 +40,7 @@ struct KernelArgs {
 // device block refactorisation (row E13); tables are host_core.hpp BlockFactor
 struct FactorArgs {
   int n, m, N, B, nnzP, nnzK, pa_len, n_levels, force_all;
+  int debug_skip;     // timing experiments only (MI_OSQP_FACTOR_SKIP): 1 rank-1 updates, 2 general updates, 4 diag, 8 trsm, 16 scatter
   uint32_t storage;
   SchedDev fwd, bwd;
   const uint32_t *blk, *lvl, *utask, *tri, *dtask, *ttask, *asm_dst, *asm_src;

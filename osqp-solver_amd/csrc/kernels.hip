@@ -224,73 +224,86 @@ __device__ __forceinline__ void prefetch_all(const SchedDev &s, const ValSrc &vs
     load_step<BT>(vs, (uint32_t)st < n ? begin + (uint32_t)st : s.zero_step, lane, p.v[st], p.gi[st]);
 }
 
+// One phase of a wave.  The buffer `p` is only READ inside branches; its refill (the
+// loads of the wave's next-phase range) is ONE unconditional straight-line site, so
+// that the compiler keeps a single copy of the buffer and does not have to merge
+// differently-defined versions of it (which would cost register copies behind a
+// vmcnt(0) at every phase).
+//   kind 0: per step {gather, fma, optional flush}, then the step's registers are
+//           refilled -> about PF steps per wave stay in flight at all times;
+//   kind 1: the block task (if this wave has one) reads the buffer first, then the
+//           same refill sequence runs.
 template <int BT, int PF, bool SUB>
-__device__ __forceinline__ void consume_refill(const SchedDev &s, const ValSrc &vs, double *xs, double *out,
-                                               PrefA<BT, PF> &p, uint32_t nbegin, uint32_t nend, int lane) {
+__device__ __forceinline__ void phase_step(const SchedDev &s, const ValSrc &vs, double *xs, double *out,
+                                           PrefA<BT, PF> &p, uint32_t kind, uint32_t has_block,
+                                           uint32_t nbegin, uint32_t nend, int lane) {
   const uint32_t n = p.end - p.begin, nn = nend - nbegin;
   const uint32_t dnext = load_desc(vs, nbegin, nn, lane);     // older than every refill below
   double *base = SUB ? xs : out;
+  if (kind != 0 && has_block) {
+    // ---- block task: lane = (i, b); 15 values in v[k / BT][k % BT], target row in the first index word
+    static_assert(PF * BT >= MI_CHUNK - 1, "prefetch buffer too small for a block task");
+    const int b = lane % BT;
+    const uint32_t row = lane < MI_CHUNK * BT ? p.gi[0] >> 16 : 0xFFFFu;
+    const bool valid = row != 0xFFFFu;
+    double accb = valid ? xs[(size_t)row * BT + b] : 0.0;
+    // broadcast of local row k to the lanes of the same QP: v_readlane (constant lane ids,
+    // SGPR results) + a select on b -- no LDS round trip in the 15-step dependent chain
+#pragma unroll
+    for (int k = 0; k < MI_CHUNK - 1; k++) {
+      double vb[BT];
+#pragma unroll
+      for (int bb = 0; bb < BT; bb++) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(accb), k * BT + bb);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(accb), k * BT + bb);
+        vb[bb] = __hiloint2double(hi, lo);
+      }
+      double v = vb[0];
+      if constexpr (BT >= 2) v = (b & 1) ? vb[1] : v;
+      if constexpr (BT == 4) { const double v2 = (b & 1) ? vb[3] : vb[2]; v = (b & 2) ? v2 : v; }
+      accb = fma(-p.v[k / BT][k % BT], v, accb);
+    }
+    if (valid) xs[(size_t)row * BT + b] = accb;
+  }
   double acc[BT];
 #pragma unroll
   for (int b = 0; b < BT; b++) acc[b] = 0.0;
 #pragma unroll
   for (int st = 0; st < PF; st++) {
-    const uint32_t w = p.gi[st];
-    double xv[BT];
-    load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
+    if (kind == 0) {
+      const uint32_t w = p.gi[st];
+      double xv[BT];
+      load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[b] = fma(p.v[st][b], xv[b], acc[b]);
-    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)p.desc, st);
-    if (d & 8u) {
-      reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
+      for (int b = 0; b < BT; b++) acc[b] = fma(p.v[st][b], xv[b], acc[b]);
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)p.desc, st);
+      if (d & 8u) {
+        reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
 #pragma unroll
-      for (int b = 0; b < BT; b++) acc[b] = 0.0;
+        for (int b = 0; b < BT; b++) acc[b] = 0.0;
+      }
     }
-    // rotate: this slot now carries step st of the next phase
+    // rotate: this slot now carries step st of the next phase (steps past the end read the zero step)
     load_step<BT>(vs, (uint32_t)st < nn ? nbegin + (uint32_t)st : s.zero_step, lane, p.v[st], p.gi[st]);
-    __builtin_amdgcn_sched_barrier(0);     // keep {gather, fma, refill} of one step together: bounded live ranges
   }
   // ranges longer than the buffer (rare): the tail is loaded on the fly
-  for (uint32_t st = PF; st < n; st++) {
-    double v[BT], xv[BT];
-    uint32_t w;
-    load_step<BT>(vs, p.begin + st, lane, v, w);
-    load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
+  if (kind == 0) {
+    for (uint32_t st = PF; st < n; st++) {
+      double v[BT], xv[BT];
+      uint32_t w;
+      load_step<BT>(vs, p.begin + st, lane, v, w);
+      load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
 #pragma unroll
-    for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
-    const uint32_t d = as_const(s.step)[p.begin + st];
-    if (d & 8u) {
-      reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
+      for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
+      const uint32_t d = as_const(s.step)[p.begin + st];
+      if (d & 8u) {
+        reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
 #pragma unroll
-      for (int b = 0; b < BT; b++) acc[b] = 0.0;
+        for (int b = 0; b < BT; b++) acc[b] = 0.0;
+      }
     }
   }
   p.begin = nbegin; p.end = nend; p.desc = dnext;
-}
-
-// ---- block tasks: the dense in-chunk triangle (<=16 rows) solved inside one wave:
-// lane = (i, b); for k = 0..14 the finished value of local row k is broadcast and
-// every lane i > k subtracts L[k->i] * v (structural zeros are stored as 0).  The 15
-// values per lane sit in the same register buffer (element k = v[k / BT][k % BT]); the
-// lane's target row rides in the first index word.
-template <int BT, int PF>
-__device__ __forceinline__ void consume_B(double *xs, const PrefA<BT, PF> &p, int lane) {
-  static_assert(PF * BT >= MI_CHUNK - 1, "prefetch buffer too small for a block task");
-  const int b = lane % BT;
-  const uint32_t row = lane < MI_CHUNK * BT ? p.gi[0] >> 16 : 0xFFFFu;
-  const bool valid = row != 0xFFFFu;
-  double acc = valid ? xs[(size_t)row * BT + b] : 0.0;
-  // byte address of the broadcasting lane for ds_bpermute; kept opaque so that the 15
-  // per-step addresses are recomputed (one add) instead of living in 15 hoisted VGPRs
-  int baddr = b << 2;
-  asm volatile("" : "+v"(baddr));
-#pragma unroll
-  for (int k = 0; k < MI_CHUNK - 1; k++) {
-    const int lo = __builtin_amdgcn_ds_bpermute(baddr + k * BT * 4, __double2loint(acc));
-    const int hi = __builtin_amdgcn_ds_bpermute(baddr + k * BT * 4, __double2hiint(acc));
-    acc = fma(-p.v[k / BT][k % BT], __hiloint2double(hi, lo), acc);
-  }
-  if (valid) xs[(size_t)row * BT + b] = acc;
 }
 
 // One triangular solve = walk the flat phase table.
@@ -309,13 +322,7 @@ __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, d
     const uint32_t kind = pr[0], has = e[3];
     uint32_t nb = s.zero_step, ne = s.zero_step;
     if (p + 1 < s.n_phases) { nb = e[stride]; ne = e[stride + 1]; }
-    if (kind == 0) {
-      consume_refill<BT, PF, true>(s, vals, xs, nullptr, pa, nb, ne, lane);
-    } else {
-      if (has) consume_B<BT, PF>(xs, pa, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      prefetch_all<BT, PF>(s, vals, nb, ne, lane, pa);
-    }
+    phase_step<BT, PF, true>(s, vals, xs, nullptr, pa, kind, has, nb, ne, lane);
     lds_barrier();
   }
 }
@@ -336,7 +343,7 @@ __device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc &vals, 
     mi_cptr e = ph + (size_t)p * stride + 1 + 4 * wave;
     uint32_t nb = s.zero_step, ne = s.zero_step;
     if (p + 1 < p1) { nb = e[stride]; ne = e[stride + 1]; }
-    consume_refill<BT, PF, false>(s, vals, xs, out, pa, nb, ne, lane);
+    phase_step<BT, PF, false>(s, vals, xs, out, pa, 0u, 0u, nb, ne, lane);
   }
 }
 
@@ -760,7 +767,7 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
   // ---- rank-1 sources (one-column chunks), 8 per batch: all operand loads of a batch
   // are in flight together, the 8 scaled B columns go through wave-private LDS
   constexpr int G = 8;
-  for (uint32_t q = q0; q < qm; q += G) {
+  for (uint32_t q = q0; q < ((a.debug_skip & 1) ? q0 : qm); q += G) {
     double av[G], bv[G];
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -791,26 +798,34 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
     wave_sync();
   }
   // ---- general sources (width > 1)
-  for (uint32_t q = qm; q < q1; q++) {
+  for (uint32_t q = qm; q < ((a.debug_skip & 2) ? qm : q1); q++) {
     const uint32_t ia = tri[2 * q], ib = tri[2 * q + 1];
     const uint32_t ao = blk[4 * ia], ahw = blk[4 * ia + 3], ah = ahw >> 8, aw = ahw & 255u, kc0 = blk[4 * ia + 2];
     const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
-    // stage (B .* d) : lane (j, b) provides row j of B
-    const bool brow = (uint32_t)i < bh && inw;
-    for (uint32_t k = 0; k < aw; k++) {
-      double v = 0.0;
-      if (brow) v = Lb[((size_t)bo + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b];
-      if (inw) Ss[MI_BS(k, b, i)] = v;
+    // all operand loads of the triple are issued up front (fixed 16-way unroll, predicated):
+    // lane (i, b) needs row i of A and provides row i of (B .* d) to the wave through LDS
+    const bool brow = (uint32_t)i < bh && inw, arow = (uint32_t)i < ah && inw;
+    double avk[MI_CHUNK], bvk[MI_CHUNK];
+#pragma unroll
+    for (int k = 0; k < MI_CHUNK; k++) {
+      avk[k] = (arow && (uint32_t)k < aw) ? Lb[((size_t)ao + k * ah + i) * BT + b] : 0.0;
+      bvk[k] = (brow && (uint32_t)k < aw) ? Lb[((size_t)bo + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b] : 0.0;
+    }
+    if (inw) {
+#pragma unroll
+      for (int k = 0; k < MI_CHUNK; k++) Ss[MI_BS(k, b, i)] = bvk[k];
     }
     wave_sync();
-    for (uint32_t k = 0; k < aw; k++) {
-      const double avk = ((uint32_t)i < ah && inw) ? Lb[((size_t)ao + k * ah + i) * BT + b] : 0.0;
-      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(k, b, 0)]);
 #pragma unroll
-      for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
-        const double2 bvv = bs[j2];
-        acc[2 * j2] = fma(-avk, bvv.x, acc[2 * j2]);
-        acc[2 * j2 + 1] = fma(-avk, bvv.y, acc[2 * j2 + 1]);
+    for (int k = 0; k < MI_CHUNK; k++) {
+      if ((uint32_t)k < aw) {
+        const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(k, b, 0)]);
+#pragma unroll
+        for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
+          const double2 bvv = bs[j2];
+          acc[2 * j2] = fma(-avk[k], bvv.x, acc[2 * j2]);
+          acc[2 * j2 + 1] = fma(-avk[k], bvv.y, acc[2 * j2 + 1]);
+        }
       }
     }
     wave_sync();
@@ -937,9 +952,9 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
       for (uint32_t t = lv[0] + wave; t < lv[1]; t += nw) fct_update<BT>(a, Lb, Dl, Ss, t, lane);
       __syncthreads();
     }
-    for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
+    if (!(a.debug_skip & 4)) for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
     __syncthreads();
-    if (lv[5] > lv[4]) {
+    if (lv[5] > lv[4] && !(a.debug_skip & 8)) {
       for (uint32_t t = lv[4] + wave; t < lv[5]; t += nw) fct_trsm<BT>(a, Lb, Dl, dnew, Ss, t, lane);
       __syncthreads();
     }
@@ -954,7 +969,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     if (tid < BT) a.npos[(size_t)tile * BT + b] = s_npos[b];
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
-  if (flag) {
+  if (flag && !(a.debug_skip & 16)) {
     double *fv = a.fwd_val + (size_t)tile * a.fwd.phys_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.phys_steps * 64 * BT;
     for (size_t e = tid; e < (size_t)a.fwd.n_slots * BT; e += nthr) {
       const uint32_t sl = (uint32_t)(e / BT);

@@ -1,0 +1,15 @@
+"""developer script: refactor kernel time with parts disabled (results invalid, timing only)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import osqp_solver_amd as M
+from osqp_solver_amd import problems as PR
+pr = PR.random_box_qp(1024)
+s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+for skip, name in ((0, "full"), (1, "no rank-1"), (2, "no general"), (3, "no updates"), (3 + 4 + 8, "no U/D/T"), (31, "assembly+zero only"), (16, "no scatter")):
+    os.environ["MI_OSQP_FACTOR_SKIP"] = str(skip)
+    s.refactor_device(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3): s.refactor_device()
+    torch.cuda.synchronize()
+    print(f"{name:22s} {(time.perf_counter()-t)/3*1e3:7.2f} ms", flush=True)
