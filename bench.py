@@ -100,11 +100,11 @@ def main():
     solver.kernel_time()                       # clear the HIP-event accumulators
     fence()
     t0 = time.perf_counter()
-    dev_s = ref_s = 0.0
+    dev_s = ref_s = cmp_s = 0.0
     for _ in range(args.steps):
         step()
         ls = solver.last_solve_stats()
-        dev_s += ls["device_s"]; ref_s += ls["refactor_s"]
+        dev_s += ls["device_s"]; ref_s += ls["refactor_s"]; cmp_s += ls["compact_s"]
     fence()
     elapsed = time.perf_counter() - t0
     if dist_on:
@@ -132,7 +132,7 @@ def main():
         "iters_mean": float(iters.mean()), "iters_max": int(iters.max()),
         "all_solved": bool(np.all(status == 1)),
         "setup_seconds": setup_s,
-        "step_breakdown_ms": {"device_iterate": 1e3 * dev_s / args.steps, "device_refactor": 1e3 * ref_s / args.steps,
+        "step_breakdown_ms": {"device_iterate": 1e3 * dev_s / args.steps, "device_refactor": 1e3 * ref_s / args.steps, "compaction": 1e3 * cmp_s / args.steps,
                               "refactors_per_step": ls["refactors"], "launches_per_step": ls["launches"]},
     }
     if rank == 0:
@@ -147,7 +147,7 @@ def main():
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "admm_kernel<%d,512>" % st["tile"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+        out["roofline"] = {"bound": "hbm", "kernel": "iterate_kernel<%d,512>" % st["tile"], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                            "frac": achieved / 8000.0, "traffic": traffic,
                            "algorithmic_bytes_per_launch": ab["total"] / launches_per_step,
                            "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,

@@ -171,10 +171,12 @@ int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_sta
 /* Benchmark helper: cold-start every QP and restore rho and the factor that
  * setup produced, so that repeated solves do identical work. */
 int mi_osqp_batch_reset(mi_osqp_batch *h);
-/* Totals of the last solve: ADMM iterations summed over QPs, launches, seconds
- * spent in the device iterate and in host refactorisations. */
+/* Totals of the last solve: ADMM iterations summed over QPs, iterate launches (= segments),
+ * seconds in iterate_kernel (HIP events), in device refactorisations and in the
+ * compaction swaps (wall, including their synchronisation). */
 int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64_t *kernel_launches,
-                                   double *device_seconds, double *refactor_seconds, int64_t *refactor_count);
+                                   double *device_seconds, double *refactor_seconds, int64_t *refactor_count,
+                                   double *compact_seconds);
 
 /* ------------------------------------------------- the path's kernels as ops
  * (parity tests and roofline measurements call these; all pointers HBM)

@@ -97,7 +97,7 @@ def lib():
         L.mi_osqp_batch_solve_device.argtypes = [vp, vp, vp, vp, vp]
         L.mi_osqp_batch_reset.argtypes = [vp]
         L.mi_osqp_batch_refactor_device.argtypes = [vp]
-        L.mi_osqp_batch_last_solve_stats.argtypes = [vp, ip, ip, dp, dp, ip]
+        L.mi_osqp_batch_last_solve_stats.argtypes = [vp, ip, ip, dp, dp, ip, dp]
         L.mi_osqp_batch_spmv.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.mi_osqp_batch_kkt_solve.argtypes = [vp, vp, vp, vp]
         L.mi_osqp_batch_kernel_time.argtypes = [vp, dp, ip]
@@ -204,9 +204,12 @@ class BatchSolver:
         _chk(rc, "mi_osqp_batch_setup")
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().mi_osqp_batch_free(self._h)
-            self._h = C.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().mi_osqp_batch_free(self._h)
+                self._h = C.c_void_p()
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
     close = __del__
 
@@ -260,9 +263,11 @@ class BatchSolver:
 
     def last_solve_stats(self):
         it, ln, rc = C.c_int64(), C.c_int64(), C.c_int64()
-        ds, rs = C.c_double(), C.c_double()
-        _chk(lib().mi_osqp_batch_last_solve_stats(self._h, C.byref(it), C.byref(ln), C.byref(ds), C.byref(rs), C.byref(rc)), "stats")
-        return dict(total_iters=it.value, launches=ln.value, device_s=ds.value, refactor_s=rs.value, refactors=rc.value)
+        ds, rs, cs = C.c_double(), C.c_double(), C.c_double()
+        _chk(lib().mi_osqp_batch_last_solve_stats(self._h, C.byref(it), C.byref(ln), C.byref(ds), C.byref(rs), C.byref(rc),
+                                                  C.byref(cs)), "stats")
+        return dict(total_iters=it.value, launches=ln.value, device_s=ds.value, refactor_s=rs.value, refactors=rc.value,
+                    compact_s=cs.value)
 
     def kernel_time(self):
         ms, cnt = C.c_double(), C.c_int64()

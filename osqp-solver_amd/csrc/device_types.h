@@ -28,12 +28,14 @@ struct KernelArgs {
   double *x, *z, *y;
   const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
   double *dx, *dy, *out1, *out2, *dscal;
-  int *iscal, *tile_iter;
+  int *iscal;
+  const int *qp_of_slot;                // slot (tile*BT + b) -> global QP id, -1 = empty (compaction during a solve)
   double *x_out, *y_out;                // QP-major [B][n], [B][m]
   // settings (row S)
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
   int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;
-  int iter_budget;
+  int iter_begin, iter_end;             // this launch runs iterations (iter_begin, iter_end]
+  int info_at_end;                      // a check_kernel follows: store delta_x / delta_y of the last iteration
   int chk_lvl[4];                       // first phase of the P x / A'y / A x levels of the check schedule (+ end)
 };
 
@@ -53,7 +55,8 @@ struct FactorArgs {
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
 
-hipError_t launch_admm(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
+hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
+hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                        const double *x, const double *y, double *Px, double *Aty, double *Ax);
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
@@ -63,6 +66,9 @@ hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads
 hipError_t launch_interleave(const double *src, double *dst, const int *ids, int nq, int len, int BT, hipStream_t st);
 hipError_t launch_scatter(const double *src, double *dst, const int *map, const int *ids, int nq, int srclen,
                           const SchedDev &sd, int BT, hipStream_t st);
+hipError_t launch_swap_plain(double *base, const int2 *pairs, int npairs, int len, int BT, hipStream_t st);
+hipError_t launch_swap_int(int *base, const int2 *pairs, int npairs, int len, int BT, hipStream_t st);
+hipError_t launch_swap_sched(double *base, const int2 *pairs, int npairs, const SchedDev &sd, int BT, hipStream_t st);
 hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st);
 hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
 hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,

@@ -429,36 +429,23 @@ __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtr
   run_tri<BT, PF>(a.bwd, p.vbwd, xs, wave, lane);
 }
 
+// E6-E10 for iterations (iter_begin, iter_end] of one tile.  Lean on purpose: the
+// residual / termination / rho logic lives in check_kernel, so this kernel needs
+// little beyond the rotating prefetch buffer.
 template <int BT, int NT>
-__global__ __launch_bounds__(NT) void admm_kernel(KernelArgs a) {
+__global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
   const int n = a.n, m = a.m, N = a.N;
   double *xs = smem;
-  double *red = smem + (size_t)N * BT;
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
-  const int qp = tile * BT + b;             // global QP id of this thread's class
-
-  int done = p.iscal[IS_DONE * BT + b];
+  const int done = p.iscal[IS_DONE * BT + b];
   if (__syncthreads_and(done)) return;
-  int iter = a.tile_iter[tile];
-  int status = p.iscal[IS_STATUS * BT + b];
-  int rho_updates = p.iscal[IS_RHO_UPDATES * BT + b];
-  double rho = p.dscal[DS_RHO * BT + b];
-  const double c = p.dscal[DS_C * BT + b], cinv = p.dscal[DS_CINV * BT + b];
   const double alpha = a.alpha, sigma = a.sigma;
-  const bool unscale = a.scaling && !a.scaled_termination;
-  int budget = a.iter_budget;
-
-  while (true) {
-    iter++;
-    const bool is_last = iter >= a.max_iter;
-    const bool is_check = a.check_termination && (iter % a.check_termination == 0);
-    const bool is_rho = a.adaptive_rho && a.rho_interval && (iter % a.rho_interval == 0);
-    const bool do_info = is_check || is_rho || is_last;
-
+  for (int iter = a.iter_begin + 1; iter <= a.iter_end; iter++) {
+    const bool do_info = a.info_at_end && iter == a.iter_end;     // delta_x / delta_y are only needed by check_kernel
     // ---- E6: rhs into the permuted LDS vector
     for (int e = tid; e < N * BT; e += nthr) {
       const int i = e / BT;
@@ -489,182 +476,203 @@ __global__ __launch_bounds__(NT) void admm_kernel(KernelArgs a) {
       if (!done) { p.z[e] = zn; p.y[e] = yv + dyv; if (do_info) p.dy[e] = dyv; }
     }
     __syncthreads();
-
-    int need_refactor = 0;
-    if (do_info) {
-      // ---- E11: [x;y] -> LDS, P x / A' y / A x
-      for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
-      for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
-      __syncthreads();
-      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
-      __syncthreads();
-      // residual vectors and the norms termination + rho estimate need
-      double mx[14];
-#pragma unroll
-      for (int k = 0; k < 14; k++) mx[k] = 0.0;
-      double sm[1] = {0.0};
-      for (int e = tid; e < n * BT; e += nthr) {
-        const double px = p.out1[e], aty = p.out1[(size_t)n * BT + e], qv = p.q[e], xv = p.x[e];
-        const double di = p.Dsc_inv[e];
-        double dres = qv + px;
-        dres += aty;
-        mx[0] = fmax(mx[0], fabs(dres));      mx[1] = fmax(mx[1], fabs(di * dres));
-        mx[2] = fmax(mx[2], fabs(qv));        mx[3] = fmax(mx[3], fabs(aty));   mx[4] = fmax(mx[4], fabs(px));
-        mx[5] = fmax(mx[5], fabs(di * qv));   mx[6] = fmax(mx[6], fabs(di * aty)); mx[7] = fmax(mx[7], fabs(di * px));
-        sm[0] += 0.5 * xv * px + qv * xv;
-      }
-      for (int e = tid; e < m * BT; e += nthr) {
-        const double ax = p.out1[(size_t)2 * n * BT + e], zv = p.z[e], ei = p.Esc_inv[e];
-        const double pres = ax - zv;
-        mx[8] = fmax(mx[8], fabs(pres));      mx[9] = fmax(mx[9], fabs(ei * pres));
-        mx[10] = fmax(mx[10], fabs(zv));      mx[11] = fmax(mx[11], fabs(ax));
-        mx[12] = fmax(mx[12], fabs(ei * zv)); mx[13] = fmax(mx[13], fabs(ei * ax));
-      }
-      block_reduce<BT, 14, true>(mx, red, tid, wave, nw, lane);
-      block_reduce<BT, 1, false>(sm, red, tid, wave, nw, lane);
-      const double pri_res = (m == 0) ? 0.0 : (unscale ? mx[9] : mx[8]);
-      const double dua_res = unscale ? cinv * mx[1] : mx[0];
-      double obj = sm[0];
-      if (a.scaling) obj *= cinv;
-      const double pri_nrm = unscale ? fmax(mx[12], mx[13]) : fmax(mx[10], mx[11]);
-      const double dua_nrm = unscale ? cinv * fmax(fmax(mx[5], mx[6]), mx[7]) : fmax(fmax(mx[2], mx[3]), mx[4]);
-
-      // ---- E12 ingredients that do not depend on the tolerances
-      // infeasibility certificates on delta_y / delta_x
-      double mi[4] = {0.0, 0.0, 0.0, 0.0};   // norm_dy, norm_dx, |Dinv A'dy|, |Dinv P dx|
-      double si[2] = {0.0, 0.0};             // ineq_lhs, q'dx
-      for (int e = tid; e < n * BT; e += nthr) {
-        const double d = p.dx[e];
-        xs[e] = d;
-        mi[1] = fmax(mi[1], unscale ? fabs(p.Dsc[e] * d) : fabs(d));
-        si[1] += p.q[e] * d;
-      }
-      for (int e = tid; e < m * BT; e += nthr) {
-        double d = p.dy[e];
-        const double lo = p.l[e], up = p.u[e];
-        if (up > MI_INFTY * MI_MIN_SCALING) {
-          if (lo < -MI_INFTY * MI_MIN_SCALING) d = 0.0; else d = fmin(d, 0.0);
-        } else if (lo < -MI_INFTY * MI_MIN_SCALING) d = fmax(d, 0.0);
-        xs[(size_t)n * BT + e] = d;
-        mi[0] = fmax(mi[0], unscale ? fabs(p.Esc[e] * d) : fabs(d));
-        si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
-      }
-      __syncthreads();
-      run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
-      __syncthreads();
-      for (int e = tid; e < n * BT; e += nthr) {
-        const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
-        const double di = unscale ? p.Dsc_inv[e] : 1.0;
-        mi[2] = fmax(mi[2], fabs(di * atdy));
-        mi[3] = fmax(mi[3], fabs(di * pdx));
-      }
-      block_reduce<BT, 4, true>(mi, red, tid, wave, nw, lane);
-      block_reduce<BT, 2, false>(si, red, tid, wave, nw, lane);
-      const double norm_dy = mi[0], norm_dx = mi[1];
-      const double cost_scaling = unscale ? c : 1.0;
-
-      // tolerance-dependent decision; approx = 10x tolerances (max_iter path)
-      auto decide = [&](bool approx) -> int {
-        const double f = approx ? 10.0 : 1.0;
-        const double eps_abs = f * a.eps_abs, eps_rel = f * a.eps_rel;
-        const double eps_pinf = f * a.eps_prim_inf, eps_dinf = f * a.eps_dual_inf;
-        // rows of A dx outside the recession cone (needs its own reduction)
-        double viol[1] = {0.0};
-        for (int e = tid; e < m * BT; e += nthr) {
-          double adx = p.out2[(size_t)2 * n * BT + e];
-          if (unscale) adx *= p.Esc_inv[e];
-          const double lo = p.l[e], up = p.u[e];
-          if ((up < MI_INFTY * MI_MIN_SCALING && adx > eps_dinf * norm_dx) ||
-              (lo > -MI_INFTY * MI_MIN_SCALING && adx < -eps_dinf * norm_dx)) viol[0] = 1.0;
-        }
-        block_reduce<BT, 1, true>(viol, red, tid, wave, nw, lane);
-        if (pri_res > MI_INFTY || dua_res > MI_INFTY) return -7;   // non-convex / diverged
-        int prim_ok = 0, dual_ok = 0, prim_inf = 0, dual_inf = 0;
-        if (m == 0) prim_ok = 1;
-        else {
-          const double eps_prim = eps_abs + eps_rel * pri_nrm;
-          if (pri_res < eps_prim) prim_ok = 1;
-          else if (norm_dy > MI_DIV_TOL && si[0] < -eps_pinf * norm_dy) prim_inf = mi[2] < eps_pinf * norm_dy;
-        }
-        const double eps_dual = eps_abs + eps_rel * dua_nrm;
-        if (dua_res < eps_dual) dual_ok = 1;
-        else if (norm_dx > MI_DIV_TOL && si[1] < -cost_scaling * eps_dinf * norm_dx &&
-                 mi[3] < cost_scaling * eps_dinf * norm_dx) dual_inf = viol[0] == 0.0;
-        if (prim_ok && dual_ok) return approx ? 2 : 1;
-        if (prim_inf) return approx ? 3 : -3;
-        if (dual_inf) return approx ? 4 : -4;
-        return 0;
-      };
-
-      int new_status = 0;
-      if (is_check || is_last) new_status = decide(false);
-      double rho_est = p.dscal[DS_RHO_EST * BT + b];
-      // ---- E13: rho estimate from the SCALED residual norms
-      auto rho_estimate = [&]() -> double {
-        const double pr = mx[8] / (fmax(mx[10], mx[11]) + MI_DIV_TOL);
-        const double du = mx[0] / (fmax(fmax(mx[2], mx[3]), mx[4]) + MI_DIV_TOL);
-        double e = rho * sqrt(pr / du);
-        return fmin(fmax(e, MI_RHO_MIN), MI_RHO_MAX);
-      };
-      if (!done && new_status == 0 && is_rho) {
-        const double rn = rho_estimate();
-        rho_est = rn;
-        if (rn > rho * a.rho_tolerance || rn < rho / a.rho_tolerance) {
-          need_refactor = 1;
-          rho = fmin(fmax(rn, MI_RHO_MIN), MI_RHO_MAX);
-          rho_updates++;
-        }
-      }
-      if (!done && new_status == 0 && is_last) {
-        new_status = decide(true);
-        if (new_status == 0) new_status = -2;   // max iterations reached
-      } else if (is_last) {
-        decide(true);   // keep barriers uniform across the workgroup
-      }
-      if (!done && new_status != 0) {
-        // ---- E14: store_solution
-        done = 1; status = new_status;
-        if (!need_refactor) rho_est = rho_estimate();
-        if (tid < BT) {
-          p.dscal[DS_PRI_RES * BT + b] = pri_res; p.dscal[DS_DUA_RES * BT + b] = dua_res;
-          p.dscal[DS_OBJ * BT + b] = (status == -3 || status == 3) ? MI_INFTY
-                                     : (status == -4 || status == 4) ? -MI_INFTY
-                                     : (status == -7) ? __builtin_nan("") : obj;
-          p.iscal[IS_ITER * BT + b] = iter;
-        }
-      }
-      if (tid < BT) p.dscal[DS_RHO_EST * BT + b] = rho_est;
-      // outputs for QPs that finished in this pass (done is uniform per class b)
-      const int just_done = done && (p.iscal[IS_DONE * BT + b] == 0);
-      __syncthreads();
-      if (just_done && qp < a.B) {
-        const bool has_sol = !(status == -3 || status == 3 || status == -4 || status == 4 || status == -7);
-        const double nanv = __builtin_nan("");
-        for (int e = tid; e < n * BT; e += nthr) {
-          const int i = e / BT;
-          a.x_out[(size_t)qp * n + i] = has_sol ? (a.scaling ? p.Dsc[e] * p.x[e] : p.x[e]) : nanv;
-          if (!has_sol) p.x[e] = 0.0;
-        }
-        for (int e = tid; e < m * BT; e += nthr) {
-          const int j = e / BT;
-          a.y_out[(size_t)qp * m + j] = has_sol ? (a.scaling ? p.Esc[e] * p.y[e] * cinv : p.y[e]) : nanv;
-          if (!has_sol) { p.y[e] = 0.0; p.z[e] = 0.0; }
-        }
-      }
-      __syncthreads();
-      if (tid < BT) {
-        p.iscal[IS_DONE * BT + b] = done; p.iscal[IS_STATUS * BT + b] = status;
-        p.iscal[IS_RHO_UPDATES * BT + b] = rho_updates;
-        p.iscal[IS_NEED_REFACTOR * BT + b] = need_refactor;
-        p.dscal[DS_RHO * BT + b] = rho;
-      }
-    }
-    budget--;
-    const int all_done = __syncthreads_and(done);
-    const int any_ref = __syncthreads_or(need_refactor);
-    if (all_done || any_ref || budget <= 0 || is_last) break;
   }
-  if (tid == 0) a.tile_iter[tile] = iter;
+}
+
+// E11-E14 at iteration iter_end: residuals, termination and infeasibility tests,
+// rho estimate / update request, solution store.  Runs once per segment.
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int b = tid % BT;
+  const int n = a.n, m = a.m, N = a.N;
+  double *xs = smem;
+  double *red = smem + (size_t)N * BT;
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  // global QP id of this thread's class: during a solve the QPs still iterating are
+  // compacted into the leading tiles (solver.hip), so the id comes from a table
+  const int qp = a.qp_of_slot[tile * BT + b];
+  int done = p.iscal[IS_DONE * BT + b];
+  if (__syncthreads_and(done)) return;
+  const int iter = a.iter_end;
+  int status = p.iscal[IS_STATUS * BT + b];
+  int rho_updates = p.iscal[IS_RHO_UPDATES * BT + b];
+  double rho = p.dscal[DS_RHO * BT + b];
+  const double c = p.dscal[DS_C * BT + b], cinv = p.dscal[DS_CINV * BT + b];
+  const bool unscale = a.scaling && !a.scaled_termination;
+  const bool is_last = iter >= a.max_iter;
+  const bool is_check = a.check_termination && (iter % a.check_termination == 0);
+  const bool is_rho = a.adaptive_rho && a.rho_interval && (iter % a.rho_interval == 0);
+  int need_refactor = 0;
+  // ---- E11: [x;y] -> LDS, P x / A' y / A x
+  for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
+  for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
+  __syncthreads();
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
+  __syncthreads();
+  // residual vectors and the norms termination + rho estimate need
+  double mx[14];
+#pragma unroll
+  for (int k = 0; k < 14; k++) mx[k] = 0.0;
+  double sm[1] = {0.0};
+  for (int e = tid; e < n * BT; e += nthr) {
+    const double px = p.out1[e], aty = p.out1[(size_t)n * BT + e], qv = p.q[e], xv = p.x[e];
+    const double di = p.Dsc_inv[e];
+    double dres = qv + px;
+    dres += aty;
+    mx[0] = fmax(mx[0], fabs(dres));      mx[1] = fmax(mx[1], fabs(di * dres));
+    mx[2] = fmax(mx[2], fabs(qv));        mx[3] = fmax(mx[3], fabs(aty));   mx[4] = fmax(mx[4], fabs(px));
+    mx[5] = fmax(mx[5], fabs(di * qv));   mx[6] = fmax(mx[6], fabs(di * aty)); mx[7] = fmax(mx[7], fabs(di * px));
+    sm[0] += 0.5 * xv * px + qv * xv;
+  }
+  for (int e = tid; e < m * BT; e += nthr) {
+    const double ax = p.out1[(size_t)2 * n * BT + e], zv = p.z[e], ei = p.Esc_inv[e];
+    const double pres = ax - zv;
+    mx[8] = fmax(mx[8], fabs(pres));      mx[9] = fmax(mx[9], fabs(ei * pres));
+    mx[10] = fmax(mx[10], fabs(zv));      mx[11] = fmax(mx[11], fabs(ax));
+    mx[12] = fmax(mx[12], fabs(ei * zv)); mx[13] = fmax(mx[13], fabs(ei * ax));
+  }
+  block_reduce<BT, 14, true>(mx, red, tid, wave, nw, lane);
+  block_reduce<BT, 1, false>(sm, red, tid, wave, nw, lane);
+  const double pri_res = (m == 0) ? 0.0 : (unscale ? mx[9] : mx[8]);
+  const double dua_res = unscale ? cinv * mx[1] : mx[0];
+  double obj = sm[0];
+  if (a.scaling) obj *= cinv;
+  const double pri_nrm = unscale ? fmax(mx[12], mx[13]) : fmax(mx[10], mx[11]);
+  const double dua_nrm = unscale ? cinv * fmax(fmax(mx[5], mx[6]), mx[7]) : fmax(fmax(mx[2], mx[3]), mx[4]);
+
+  // ---- E12 ingredients that do not depend on the tolerances
+  // infeasibility certificates on delta_y / delta_x
+  double mi[4] = {0.0, 0.0, 0.0, 0.0};   // norm_dy, norm_dx, |Dinv A'dy|, |Dinv P dx|
+  double si[2] = {0.0, 0.0};             // ineq_lhs, q'dx
+  for (int e = tid; e < n * BT; e += nthr) {
+    const double d = p.dx[e];
+    xs[e] = d;
+    mi[1] = fmax(mi[1], unscale ? fabs(p.Dsc[e] * d) : fabs(d));
+    si[1] += p.q[e] * d;
+  }
+  for (int e = tid; e < m * BT; e += nthr) {
+    double d = p.dy[e];
+    const double lo = p.l[e], up = p.u[e];
+    if (up > MI_INFTY * MI_MIN_SCALING) {
+      if (lo < -MI_INFTY * MI_MIN_SCALING) d = 0.0; else d = fmin(d, 0.0);
+    } else if (lo < -MI_INFTY * MI_MIN_SCALING) d = fmax(d, 0.0);
+    xs[(size_t)n * BT + e] = d;
+    mi[0] = fmax(mi[0], unscale ? fabs(p.Esc[e] * d) : fabs(d));
+    si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
+  }
+  __syncthreads();
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
+  __syncthreads();
+  for (int e = tid; e < n * BT; e += nthr) {
+    const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
+    const double di = unscale ? p.Dsc_inv[e] : 1.0;
+    mi[2] = fmax(mi[2], fabs(di * atdy));
+    mi[3] = fmax(mi[3], fabs(di * pdx));
+  }
+  block_reduce<BT, 4, true>(mi, red, tid, wave, nw, lane);
+  block_reduce<BT, 2, false>(si, red, tid, wave, nw, lane);
+  const double norm_dy = mi[0], norm_dx = mi[1];
+  const double cost_scaling = unscale ? c : 1.0;
+
+  // tolerance-dependent decision; approx = 10x tolerances (max_iter path)
+  auto decide = [&](bool approx) -> int {
+    const double f = approx ? 10.0 : 1.0;
+    const double eps_abs = f * a.eps_abs, eps_rel = f * a.eps_rel;
+    const double eps_pinf = f * a.eps_prim_inf, eps_dinf = f * a.eps_dual_inf;
+    // rows of A dx outside the recession cone (needs its own reduction)
+    double viol[1] = {0.0};
+    for (int e = tid; e < m * BT; e += nthr) {
+      double adx = p.out2[(size_t)2 * n * BT + e];
+      if (unscale) adx *= p.Esc_inv[e];
+      const double lo = p.l[e], up = p.u[e];
+      if ((up < MI_INFTY * MI_MIN_SCALING && adx > eps_dinf * norm_dx) ||
+          (lo > -MI_INFTY * MI_MIN_SCALING && adx < -eps_dinf * norm_dx)) viol[0] = 1.0;
+    }
+    block_reduce<BT, 1, true>(viol, red, tid, wave, nw, lane);
+    if (pri_res > MI_INFTY || dua_res > MI_INFTY) return -7;   // non-convex / diverged
+    int prim_ok = 0, dual_ok = 0, prim_inf = 0, dual_inf = 0;
+    if (m == 0) prim_ok = 1;
+    else {
+      const double eps_prim = eps_abs + eps_rel * pri_nrm;
+      if (pri_res < eps_prim) prim_ok = 1;
+      else if (norm_dy > MI_DIV_TOL && si[0] < -eps_pinf * norm_dy) prim_inf = mi[2] < eps_pinf * norm_dy;
+    }
+    const double eps_dual = eps_abs + eps_rel * dua_nrm;
+    if (dua_res < eps_dual) dual_ok = 1;
+    else if (norm_dx > MI_DIV_TOL && si[1] < -cost_scaling * eps_dinf * norm_dx &&
+             mi[3] < cost_scaling * eps_dinf * norm_dx) dual_inf = viol[0] == 0.0;
+    if (prim_ok && dual_ok) return approx ? 2 : 1;
+    if (prim_inf) return approx ? 3 : -3;
+    if (dual_inf) return approx ? 4 : -4;
+    return 0;
+  };
+
+  int new_status = 0;
+  if (is_check || is_last) new_status = decide(false);
+  double rho_est = p.dscal[DS_RHO_EST * BT + b];
+  // ---- E13: rho estimate from the SCALED residual norms
+  auto rho_estimate = [&]() -> double {
+    const double pr = mx[8] / (fmax(mx[10], mx[11]) + MI_DIV_TOL);
+    const double du = mx[0] / (fmax(fmax(mx[2], mx[3]), mx[4]) + MI_DIV_TOL);
+    double e = rho * sqrt(pr / du);
+    return fmin(fmax(e, MI_RHO_MIN), MI_RHO_MAX);
+  };
+  if (!done && new_status == 0 && is_rho) {
+    const double rn = rho_estimate();
+    rho_est = rn;
+    if (rn > rho * a.rho_tolerance || rn < rho / a.rho_tolerance) {
+      need_refactor = 1;
+      rho = fmin(fmax(rn, MI_RHO_MIN), MI_RHO_MAX);
+      rho_updates++;
+    }
+  }
+  if (!done && new_status == 0 && is_last) {
+    new_status = decide(true);
+    if (new_status == 0) new_status = -2;   // max iterations reached
+  } else if (is_last) {
+    decide(true);   // keep barriers uniform across the workgroup
+  }
+  if (!done && new_status != 0) {
+    // ---- E14: store_solution
+    done = 1; status = new_status;
+    if (!need_refactor) rho_est = rho_estimate();
+    if (tid < BT) {
+      p.dscal[DS_PRI_RES * BT + b] = pri_res; p.dscal[DS_DUA_RES * BT + b] = dua_res;
+      p.dscal[DS_OBJ * BT + b] = (status == -3 || status == 3) ? MI_INFTY
+                                 : (status == -4 || status == 4) ? -MI_INFTY
+                                 : (status == -7) ? __builtin_nan("") : obj;
+      p.iscal[IS_ITER * BT + b] = iter;
+    }
+  }
+  if (tid < BT) p.dscal[DS_RHO_EST * BT + b] = rho_est;
+  // outputs for QPs that finished in this pass (done is uniform per class b)
+  const int just_done = done && (p.iscal[IS_DONE * BT + b] == 0);
+  __syncthreads();
+  if (just_done && qp >= 0) {
+    const bool has_sol = !(status == -3 || status == 3 || status == -4 || status == 4 || status == -7);
+    const double nanv = __builtin_nan("");
+    for (int e = tid; e < n * BT; e += nthr) {
+      const int i = e / BT;
+      a.x_out[(size_t)qp * n + i] = has_sol ? (a.scaling ? p.Dsc[e] * p.x[e] : p.x[e]) : nanv;
+      if (!has_sol) p.x[e] = 0.0;
+    }
+    for (int e = tid; e < m * BT; e += nthr) {
+      const int j = e / BT;
+      a.y_out[(size_t)qp * m + j] = has_sol ? (a.scaling ? p.Esc[e] * p.y[e] * cinv : p.y[e]) : nanv;
+      if (!has_sol) { p.y[e] = 0.0; p.z[e] = 0.0; }
+    }
+  }
+  __syncthreads();
+  if (tid < BT) {
+    p.iscal[IS_DONE * BT + b] = done; p.iscal[IS_STATUS * BT + b] = status;
+    p.iscal[IS_RHO_UPDATES * BT + b] = rho_updates;
+    p.iscal[IS_NEED_REFACTOR * BT + b] = need_refactor;
+    p.dscal[DS_RHO * BT + b] = rho;
+  }
+
 }
 
 // ---------------------------------------------------------- standalone ops
@@ -944,7 +952,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     }
   }
   __syncthreads();
-  int npos = 0;
+  int npos = 0, bad_inertia = 0;
   double *dnew = a.dinv_scratch + (size_t)tile * N * BT;
   for (int L = 0; L < a.n_levels; L++) {
     const uint32_t *lv = a.lvl + 6 * L;
@@ -967,6 +975,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     if (npos) atomicAdd(&s_npos[b], npos);
     __syncthreads();
     if (tid < BT) a.npos[(size_t)tile * BT + b] = s_npos[b];
+    if (tid < BT && flag && s_npos[b] != a.n && !a.debug_skip) bad_inertia = 1;
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag && !(a.debug_skip & 16)) {
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
   }
   __syncthreads();
-  if (tid < BT) iscal[IS_NEED_REFACTOR * BT + b] = 0;
+  if (tid < BT) iscal[IS_NEED_REFACTOR * BT + b] = bad_inertia ? -1 : 0;   // -1: the new factor has the wrong inertia
 }
 
 template <int BT>
@@ -1029,6 +1038,47 @@ __global__ void scatter_kernel(const double *__restrict__ src, double *dst, cons
   const size_t tile_doubles = (size_t)sd.phys_steps * 64 * BT;
   dst[(size_t)(q / BT) * tile_doubles + phys_index(sd, s, q % BT, BT)] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
 }
+// Compaction support: exchange the complete per-QP contents of slot pairs (slot =
+// tile*BT + b).  Plain arrays are [tile][len][BT]; scheduled value arrays use the
+// physical layout of phys_index (block-task region interleaved differently).
+__global__ void swap_plain_kernel(double *base, const int2 *pairs, int npairs, int len, int BT) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)npairs * len) return;
+  const int2 pr = pairs[g / len];
+  const int i = (int)(g % len);
+  double *pa = base + ((size_t)(pr.x / BT) * len + i) * BT + pr.x % BT;
+  double *pb = base + ((size_t)(pr.y / BT) * len + i) * BT + pr.y % BT;
+  const double t = *pa; *pa = *pb; *pb = t;
+}
+__global__ void swap_int_kernel(int *base, const int2 *pairs, int npairs, int len, int BT) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)npairs * len) return;
+  const int2 pr = pairs[g / len];
+  const int i = (int)(g % len);
+  int *pa = base + ((size_t)(pr.x / BT) * len + i) * BT + pr.x % BT;
+  int *pb = base + ((size_t)(pr.y / BT) * len + i) * BT + pr.y % BT;
+  const int t = *pa; *pa = *pb; *pb = t;
+}
+__global__ void swap_sched_kernel(double *base, const int2 *pairs, int npairs, SchedDev sd, int BT) {
+  // per-QP element index u: A region u = slot (n_steps*64 of them); block region: (step, i, c)
+  const size_t nA = (size_t)sd.n_steps * 64, nB = (size_t)(sd.phys_steps - sd.n_steps) * MI_CHUNK * BT;
+  const size_t per = nA + nB;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)npairs * per) return;
+  const int2 pr = pairs[g / per];
+  const size_t u = g % per;
+  const size_t tile_doubles = (size_t)sd.phys_steps * 64 * BT;
+  size_t ea, eb;
+  if (u < nA) { ea = u * BT + pr.x % BT; eb = u * BT + pr.y % BT; }
+  else {
+    const size_t r = u - nA, step = sd.n_steps + r / (MI_CHUNK * BT), rem = r % (MI_CHUNK * BT), i = rem / BT, c = rem % BT;
+    ea = ((step * 64) + i * BT + pr.x % BT) * BT + c; eb = ((step * 64) + i * BT + pr.y % BT) * BT + c;
+  }
+  double *pa = base + (size_t)(pr.x / BT) * tile_doubles + ea;
+  double *pb = base + (size_t)(pr.y / BT) * tile_doubles + eb;
+  const double t = *pa; *pa = *pb; *pb = t;
+}
+
 // dst[q][i] = src[tile][i][b]
 __global__ void deinterleave_kernel(const double *__restrict__ src, double *dst, int nq, int len, int BT) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1082,8 +1132,11 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
     return go(&KERNEL<4, 512>);                                                                    \
   } while (0)
 
-hipError_t launch_admm(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
-  MI_DISPATCH(admm_kernel, a);
+hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
+  MI_DISPATCH(iterate_kernel, a);
+}
+hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
+  MI_DISPATCH(check_kernel, a);
 }
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                        const double *x, const double *y, double *Px, double *Aty, double *Ax) {
@@ -1108,6 +1161,22 @@ hipError_t launch_scatter(const double *src, double *dst, const int *map, const 
                           const SchedDev &sd, int BT, hipStream_t st) {
   if (!nq || !sd.n_slots) return hipSuccess;
   hipLaunchKernelGGL(scatter_kernel, dim3(nblk((size_t)nq * sd.n_slots, 256)), dim3(256), 0, st, src, dst, map, ids, nq, srclen, sd, BT);
+  return hipGetLastError();
+}
+hipError_t launch_swap_plain(double *base, const int2 *pairs, int npairs, int len, int BT, hipStream_t st) {
+  if (!npairs || !len) return hipSuccess;
+  hipLaunchKernelGGL(swap_plain_kernel, dim3(nblk((size_t)npairs * len, 256)), dim3(256), 0, st, base, pairs, npairs, len, BT);
+  return hipGetLastError();
+}
+hipError_t launch_swap_int(int *base, const int2 *pairs, int npairs, int len, int BT, hipStream_t st) {
+  if (!npairs || !len) return hipSuccess;
+  hipLaunchKernelGGL(swap_int_kernel, dim3(nblk((size_t)npairs * len, 256)), dim3(256), 0, st, base, pairs, npairs, len, BT);
+  return hipGetLastError();
+}
+hipError_t launch_swap_sched(double *base, const int2 *pairs, int npairs, const SchedDev &sd, int BT, hipStream_t st) {
+  if (!npairs) return hipSuccess;
+  const size_t per = (size_t)sd.n_steps * 64 + (size_t)(sd.phys_steps - sd.n_steps) * MI_CHUNK * BT;
+  hipLaunchKernelGGL(swap_sched_kernel, dim3(nblk((size_t)npairs * per, 256)), dim3(256), 0, st, base, pairs, npairs, sd, BT);
   return hipGetLastError();
 }
 hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st) {

@@ -126,7 +126,8 @@ struct mi_osqp_batch {
   DevBuf<double> fwd_val, bwd_val, chk_val, dinv, x, z, y, q, l, u, rho_vec, rho_inv, Dsc, Dsc_inv, Esc, Esc_inv;
   DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out;
   DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
-  DevBuf<int> iscal, tile_iter, flag, npos;
+  DevBuf<int> iscal, qp_of_slot, flag, npos;
+  DevBuf<int2> pairs;
   // device refactorisation (BlockFactor tables + scratch)
   DevBuf<uint32_t> bf_blk, bf_lvl, bf_utask, bf_tri, bf_dtask, bf_ttask, bf_asm_dst, bf_asm_src;
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
@@ -140,8 +141,8 @@ struct mi_osqp_batch {
   mi_osqp_stats stats{};
   // last-solve accounting
   int64_t last_total_iters = 0, last_launches = 0, last_refactors = 0;
-  double last_device_s = 0.0, last_refactor_s = 0.0, kernel_ms_sum = 0.0;
-  int64_t kernel_launches = 0;
+  double last_device_s = 0.0, last_refactor_s = 0.0, last_compact_s = 0.0, kernel_ms_sum = 0.0;
+  int64_t kernel_launches = 0, kernel_qp_iters = 0;
   bool solved_once = false;
   ~mi_osqp_batch() {
     if (h_iscal) (void)hipHostFree(h_iscal);
@@ -182,14 +183,14 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.x = h->x.p; a.z = h->z.p; a.y = h->y.p; a.q = h->q.p; a.l = h->l.p; a.u = h->u.p;
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Dsc = h->Dsc.p; a.Dsc_inv = h->Dsc_inv.p;
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
-  a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.tile_iter = h->tile_iter.p;
+  a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
   const Settings &s = h->st;
   a.sigma = s.sigma; a.alpha = s.alpha; a.eps_abs = s.eps_abs; a.eps_rel = s.eps_rel;
   a.eps_prim_inf = s.eps_prim_inf; a.eps_dual_inf = s.eps_dual_inf; a.rho_tolerance = s.adaptive_rho_tolerance;
   a.check_termination = (int)s.check_termination; a.rho_interval = (int)s.adaptive_rho_interval;
   a.max_iter = (int)s.max_iter; a.scaled_termination = (int)s.scaled_termination; a.scaling = s.scaling ? 1 : 0;
-  a.adaptive_rho = (int)s.adaptive_rho; a.iter_budget = (int)s.max_iter;
+  a.adaptive_rho = (int)s.adaptive_rho; a.iter_begin = 0; a.iter_end = 0; a.info_at_end = 1;
   for (int k = 0; k < 4; k++) a.chk_lvl[k] = h->an.chk.level_first_phase[k];
   return a;
 }
@@ -376,7 +377,6 @@ static int reset_solve_state(mi_osqp_batch *h, bool cold) {
       p[IS_DONE * h->BT + b] = (t * h->BT + b >= h->B) ? 1 : 0;
     }
   HIPCHK(hipMemcpyAsync(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  if ((rc = h->tile_iter.zero(h->stream))) return rc;
   if (cold) { if ((rc = h->x.zero(h->stream)) || (rc = h->z.zero(h->stream)) || (rc = h->y.zero(h->stream))) return rc; }
   return 0;
 }
@@ -401,7 +401,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     return MI_OSQP_ERR_ALLOC;
   }
   // ---- tile shape (needed by the schedule layout)
-  int BT = B >= 768 ? 4 : (B >= 384 ? 2 : 1);
+  // 2 QPs per tile: iterate_kernel<2> needs 112 VGPRs, so two 512-thread workgroups share a CU and
+  // cover each other's barrier stalls; measured best on the 1024-QP headline batch (4 and 1 are slower)
+  int BT = B >= 384 ? 2 : 1;
   {
     const char *et = getenv("MI_OSQP_TILE");
     if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
@@ -436,7 +438,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
 #undef ALLOC
-  if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->tile_iter.alloc(h->ntiles)) || (rc = h->flag.alloc(4))) return rc;
+  if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
   {
     const BlockFactor &bf = an.bf;
     if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_utask.upload(bf.utask)) ||
@@ -526,6 +528,32 @@ static int refactor_flagged(mi_osqp_batch *h, const std::vector<int> &ids) {
   return 0;
 }
 
+// exchange the complete device state of slot pairs (slot = tile*BT + b)
+static int apply_swaps(mi_osqp_batch *h, const std::vector<int2> &pairs) {
+  if (pairs.empty()) return 0;
+  const Analysis &an = h->an;
+  int np = (int)pairs.size(), BT = h->BT, n = an.n, m = an.m, rc;
+  if (h->pairs.n < pairs.size() && (rc = h->pairs.alloc(std::max<size_t>(pairs.size(), (size_t)h->ntiles * BT)))) return rc;
+  HIPCHK(hipMemcpyAsync(h->pairs.p, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+  hipStream_t st = h->stream;
+  HIPCHK(launch_swap_sched(h->fwd_val.p, h->pairs.p, np, h->fwd.view(an.fwd), BT, st));
+  HIPCHK(launch_swap_sched(h->bwd_val.p, h->pairs.p, np, h->bwd.view(an.bwd), BT, st));
+  HIPCHK(launch_swap_sched(h->chk_val.p, h->pairs.p, np, h->chk.view(an.chk), BT, st));
+  struct PL { double *p; int len; };
+  const PL plain[] = {{h->dinv.p, an.N}, {h->x.p, n}, {h->z.p, m}, {h->y.p, m}, {h->q.p, n}, {h->l.p, m}, {h->u.p, m},
+                      {h->rho_vec.p, m}, {h->rho_inv.p, m}, {h->Dsc.p, n}, {h->Dsc_inv.p, n}, {h->Esc.p, m}, {h->Esc_inv.p, m},
+                      {h->pa_val.p, an.Pp[n] + an.Ap[n]}, {h->dscal.p, DS_COUNT}};
+  for (const PL &a : plain) HIPCHK(launch_swap_plain(a.p, h->pairs.p, np, a.len, BT, st));
+  HIPCHK(launch_swap_int(h->iscal.p, h->pairs.p, np, IS_COUNT, BT, st));
+  return 0;
+}
+
+// The ADMM loop runs in segments that end at every termination-check / rho-update
+// point: iterate_kernel (E6-E10) -> check_kernel (E11-E14) -> host reads the flags,
+// compacts the QPs still iterating into the leading tiles (slot swaps on the device),
+// runs the device refactorisation for the QPs whose rho changed, and continues with a
+// smaller grid.  The swaps are undone at the end, so outside a solve every array is in
+// the identity layout.
 static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream) {
   hipStream_t keep = h->stream;
   struct Restore { mi_osqp_batch *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, keep};
@@ -535,50 +563,85 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
   KernelArgs a = make_args(h);
   if (d_x_out) a.x_out = d_x_out;
   h->last_total_iters = h->last_launches = h->last_refactors = 0;
-  h->last_device_s = h->last_refactor_s = 0.0;
-  size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
-  const int BT = h->BT;
-  for (int guard = 0; guard < 100000; guard++) {
+  h->last_device_s = h->last_refactor_s = h->last_compact_s = 0.0;
+  const int BT = h->BT, nslots = h->ntiles * BT;
+  const Settings &S = h->st;
+  std::vector<int> qp_of_slot(nslots);
+  for (int s = 0; s < nslots; s++) qp_of_slot[s] = s < h->B ? s : -1;
+  HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, qp_of_slot.data(), nslots * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<std::vector<int2>> rounds;
+  // compaction is implemented and tested but OFF by default: a CU ingests ~18 GB/s whatever the number of
+  // active tiles, so packing the survivors into fewer tiles does not shorten a segment (profiles/r01/README.md)
+  const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr;
+  int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
+  while (true) {
+    int seg_end = (int)S.max_iter;
+    if (S.check_termination > 0) seg_end = std::min<int64_t>(seg_end, (iter / S.check_termination + 1) * S.check_termination);
+    if (S.adaptive_rho && S.adaptive_rho_interval > 0)
+      seg_end = std::min<int64_t>(seg_end, (iter / S.adaptive_rho_interval + 1) * S.adaptive_rho_interval);
+    a.iter_begin = iter; a.iter_end = seg_end; a.info_at_end = 1;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(launch_admm(a, BT, h->ntiles, h->threads, h->lds, h->stream));
+    HIPCHK(launch_iterate(a, BT, ntl, h->threads, h->lds, h->stream));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(launch_check(a, BT, ntl, h->threads, h->lds, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
-    bool all_done = true;
-    std::vector<int> ref;
-    for (int qi = 0; qi < h->B; qi++) {
-      const int *t = h->h_iscal + (size_t)(qi / BT) * IS_COUNT * BT;
-      if (!t[IS_DONE * BT + qi % BT]) all_done = false;
-      if (t[IS_NEED_REFACTOR * BT + qi % BT]) ref.push_back(qi);
+    h->kernel_qp_iters += 0;
+    iter = seg_end;
+    // slots still iterating / asking for a refactorisation
+    std::vector<int> active;
+    int n_ref = 0;
+    for (int s = 0; s < ntl * BT; s++) {
+      const int *t = h->h_iscal + (size_t)(s / BT) * IS_COUNT * BT;
+      if (qp_of_slot[s] >= 0 && !t[IS_DONE * BT + s % BT]) { active.push_back(s); if (t[IS_NEED_REFACTOR * BT + s % BT]) n_ref++; }
     }
-    if (!ref.empty() && !h->host_refactor) {
-      // row E13 on the device: rho vector, KKT assembly, block LDL', scatter into the schedules
+    if (active.empty()) break;
+    // ---- compaction
+    int target = ((int)active.size() + BT - 1) / BT;
+    if (!no_compact && target < ntl) {
+      double tc = now_s();
+      std::vector<char> is_active(ntl * BT, 0);
+      for (int s : active) is_active[s] = 1;
+      std::vector<int2> pairs;
+      int hole = 0;
+      for (int k = (int)active.size() - 1; k >= 0 && active[k] >= target * BT; k--) {
+        while (hole < target * BT && is_active[hole]) hole++;
+        pairs.push_back(int2{hole, active[k]});
+        std::swap(qp_of_slot[hole], qp_of_slot[active[k]]);
+        is_active[hole] = 1;
+      }
+      if ((rc = apply_swaps(h, pairs))) return rc;
+      HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, qp_of_slot.data(), nslots * sizeof(int), hipMemcpyHostToDevice, h->stream));
+      rounds.push_back(std::move(pairs));
+      ntl = target;
+      h->last_compact_s += now_s() - tc;
+    }
+    // ---- row E13 on the device: rho vector, KKT assembly, block LDL', scatter into the schedules
+    if (n_ref) {
       double tr = now_s();
       FactorArgs fa = make_factor_args(h, 0);
-      HIPCHK(launch_factor(fa, BT, h->ntiles, h->threads, h->stream));
-      HIPCHK(hipMemcpyAsync(h->h_npos, h->npos.p, (size_t)h->ntiles * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(launch_factor(fa, BT, ntl, h->threads, h->stream));
+      HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
-      for (int qi : ref) if (h->h_npos[qi] != h->an.n) { g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX; }
+      for (int s = 0; s < ntl * BT; s++)
+        if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
+          g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX;
+        }
       h->host_rho_stale = true;
-      h->last_refactors += (int64_t)ref.size();
-      h->last_refactor_s += now_s() - tr;
-    } else if (!ref.empty()) {
-      double tr = now_s();
-      HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
-      for (int qi : ref) {
-        double rho_new = h->h_dscal[(size_t)(qi / BT) * DS_COUNT * BT + DS_RHO * BT + qi % BT];
-        apply_rho(h->an, h->qp[qi], rho_new);
-        h->h_iscal[(size_t)(qi / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + qi % BT] = 0;
-      }
-      if ((rc = refactor_flagged(h, ref))) return rc;
-      HIPCHK(hipMemcpy(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice));
-      h->last_refactors += (int64_t)ref.size();
+      h->last_refactors += n_ref;
       h->last_refactor_s += now_s() - tr;
     }
-    if (all_done) break;
+  }
+  // ---- undo the compaction (reverse order; swaps are involutions)
+  {
+    double tc = now_s();
+    for (int r = (int)rounds.size() - 1; r >= 0; r--) if ((rc = apply_swaps(h, rounds[r]))) return rc;
+    HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)nslots * IS_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->last_compact_s += now_s() - tc;
   }
   for (int qi = 0; qi < h->B; qi++)
     h->last_total_iters += h->h_iscal[(size_t)(qi / BT) * IS_COUNT * BT + IS_ITER * BT + qi % BT];
@@ -699,7 +762,8 @@ int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st) {
 }
 
 int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64_t *kernel_launches, double *device_seconds,
-                                   double *refactor_seconds, int64_t *refactor_count) {
+                                   double *refactor_seconds, int64_t *refactor_count, double *compact_seconds) {
+  if (h && compact_seconds) *compact_seconds = h->last_compact_s;
   if (!h) return MI_OSQP_ERR_NULL;
   if (total_iters) *total_iters = h->last_total_iters;
   if (kernel_launches) *kernel_launches = h->last_launches;
@@ -837,9 +901,10 @@ int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
   FactorArgs fa = make_factor_args(h, 1);
   HIPCHK(launch_factor(fa, h->BT, h->ntiles, h->threads, h->stream));
-  HIPCHK(hipMemcpyAsync(h->h_npos, h->npos.p, (size_t)h->ntiles * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (!getenv("MI_OSQP_FACTOR_SKIP")) for (int q = 0; q < h->B; q++) if (h->h_npos[q] != h->an.n) return MI_OSQP_ERR_NONCONVEX;
+  for (int q = 0; q < h->B; q++)
+    if (h->h_iscal[(size_t)(q / h->BT) * IS_COUNT * h->BT + IS_NEED_REFACTOR * h->BT + q % h->BT] < 0) return MI_OSQP_ERR_NONCONVEX;
   return MI_OSQP_OK;
 }
 

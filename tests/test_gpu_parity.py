@@ -282,3 +282,25 @@ def test_device_refactor_matches_host_factor(tile, monkeypatch):
         # and a solve after the device refactor still matches the oracle
         info = s.solve()
         _compare(info, s.primal(), _oracle_batch(pr, range(B)), range(B))
+
+
+def test_compaction_path_gives_identical_results(monkeypatch):
+    """MI_OSQP_COMPACT=1 packs the QPs still iterating into the leading tiles between
+    segments (slot swaps on the device, undone afterwards): results must be bitwise
+    identical to the plain path, and a following solve must still work."""
+    pr = PR.random_box_qp(24, n=96, mg=64, nnz_per_row=6)
+    def run():
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+        i1 = s.solve(); x1 = s.primal().copy(); y1 = s.dual().copy()
+        s.update_bounds(pr["l"] * 0.9, pr["u"] * 0.9)
+        i2 = s.solve(); x2 = s.primal().copy()
+        return [i.iter for i in i1], x1, y1, [i.iter for i in i2], x2, s.last_solve_stats()
+    a = run()
+    monkeypatch.setenv("MI_OSQP_COMPACT", "1")
+    monkeypatch.setenv("MI_OSQP_TILE", "4")
+    b = run()
+    monkeypatch.delenv("MI_OSQP_COMPACT")
+    c = run()
+    assert b[0] == c[0] and b[3] == c[3]
+    np.testing.assert_array_equal(b[1], c[1]); np.testing.assert_array_equal(b[2], c[2]); np.testing.assert_array_equal(b[4], c[4])
+    assert a[0] == b[0] and np.max(np.abs(a[1] - b[1])) <= 1e-9      # tile 2 vs tile 4: same algorithm, round-off only
