@@ -435,43 +435,68 @@ static void build_block_factor(Analysis &an) {
   bf.n_levels = nlev;
   std::vector<std::vector<int>> cols_of_level(nlev);
   for (int c = 0; c < nch; c++) cols_of_level[an.chunk_lev[c]].push_back(c);
-  for (int L = 0; L < nlev; L++) {
-    uint32_t u0 = (uint32_t)(bf.utask.size() / 4), d0 = (uint32_t)bf.dtask.size(), t0 = (uint32_t)(bf.ttask.size() / 2);
-    struct UT { uint32_t id, tb, tm, te; };
-    std::vector<UT> uts;
-    auto width_of = [&](uint32_t bid) { return bf.blk[4 * bid + 3] & 255u; };
+  // Update tasks.  A target block (I,J) gets two of them: its rank-1 sources (one-column
+  // chunks) are applied EAGERLY, at the first level after the last such source is final
+  // (many targets at once: wide, well balanced), its general sources at level(J).
+  struct UT { uint32_t id, tb, tm, te; };
+  std::vector<std::vector<UT>> ut_of_level(nlev);
+  auto width_of = [&](uint32_t bid) { return bf.blk[4 * bid + 3] & 255u; };
+  auto colchunk_level = [&](uint32_t bid) {            // level of the column chunk of a block
+    int c0 = (int)bf.blk[4 * bid + 2];
+    return an.chunk_lev[chunk_of[c0]];
+  };
+  for (int L = 0; L < nlev; L++)
     for (int J : cols_of_level[L]) {
       const auto &rj = rowlist[J];
       for (const auto &[I, id] : colblk[J]) {
-        uint32_t tb = (uint32_t)(bf.tri.size() / 2);
+        std::vector<std::pair<uint32_t, uint32_t>> tl;
         if (I == J) {
-          for (const auto &[K, bid] : rj) bf.tri.insert(bf.tri.end(), {bid, bid});
+          for (const auto &[K, bid] : rj) tl.push_back({bid, bid});
         } else {
           const auto &ri = rowlist[I];
           size_t a = 0, b = 0;
           while (a < ri.size() && b < rj.size()) {
             if (ri[a].first < rj[b].first) a++;
             else if (ri[a].first > rj[b].first) b++;
-            else { bf.tri.insert(bf.tri.end(), {ri[a].second, rj[b].second}); a++; b++; }
+            else { tl.push_back({ri[a].second, rj[b].second}); a++; b++; }
           }
         }
-        uint32_t te = (uint32_t)(bf.tri.size() / 2);
-        // rank-1 sources first (the device batches them 8 at a time)
-        std::vector<std::pair<uint32_t, uint32_t>> tl;
-        for (uint32_t q = tb; q < te; q++) tl.push_back({bf.tri[2 * q], bf.tri[2 * q + 1]});
         std::stable_partition(tl.begin(), tl.end(), [&](const std::pair<uint32_t, uint32_t> &t) { return width_of(t.first) == 1; });
-        uint32_t tm = tb;
-        for (uint32_t q = tb; q < te; q++) {
-          bf.tri[2 * q] = tl[q - tb].first; bf.tri[2 * q + 1] = tl[q - tb].second;
-          if (width_of(tl[q - tb].first) == 1) tm = q + 1;
+        size_t n1 = 0;
+        int lev1 = 0;
+        while (n1 < tl.size() && width_of(tl[n1].first) == 1) { lev1 = std::max(lev1, colchunk_level(tl[n1].first) + 1); n1++; }
+        if (n1 && (lev1 >= L || n1 == tl.size()) ) {
+          // no earlier level available (or nothing else to do): ONE task, so that never two waves touch a block
+          uint32_t tb = (uint32_t)(bf.tri.size() / 2);
+          for (size_t q = 0; q < tl.size(); q++) bf.tri.insert(bf.tri.end(), {tl[q].first, tl[q].second});
+          uint32_t te = (uint32_t)(bf.tri.size() / 2);
+          ut_of_level[std::min(lev1, L)].push_back({id, tb, tb + (uint32_t)n1, te});
+          continue;
         }
-        if (te > tb) uts.push_back({id, tb, tm, te});
+        if (n1) {
+          uint32_t tb = (uint32_t)(bf.tri.size() / 2);
+          for (size_t q = 0; q < n1; q++) bf.tri.insert(bf.tri.end(), {tl[q].first, tl[q].second});
+          uint32_t te = (uint32_t)(bf.tri.size() / 2);
+          ut_of_level[lev1].push_back({id, tb, te, te});
+        }
+        if (n1 < tl.size()) {
+          uint32_t tb = (uint32_t)(bf.tri.size() / 2);
+          for (size_t q = n1; q < tl.size(); q++) bf.tri.insert(bf.tri.end(), {tl[q].first, tl[q].second});
+          uint32_t te = (uint32_t)(bf.tri.size() / 2);
+          ut_of_level[L].push_back({id, tb, tb, te});
+        }
+      }
+    }
+  for (int L = 0; L < nlev; L++) {
+    uint32_t u0 = (uint32_t)(bf.utask.size() / 4), d0 = (uint32_t)bf.dtask.size(), t0 = (uint32_t)(bf.ttask.size() / 2);
+    auto &uts = ut_of_level[L];
+    std::stable_sort(uts.begin(), uts.end(), [](const UT &a, const UT &b) { return a.te - a.tb > b.te - b.tb; });
+    for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.tm, u.te});
+    for (int J : cols_of_level[L])
+      for (const auto &[I, id] : colblk[J]) {
         if (I == J) bf.dtask.push_back(id);
         else bf.ttask.insert(bf.ttask.end(), {id, colblk[J][0].second});
       }
-    }
-    std::stable_sort(uts.begin(), uts.end(), [](const UT &a, const UT &b) { return a.te - a.tb > b.te - b.tb; });
-    for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.tm, u.te});
     bf.lvl.insert(bf.lvl.end(), {u0, (uint32_t)(bf.utask.size() / 4), d0, (uint32_t)bf.dtask.size(), t0, (uint32_t)(bf.ttask.size() / 2)});
   }
   // assembly map: natural KKT entry -> (storage position, value source)

@@ -623,7 +623,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     if (n_ref) {
       double tr = now_s();
       FactorArgs fa = make_factor_args(h, 0);
-      HIPCHK(launch_factor(fa, BT, ntl, h->threads, h->stream));
+      HIPCHK(launch_factor(fa, BT, ntl, 1024, h->stream));
       HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       for (int s = 0; s < ntl * BT; s++)
@@ -900,7 +900,7 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
 int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
   FactorArgs fa = make_factor_args(h, 1);
-  HIPCHK(launch_factor(fa, h->BT, h->ntiles, h->threads, h->stream));
+  HIPCHK(launch_factor(fa, h->BT, h->ntiles, 1024, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int q = 0; q < h->B; q++)
