@@ -35,6 +35,7 @@ struct KernelArgs {
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
   int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;
   int iter_begin, iter_end;             // this launch runs iterations (iter_begin, iter_end]
+  int op_out_lds;                       // spmv op: results staged in LDS (the launcher sized it)
   int info_at_end;                      // a check_kernel follows: store delta_x / delta_y of the last iteration
   int chk_lvl[4];                       // first phase of the P x / A'y / A x levels of the check schedule (+ end)
 };

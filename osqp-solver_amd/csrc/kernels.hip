@@ -684,20 +684,28 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
                                                     double *gAty, double *gAx) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n, m = a.m;
-  const int qp = tile * BT + b;
   double *xs = smem;
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
-  for (int e = tid; e < n * BT; e += nthr) xs[e] = (qp < a.B && gx) ? gx[(size_t)qp * n + e / BT] : 0.0;
-  for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = (qp < a.B && gy) ? gy[(size_t)qp * m + e / BT] : 0.0;
+  // results go to LDS when the launcher provided room for them (op_out_lds), else to the tile's global scratch
+  double *res = a.op_out_lds ? smem + (size_t)(n + m) * BT : p.out1;
+  // coalesced QP-major I/O: consecutive threads touch consecutive elements of one QP
+  for (int bb = 0; bb < BT; bb++) {
+    const int q = tile * BT + bb;
+    const bool ok = q < a.B;
+    for (int i = tid; i < n; i += nthr) xs[(size_t)i * BT + bb] = (ok && gx) ? gx[(size_t)q * n + i] : 0.0;
+    for (int i = tid; i < m; i += nthr) xs[((size_t)n + i) * BT + bb] = (ok && gy) ? gy[(size_t)q * m + i] : 0.0;
+  }
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, res, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
   __syncthreads();
-  if (qp < a.B) {
-    if (gPx) for (int e = tid; e < n * BT; e += nthr) gPx[(size_t)qp * n + e / BT] = p.out1[e];
-    if (gAty) for (int e = tid; e < n * BT; e += nthr) gAty[(size_t)qp * n + e / BT] = p.out1[(size_t)n * BT + e];
-    if (gAx) for (int e = tid; e < m * BT; e += nthr) gAx[(size_t)qp * m + e / BT] = p.out1[(size_t)2 * n * BT + e];
+  for (int bb = 0; bb < BT; bb++) {
+    const int q = tile * BT + bb;
+    if (q >= a.B) continue;
+    if (gPx) for (int i = tid; i < n; i += nthr) gPx[(size_t)q * n + i] = res[(size_t)i * BT + bb];
+    if (gAty) for (int i = tid; i < n; i += nthr) gAty[(size_t)q * n + i] = res[((size_t)n + i) * BT + bb];
+    if (gAx) for (int i = tid; i < m; i += nthr) gAx[(size_t)q * m + i] = res[((size_t)2 * n + i) * BT + bb];
   }
 }
 
@@ -706,19 +714,20 @@ template <int BT, int NT>
 __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int N = a.N;
-  const int qp = tile * BT + b;
   double *xs = smem;
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
-  for (int e = tid; e < N * BT; e += nthr) {
-    const int i = e / BT;
-    xs[(size_t)a.pinv[i] * BT + b] = qp < a.B ? rhs[(size_t)qp * N + i] : 0.0;
+  for (int bb = 0; bb < BT; bb++) {           // coalesced QP-major I/O
+    const int q = tile * BT + bb;
+    for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
   }
   __syncthreads();
   kkt_solve_lds<BT, MI_PFV>(a, p, xs, tid, nthr, wave, nw, lane);
-  if (qp < a.B)
-    for (int e = tid; e < N * BT; e += nthr) { const int i = e / BT; sol[(size_t)qp * N + i] = xs[(size_t)a.pinv[i] * BT + b]; }
+  for (int bb = 0; bb < BT; bb++) {
+    const int q = tile * BT + bb;
+    if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
+  }
 }
 
 // warm start (row E14): x <- Dinv .* x0 ; z <- A x   (QP-major x0[B][n])

@@ -913,7 +913,10 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
   if (!h) return MI_OSQP_ERR_NULL;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
-  HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, h->lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
+  size_t lds = (size_t)(h->an.N + 2 * h->an.n + h->an.m) * h->BT * sizeof(double);
+  a.op_out_lds = lds <= 160 * 1024;
+  if (!a.op_out_lds) lds = h->lds;
+  HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
   HIPCHK(hipStreamSynchronize(s));
   return MI_OSQP_OK;
 }

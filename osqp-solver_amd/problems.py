@@ -77,6 +77,40 @@ def random_box_qp(B, n=512, mg=512, nnz_per_row=8, half_bw=4, pattern_seed=1234,
     return dict(n=n, m=m, P=P_pat, A=A_pat, Px=Px, Ax=Ax, q=q, l=l, u=u)
 
 
+def grid_qp(g, seed=7):
+    """Config-5 style structured sparse QP at a size that fits the LDS-resident solver:
+    variables on a g x g grid, P = 5-point Laplacian + I (strictly convex),
+    A = [I ; Dx ; Dy] (boxes on the variables and on their first differences),
+    so n = g^2, m = n + 2 g (g - 1).  The KKT factor has the deep, nested-dissection-like
+    elimination tree of a 2-D mesh.  Returns a batch dict with B = 1."""
+    r = np.random.default_rng(seed)
+    n = g * g
+    idx = np.arange(n).reshape(g, g)
+    rows, cols, vals = [], [], []
+    def add(i, j, v):
+        rows.append(i); cols.append(j); vals.append(v)
+    for a in range(g):
+        for b in range(g):
+            add(idx[a, b], idx[a, b], 5.0)
+            if a + 1 < g: add(min(idx[a, b], idx[a + 1, b]), max(idx[a, b], idx[a + 1, b]), -1.0)
+            if b + 1 < g: add(min(idx[a, b], idx[a, b + 1]), max(idx[a, b], idx[a, b + 1]), -1.0)
+    P = sp.csc_matrix((vals, (rows, cols)), shape=(n, n)); P.sort_indices()
+    ar, ac, av = list(range(n)), list(range(n)), [1.0] * n
+    k = n
+    for a in range(g):
+        for b in range(g - 1):
+            ar += [k, k]; ac += [idx[a, b + 1], idx[a, b]]; av += [1.0, -1.0]; k += 1
+    for a in range(g - 1):
+        for b in range(g):
+            ar += [k, k]; ac += [idx[a + 1, b], idx[a, b]]; av += [1.0, -1.0]; k += 1
+    m = k
+    A = sp.csc_matrix((av, (ar, ac)), shape=(m, n)); A.sort_indices()
+    q = r.standard_normal(n) * 3.0
+    l = np.concatenate([-r.uniform(0.2, 1.0, n), -r.uniform(0.05, 0.3, m - n)])
+    u = np.concatenate([r.uniform(0.2, 1.0, n), r.uniform(0.05, 0.3, m - n)])
+    return dict(n=n, m=m, P=P, A=A, Px=P.data[None].copy(), Ax=A.data[None].copy(), q=q[None], l=l[None], u=u[None])
+
+
 def qp_matrices(prob, b):
     """scipy matrices (P upper triangle, A) of QP b of a batch dict."""
     P = prob["P"].copy(); P.data = prob["Px"][b].copy()

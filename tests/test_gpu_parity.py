@@ -304,3 +304,50 @@ def test_compaction_path_gives_identical_results(monkeypatch):
     assert b[0] == c[0] and b[3] == c[3]
     np.testing.assert_array_equal(b[1], c[1]); np.testing.assert_array_equal(b[2], c[2]); np.testing.assert_array_equal(b[4], c[4])
     assert a[0] == b[0] and np.max(np.abs(a[1] - b[1])) <= 1e-9      # tile 2 vs tile 4: same algorithm, round-off only
+
+
+def test_config4_full_size_gomp_batch():
+    """BASELINE config 4: 256 GOMP 7-DOF trajectories, 100 waypoints (n=1400, m=4872,
+    N=6272), warm-started like GOMPSolver::run; every QP optimal + sampled oracle parity."""
+    B = 256
+    pr = PR.gomp_batch(B, 7, 100)
+    s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
+    s.warm_start_x(pr["warm"])
+    info = s.solve()
+    x = s.primal()
+    assert all(i.status_val == 1 for i in info)
+    sample = [0, 1, 100, 255]
+    ref = []
+    for b in sample:
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, None, A, pr["l"][b], pr["u"][b])
+        o.set_warm_start(pr["warm"][b])
+        st, xo = o.solve()
+        ref.append((st, xo, o.info(), o))
+    _compare(info, x, ref, sample)
+    # start / goal pinned ([REF] src/gomp-solver.h:130-133): check on the returned trajectories
+    D, W = 7, 100
+    rng0 = np.random.default_rng(2000)
+    start0, end0 = rng0.uniform(-np.pi, np.pi, D), rng0.uniform(-np.pi, np.pi, D)
+    assert np.max(np.abs(x[0][:D] - start0)) < 5e-3 and np.max(np.abs(x[0][(W - 3) * D:(W - 2) * D] - end0)) < 5e-3
+
+
+def test_config5_style_structured_sparse_qp():
+    """BASELINE config 5 (single large sparse QP, deep level-set solve) at the largest size the
+    LDS-resident design takes: 64x64 grid, n=4096, m=12160, N=16256 (the literal n=1e5 needs
+    the global-memory-vector variant)."""
+    pr = PR.grid_qp(64)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    st = s.stats()
+    assert st["N"] == 16256 and st["tile"] == 1
+    info = s.solve()
+    _compare(info, s.primal(), _oracle_batch(pr, [0]), [0])
+    r = kkt_residuals(*PR.qp_matrices(pr, 0)[:1], pr["q"][0], PR.qp_matrices(pr, 0)[1], pr["l"][0], pr["u"][0], s.primal()[0], s.dual()[0])
+    assert r["prim"] < 5e-3 and r["stat"] < 5e-2
+
+
+def test_too_large_problem_is_refused_loudly():
+    pr = PR.grid_qp(100)          # N = 29 800 > LDS-resident limit
+    with pytest.raises(M.MiOsqpError) as e:
+        M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    assert e.value.code == 7
