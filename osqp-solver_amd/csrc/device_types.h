@@ -9,7 +9,7 @@ namespace miosqp {
 
 // device view of one host_core.hpp Schedule (tables are shared by all tiles)
 struct SchedDev {
-  const uint32_t *phase, *step, *idxw;
+  const uint32_t *phase, *step, *idxw, *bstep0;
   int n_phases, nw, sb;
   uint32_t n_steps, phys_steps, zero_step, n_slots;
 };

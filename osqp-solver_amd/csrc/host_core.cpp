@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -76,6 +78,124 @@ static void min_degree(int N, const std::vector<int> &Kp, const std::vector<int>
     }
     std::vector<int>().swap(adj[v]);
   }
+}
+
+// Nested dissection by BFS level structures (George-Liu style): find a pseudo-peripheral
+// node, take a middle BFS level as separator, recurse on both sides, number the separator
+// last.  On chain-/mesh-like KKT graphs (GOMP trajectories, grids) this gives an
+// elimination tree of logarithmic depth, i.e. few device phases; on expander-like graphs it
+// degenerates and minimum degree wins (analyze() picks by a cost model).
+namespace {
+struct NDCtx {
+  const std::vector<std::vector<int>> &adj;
+  std::vector<int> stamp, level;
+  int cur = 0;
+  std::vector<int> out;
+  int leaf;
+};
+
+void nd_leaf(NDCtx &c, const std::vector<int> &nodes) {
+  // minimum degree on the induced subgraph
+  int k = (int)nodes.size();
+  if (k <= 2) { for (int v : nodes) c.out.push_back(v); return; }
+  int st = ++c.cur;
+  std::vector<int> loc(k);
+  for (int i = 0; i < k; i++) { c.stamp[nodes[i]] = st; c.level[nodes[i]] = i; }
+  std::vector<int> Kp(k + 1, 0), Ki;
+  for (int j = 0; j < k; j++) {
+    for (int u : c.adj[nodes[j]]) if (c.stamp[u] == st && c.level[u] < j) Ki.push_back(c.level[u]);
+    Ki.push_back(j);
+    Kp[j + 1] = (int)Ki.size();
+  }
+  std::vector<int> perm;
+  min_degree(k, Kp, Ki, perm);
+  for (int i = 0; i < k; i++) c.out.push_back(nodes[perm[i]]);
+}
+
+void nd_rec(NDCtx &c, std::vector<int> nodes) {
+  if ((int)nodes.size() <= c.leaf) { nd_leaf(c, nodes); return; }
+  // connected components of the induced subgraph
+  int st = ++c.cur;
+  for (int v : nodes) c.stamp[v] = st;
+  {
+    int seen = ++c.cur;
+    std::vector<int> comp0, q;
+    q.push_back(nodes[0]); c.stamp[nodes[0]] = seen;
+    for (size_t h = 0; h < q.size(); h++)
+      for (int u : c.adj[q[h]]) if (c.stamp[u] == st) { c.stamp[u] = seen; q.push_back(u); }
+    if (q.size() < nodes.size()) {
+      std::vector<int> rest;
+      for (int v : nodes) if (c.stamp[v] != seen) rest.push_back(v);
+      nd_rec(c, q);
+      nd_rec(c, rest);
+      return;
+    }
+    for (int v : nodes) c.stamp[v] = st;
+  }
+  // pseudo-peripheral node + level structure
+  auto bfs = [&](int root, std::vector<std::vector<int>> &levels) {
+    int seen = ++c.cur;
+    levels.clear();
+    levels.push_back({root}); c.stamp[root] = seen; c.level[root] = 0;
+    while (true) {
+      std::vector<int> nxt;
+      for (int v : levels.back())
+        for (int u : c.adj[v]) if (c.stamp[u] == st) { c.stamp[u] = seen; c.level[u] = (int)levels.size(); nxt.push_back(u); }
+      if (nxt.empty()) break;
+      levels.push_back(std::move(nxt));
+    }
+    for (auto &lv : levels) for (int v : lv) c.stamp[v] = st;
+  };
+  std::vector<std::vector<int>> levels;
+  int root = nodes[0];
+  for (int rep = 0; rep < 4; rep++) {
+    bfs(root, levels);
+    int best = levels.back()[0];
+    for (int v : levels.back()) if (c.adj[v].size() < c.adj[best].size()) best = v;
+    if (best == root) break;
+    size_t depth = levels.size();
+    std::vector<std::vector<int>> l2;
+    bfs(best, l2);
+    if (l2.size() <= depth) { if (l2.size() == depth) { levels.swap(l2); root = best; } break; }
+    levels.swap(l2); root = best;
+  }
+  int k = (int)levels.size();
+  if (k < 4) { nd_leaf(c, nodes); return; }
+  // separator: the smallest level in the middle third (by cumulative size)
+  size_t total = nodes.size(), cum = 0;
+  int j = -1; size_t bestsz = (size_t)-1;
+  for (int i = 0; i < k; i++) {
+    if (i >= 1 && i <= k - 2 && cum >= total / 3 && cum + levels[i].size() <= total - total / 3 + levels[i].size()) {
+      if (levels[i].size() < bestsz) { bestsz = levels[i].size(); j = i; }
+    }
+    cum += levels[i].size();
+  }
+  if (j < 0) j = k / 2;
+  std::vector<int> left, right, sep;
+  for (int i = 0; i < j; i++) left.insert(left.end(), levels[i].begin(), levels[i].end());
+  for (int i = j + 1; i < k; i++) right.insert(right.end(), levels[i].begin(), levels[i].end());
+  for (int v : levels[j]) {
+    bool touches_right = false;
+    for (int u : c.adj[v]) if (c.stamp[u] == st && c.level[u] == j + 1) { touches_right = true; break; }
+    (touches_right ? sep : left).push_back(v);
+  }
+  if (left.empty() || right.empty()) { nd_leaf(c, nodes); return; }
+  nd_rec(c, std::move(left));
+  nd_rec(c, std::move(right));
+  for (int v : sep) c.out.push_back(v);
+}
+}  // namespace
+
+static void nested_dissection(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, std::vector<int> &perm) {
+  std::vector<std::vector<int>> adj(N);
+  for (int j = 0; j < N; j++)
+    for (int k = Kp[j]; k < Kp[j + 1]; k++) { int i = Ki[k]; if (i != j) { adj[i].push_back(j); adj[j].push_back(i); } }
+  for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+  NDCtx c{adj, std::vector<int>(N, 0), std::vector<int>(N, 0), 0, {}, 48};
+  std::vector<int> all(N);
+  std::iota(all.begin(), all.end(), 0);
+  nd_rec(c, all);
+  perm = c.out;
 }
 
 // lower-triangular CSC of the permuted KKT with a natural->permuted entry map
@@ -168,11 +288,20 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     sch.level_first_phase.push_back((int)phases.size());
     std::vector<Unit> units;
     std::vector<const RowWork *> longs;
-    std::vector<std::vector<const RowWork *>> byT(7);
+    // short rows (<= 64 entries): lane-group width T and step count S <= 4 chosen to minimise the
+    // padded slots T*S (ties -> fewer steps); rows with equal (T,S) are packed 64/T per unit
+    std::vector<std::vector<const RowWork *>> byTS(7 * 4);
     for (const RowWork &rw : lw.rowsA) {
       int len = std::max<int>(1, (int)rw.ent.size());
-      if (len > 64) longs.push_back(&rw);
-      else byT[ilog2(pow2ceil(len))].push_back(&rw);
+      if (len > 64) { longs.push_back(&rw); continue; }
+      int bestlt = 6, bestS = 1, bestcost = 1 << 30;
+      for (int lt = 0; lt <= 6; lt++) {
+        int T = 1 << lt, S = (len + T - 1) / T;
+        if (S > 4) continue;
+        int cost = T * S * 4 + S;          // slots first, then steps
+        if (cost < bestcost) { bestcost = cost; bestlt = lt; bestS = S; }
+      }
+      byTS[bestlt * 4 + (bestS - 1)].push_back(&rw);
     }
     std::stable_sort(longs.begin(), longs.end(),
                      [](const RowWork *a, const RowWork *b) { return a->ent.size() > b->ent.size(); });
@@ -187,16 +316,17 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       for (int st = 0; st < S; st++) u.steps.push_back({ilog2(T), st == S - 1, grp, st * T});
       units.push_back(std::move(u));
     }
-    for (int lt = 6; lt >= 0; lt--) {
-      int T = 1 << lt, per = 64 / T;
-      const auto &v = byT[lt];
-      for (size_t i = 0; i < v.size(); i += per) {
-        std::vector<const RowWork *> grp(v.begin() + i, v.begin() + std::min(v.size(), i + per));
-        Unit u;
-        u.steps.push_back({lt, true, grp, 0});
-        units.push_back(std::move(u));
+    for (int lt = 6; lt >= 0; lt--)
+      for (int S = 4; S >= 1; S--) {
+        int T = 1 << lt, per = 64 / T;
+        const auto &v = byTS[lt * 4 + (S - 1)];
+        for (size_t i = 0; i < v.size(); i += per) {
+          std::vector<const RowWork *> grp(v.begin() + i, v.begin() + std::min(v.size(), i + per));
+          Unit u;
+          for (int st = 0; st < S; st++) u.steps.push_back({lt, st == S - 1, grp, st * T});
+          units.push_back(std::move(u));
+        }
       }
-    }
     if (!units.empty()) {
       // longest-processing-time assignment of units to waves
       std::vector<size_t> order(units.size());
@@ -256,11 +386,13 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
   // logical slots / physical steps of the block tasks (after all A steps)
   sch.n_slots = sch.n_steps * 64u;
   std::vector<std::vector<uint32_t>> task_of(levels.size());
+  sch.bstep0.push_back(sch.n_steps);
   for (size_t L = 0; L < levels.size(); L++)
     for (const BlockWork *bw : level_blocks[L]) {
       uint32_t task = sch.n_taskB++;
       task_of[L].push_back(task);
       int r = (int)bw->rows.size();
+      sch.bstep0.push_back(sch.bstep0.back() + (uint32_t)((r - 1 + bt - 1) / bt));
       uint32_t base = sch.n_slots;
       sch.n_slots += (uint32_t)(kChunk * (kChunk - 1));
       sch.src.resize(sch.n_slots, -1);
@@ -282,8 +414,11 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     for (int i = 0; i < kChunk; i++)
       for (int b = 0; b < bt; b++) {
         uint32_t r = sch.outB[task * kChunk + i];
-        sch.idxw[(size_t)(sch.n_steps + task * sch.sb) * 64 + i * bt + b] = (r == kNoRow ? 0xFFFFu : r) << 16;
+        sch.idxw[(size_t)sch.bstep0[task] * 64 + i * bt + b] = (r == kNoRow ? 0xFFFFu : r) << 16;
       }
+  if (getenv("MI_OSQP_DEBUG_ORDER"))
+    fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu A-steps %u block tasks %u (x%d steps) outA %zu\n", levels.size(),
+            phases.size(), sch.n_steps, sch.n_taskB, sch.sb, sch.outA.size());
   sch.n_phases = (int)phases.size();
   for (PhaseRec &ph : phases) {
     sch.phase.push_back((uint32_t)ph.kind);
@@ -291,7 +426,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       uint32_t *e = &ph.wave[4 * w];
       if (ph.kind == 1 && e[0] == 0xFFFFFFFFu) {
         uint32_t task = task_of[e[2]][e[1]];
-        e[0] = sch.n_steps + task * (uint32_t)sch.sb; e[1] = e[0] + (uint32_t)sch.sb; e[2] = task * kChunk; e[3] = 1u;
+        e[0] = sch.bstep0[task]; e[1] = sch.bstep0[task + 1]; e[2] = task * kChunk; e[3] = 1u;
       }
       sch.phase.insert(sch.phase.end(), e, e + 4);
     }
@@ -571,49 +706,82 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   for (int j = 0; j < n; j++)
     for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) { int pos = nxt[n + an.Ai[k]]++; an.Ki[pos] = j; an.AtoK[k] = pos; }
   for (int r = 0; r < m; r++) { int pos = nxt[n + r]++; an.Ki[pos] = n + r; an.rhotoK[r] = pos; }
-  // ---- ordering, then etree postorder so that supernodes are contiguous
-  min_degree(N, an.Kp, an.Ki, an.perm);
-  an.pinv.assign(N, 0);
-  for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
-  build_permuted_lower(an);
-  std::vector<std::vector<int>> cols;
-  std::vector<int> parent, post;
-  symbolic(an, cols, parent);
-  postorder(parent, post);
-  {
-    std::vector<int> p2(N);
-    for (int k = 0; k < N; k++) p2[k] = an.perm[post[k]];
-    an.perm.swap(p2);
+  // ---- ordering: two candidates, chosen by the modelled time of one KKT solve on the device
+  // (phases cost ~1.5 us each, the factor streams at ~18 GB/s per CU)
+  auto finalize = [&](const std::vector<int> &perm0, double &cost) {
+    an.perm = perm0;
+    an.pinv.assign(N, 0);
     for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
-  }
-  build_permuted_lower(an);
-  symbolic(an, cols, parent);
-  an.etree = parent;
-  an.Lp.assign(N + 1, 0);
-  for (int j = 0; j < N; j++) an.Lp[j + 1] = an.Lp[j] + (int)cols[j].size();
-  an.Li.resize(an.Lp[N]);
-  for (int j = 0; j < N; j++) std::copy(cols[j].begin(), cols[j].end(), an.Li.begin() + an.Lp[j]);
-  // row view of L
-  an.Rp.assign(N + 1, 0);
-  for (int p = 0; p < an.Lp[N]; p++) an.Rp[an.Li[p] + 1]++;
-  for (int i = 0; i < N; i++) an.Rp[i + 1] += an.Rp[i];
-  an.Rj.resize(an.Lp[N]); an.Rpos.resize(an.Lp[N]);
+    build_permuted_lower(an);
+    std::vector<std::vector<int>> cols;
+    std::vector<int> parent, post;
+    symbolic(an, cols, parent);
+    postorder(parent, post);       // etree postorder so that supernodes are contiguous
+    {
+      std::vector<int> p2(N);
+      for (int k = 0; k < N; k++) p2[k] = an.perm[post[k]];
+      an.perm.swap(p2);
+      for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
+    }
+    build_permuted_lower(an);
+    symbolic(an, cols, parent);
+    an.etree = parent;
+    an.Lp.assign(N + 1, 0);
+    for (int j = 0; j < N; j++) an.Lp[j + 1] = an.Lp[j] + (int)cols[j].size();
+    an.Li.resize(an.Lp[N]);
+    for (int j = 0; j < N; j++) std::copy(cols[j].begin(), cols[j].end(), an.Li.begin() + an.Lp[j]);
+    // row view of L
+    an.Rp.assign(N + 1, 0);
+    for (int p = 0; p < an.Lp[N]; p++) an.Rp[an.Li[p] + 1]++;
+    for (int i = 0; i < N; i++) an.Rp[i + 1] += an.Rp[i];
+    an.Rj.resize(an.Lp[N]); an.Rpos.resize(an.Lp[N]);
+    {
+      std::vector<int> fill(an.Rp.begin(), an.Rp.end() - 1);
+      for (int j = 0; j < N; j++)
+        for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int q = fill[an.Li[p]]++; an.Rj[q] = j; an.Rpos[q] = p; }
+    }
+    // fundamental supernodes: j+1 joins j when parent(j)=j+1 and |col j| = |col j+1| + 1
+    an.sn_start.clear(); an.sn_start.push_back(0);
+    for (int j = 0; j + 1 < N; j++) {
+      bool join = parent[j] == j + 1 && cols[j].size() == cols[j + 1].size() + 1;
+      if (!join) an.sn_start.push_back(j + 1);
+    }
+    an.sn_start.push_back(N);
+    an.chunk_start.clear();
+    for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
+      for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) an.chunk_start.push_back(c);
+    an.chunk_start.push_back(N);
+    // forward chunk levels (the backward sweep has the same depth)
+    int nch = (int)an.chunk_start.size() - 1, depth = 0;
+    std::vector<int> chunk_of(N), lev(nch, 0);
+    for (int c = 0; c < nch; c++) for (int j = an.chunk_start[c]; j < an.chunk_start[c + 1]; j++) chunk_of[j] = c;
+    for (int c = 0; c < nch; c++) {
+      int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], L = 0;
+      for (int i = c0; i < c1; i++)
+        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0) L = std::max(L, lev[chunk_of[j]] + 1); }
+      lev[c] = L; depth = std::max(depth, L + 1);
+    }
+    // phases of one sweep: one A phase per level + ceil(block tasks of the level / waves) B phases
+    std::vector<int> blocks_at(depth, 0);
+    for (int c = 0; c < nch; c++) if (an.chunk_start[c + 1] - an.chunk_start[c] >= 2) blocks_at[lev[c]]++;
+    int phases = depth;
+    for (int L = 0; L < depth; L++) phases += (blocks_at[L] + nwaves - 1) / nwaves;
+    cost = 2.0 * phases * 1.5e-6 + 2.0 * 8.0 * bt * 1.3 * (double)an.Lp[N] / 18e9;
+  };
   {
-    std::vector<int> fill(an.Rp.begin(), an.Rp.end() - 1);
-    for (int j = 0; j < N; j++)
-      for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int q = fill[an.Li[p]]++; an.Rj[q] = j; an.Rpos[q] = p; }
+    std::vector<int> p_md, p_nd;
+    double c_md = 0.0, c_nd = 0.0;
+    min_degree(N, an.Kp, an.Ki, p_md);
+    nested_dissection(N, an.Kp, an.Ki, p_nd);
+    const char *force = getenv("MI_OSQP_ORDERING");       // "md" / "nd": experiments
+    finalize(p_nd, c_nd);
+    finalize(p_md, c_md);
+    bool use_nd = c_nd < c_md;
+    if (getenv("MI_OSQP_DEBUG_ORDER")) fprintf(stderr, "[mi_osqp] ordering cost md %.3e nd %.3e\n", c_md, c_nd);
+    if (force) use_nd = force[0] == 'n';
+    if (use_nd) finalize(p_nd, c_nd);
+    an.ordering = use_nd ? 1 : 0;
   }
-  // fundamental supernodes: j+1 joins j when parent(j)=j+1 and |col j| = |col j+1| + 1
-  an.sn_start.clear(); an.sn_start.push_back(0);
-  for (int j = 0; j + 1 < N; j++) {
-    bool join = parent[j] == j + 1 && cols[j].size() == cols[j + 1].size() + 1;
-    if (!join) an.sn_start.push_back(j + 1);
-  }
-  an.sn_start.push_back(N);
-  an.chunk_start.clear();
-  for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
-    for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) an.chunk_start.push_back(c);
-  an.chunk_start.push_back(N);
   build_tri_schedules(an, nwaves, bt);
   build_chk_schedule(an, nwaves, bt);
   build_block_factor(an);
@@ -795,7 +963,8 @@ size_t phys_index(const Schedule &s, uint32_t slot, int b) {
   if (slot < nA) return (size_t)slot * s.bt + b;
   const uint32_t r = slot - nA, task = r / (kChunk * (kChunk - 1)), rem = r % (kChunk * (kChunk - 1));
   const uint32_t k = rem / kChunk, i = rem % kChunk;
-  return ((size_t)(s.n_steps + task * s.sb + k / s.bt) * 64 + (size_t)i * s.bt + b) * s.bt + k % s.bt;
+  if (k / s.bt >= s.bstep0[task + 1] - s.bstep0[task]) return (size_t)-1;
+  return ((size_t)(s.bstep0[task] + k / s.bt) * 64 + (size_t)i * s.bt + b) * s.bt + k % s.bt;
 }
 
 // sequential interpreter of one schedule (tests): walks the phase table exactly as the device does

@@ -49,8 +49,7 @@ int validate_settings(const Settings &s);   // 0 ok
 //
 // Logical slots (what `src`, `idx` index): A steps: step*64 + lane; B tasks:
 // 64*n_steps + task*240 + k*16 + i.  Physical position of QP b's double inside a
-// tile: A: slot*BT + b ; B: ((n_steps + task*SB + k/BT)*64 + i*BT + b)*BT + k%BT
-// with SB = ceil(15/BT) steps per block task.
+// tile: A: slot*BT + b ; B: ((bstep0[task] + k/BT)*64 + i*BT + b)*BT + k%BT for k < BT * (steps of the task).
 struct Schedule {
   int n_phases = 0, nw = 0, bt = 1, sb = 15;
   std::vector<uint32_t> phase;  // per phase, stride 4*nw+1: kind(0=A,1=B) then per wave (begin, end, out_base, 0)
@@ -66,7 +65,8 @@ struct Schedule {
   uint32_t n_slots = 0;         // logical slots
   uint32_t n_steps = 0;         // A steps (incl. the all-zero padding step `zero_step`)
   uint32_t n_taskB = 0, zero_step = 0;
-  uint32_t phys_steps() const { return n_steps + n_taskB * (uint32_t)sb; }
+  std::vector<uint32_t> bstep0;  // per block task: first physical step (n_taskB + 1 entries); a task of r rows owns ceil((r-1)/bt) steps
+  uint32_t phys_steps() const { return bstep0.empty() ? n_steps : bstep0.back(); }
   size_t phase_stride() const { return 4 * (size_t)nw + 1; }
   int n_levels = 0;
 };
@@ -103,6 +103,7 @@ struct Analysis {
   std::vector<char> PisDiag;
   // fill-reducing permutation (perm[new] = old)
   std::vector<int> perm, pinv;
+  int ordering = 0;                // 0 minimum degree, 1 nested dissection (picked by analyze())
   // permuted KKT, lower triangle by columns, and map natural entry -> position
   std::vector<int> Klp, Kli, KtoKl;
   // symbolic factor: strictly-lower L by columns (sorted rows) + row view
@@ -124,7 +125,7 @@ struct Analysis {
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
             const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1);
 // physical position (in doubles, inside one tile) of QP b's value of a logical slot
-size_t phys_index(const Schedule &s, uint32_t slot, int b);
+size_t phys_index(const Schedule &s, uint32_t slot, int b);   // (size_t)-1: the slot has no storage (k beyond the task's steps)
 
 // Per-QP numeric state kept on the host (needed for rescaling and refactors).
 struct QPNumeric {

@@ -110,7 +110,9 @@ __device__ __forceinline__ size_t phys_index(const SchedDev &s, uint32_t slot, i
   if (slot < nA) return (size_t)slot * BT + b;
   const uint32_t r = slot - nA, task = r / (MI_CHUNK * (MI_CHUNK - 1)), rem = r % (MI_CHUNK * (MI_CHUNK - 1));
   const uint32_t k = rem / MI_CHUNK, i = rem % MI_CHUNK;
-  return ((size_t)(s.n_steps + task * s.sb + k / BT) * 64 + (size_t)i * BT + b) * BT + k % BT;
+  const uint32_t st0 = s.bstep0[task];
+  if (k / BT >= s.bstep0[task + 1] - st0) return (size_t)-1;      // no storage: the task has fewer rows
+  return ((size_t)(st0 + k / BT) * 64 + (size_t)i * BT + b) * BT + k % BT;
 }
 
 // ----------------------------------------------------------------- row steps
@@ -992,12 +994,14 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     for (size_t e = tid; e < (size_t)a.fwd.n_slots * BT; e += nthr) {
       const uint32_t sl = (uint32_t)(e / BT);
       const int32_t mp = a.fwd_srcblk[sl];
-      fv[phys_index(a.fwd, sl, b, BT)] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+      const size_t ph = phys_index(a.fwd, sl, b, BT);
+      if (ph != (size_t)-1) fv[ph] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
     }
     for (size_t e = tid; e < (size_t)a.bwd.n_slots * BT; e += nthr) {
       const uint32_t sl = (uint32_t)(e / BT);
       const int32_t mp = a.bwd_srcblk[sl];
-      bv[phys_index(a.bwd, sl, b, BT)] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+      const size_t ph = phys_index(a.bwd, sl, b, BT);
+      if (ph != (size_t)-1) bv[ph] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
     }
     for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
   }
@@ -1045,7 +1049,8 @@ __global__ void scatter_kernel(const double *__restrict__ src, double *dst, cons
   const int q = ids ? ids[j] : j;
   const int mp = map[s];
   const size_t tile_doubles = (size_t)sd.phys_steps * 64 * BT;
-  dst[(size_t)(q / BT) * tile_doubles + phys_index(sd, s, q % BT, BT)] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
+  const size_t ph = phys_index(sd, s, q % BT, BT);
+  if (ph != (size_t)-1) dst[(size_t)(q / BT) * tile_doubles + ph] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
 }
 // Compaction support: exchange the complete per-QP contents of slot pairs (slot =
 // tile*BT + b).  Plain arrays are [tile][len][BT]; scheduled value arrays use the

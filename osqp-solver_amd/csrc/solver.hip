@@ -98,15 +98,16 @@ struct DevBuf {
 };
 
 struct SchedBufs {
-  DevBuf<uint32_t> phase, step, idxw;
+  DevBuf<uint32_t> phase, step, idxw, bstep0;
   DevBuf<int32_t> src;
   int upload(const Schedule &s) {
     int rc;
-    if ((rc = phase.upload(s.phase)) || (rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src))) return rc;
+    if ((rc = phase.upload(s.phase)) || (rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src)) ||
+        (rc = bstep0.upload(s.bstep0))) return rc;
     return 0;
   }
   SchedDev view(const Schedule &s) const {
-    SchedDev d; d.phase = phase.p; d.step = step.p; d.idxw = idxw.p;
+    SchedDev d; d.phase = phase.p; d.step = step.p; d.idxw = idxw.p; d.bstep0 = bstep0.p;
     d.n_phases = s.n_phases; d.nw = s.nw; d.sb = s.sb;
     d.n_steps = s.n_steps; d.phys_steps = s.phys_steps(); d.zero_step = s.zero_step; d.n_slots = s.n_slots;
     return d;
