@@ -1,0 +1,390 @@
+// gomp.hpp -- the callers of the solver path, SURVEY.md section 8(f) ranks 1-3, as a
+// header-only C++17 layer on top of qp_solver.hpp (no Eigen):
+//
+//   constraints helpers      [REF] /root/reference/src/constraints/constraints.h:9-69
+//   HorizontalLine           [REF] src/horizontal-line.h:6-104
+//   RobotBall, linspace,
+//   triDiagonalMatrix        [REF] src/utils.h:33-42,50-64,72-96
+//   ConstraintBuilder<N>     [REF] src/constraints/constraint-builder.h:18-283
+//   GOMPSolver<N>            [REF] src/gomp-solver.h:13-201
+//
+// Same names, argument meaning, row layout and control flow as the reference (the known-answer
+// tests of [REF] tests/test.cpp are replayed against it in tests/cpp/), written against plain
+// containers.  GOMPSolver takes the QP backend as a template parameter: `QPSolver` (the MI355X
+// path) by default; the parity test instantiates it with an oracle-backed twin.
+// The reference prints every waypoint; here printing is off unless `verbose` is set.
+#pragma once
+
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <optional>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "qp_solver.hpp"
+
+namespace miosqp_ref {
+
+// ------------------------------------------------------------------ constraints.h
+template <size_t N> using Vec = std::array<double, N>;
+template <size_t N> using Bound = std::optional<Vec<N>>;
+template <size_t N> using Constraint = std::pair<Bound<N>, Bound<N>>;
+template <size_t N> using Ctrl = Vec<N>;
+using Point = Vec<3>;
+enum Axis : size_t { X, Y, Z };
+constexpr std::array<Axis, 3> XYZ_AXES = {X, Y, Z};
+constexpr double CENTIMETER = 0.01;
+constexpr double ERROR = 1e-3;                         // [REF] src/utils.h:31
+
+namespace constraints {
+template <size_t N> Vec<N> of(double v) { Vec<N> r; r.fill(v); return r; }
+template <size_t N> Constraint<N> inRange(Bound<N> low, Bound<N> upp) { return {low, upp}; }
+template <size_t N> Constraint<N> equal(const Vec<N> &v) { return {v, v}; }
+template <size_t N> Constraint<N> greaterEq(const Vec<N> &v) { return {v, std::nullopt}; }
+template <size_t N> Constraint<N> lessEq(const Vec<N> &v) { return {std::nullopt, v}; }
+template <size_t N> Constraint<N> any() { return {std::nullopt, std::nullopt}; }
+template <size_t N> Constraint<N> eqZero() { return equal<N>(of<N>(0.0)); }
+template <size_t N> Bound<N> scaled(const Bound<N> &b, double f) {
+  if (!b) return std::nullopt;
+  Vec<N> r = *b;
+  for (double &x : r) x *= f;
+  return r;
+}
+template <size_t N> Constraint<N> scaled(const Constraint<N> &c, double f) { return {scaled<N>(c.first, f), scaled<N>(c.second, f)}; }
+}  // namespace constraints
+
+// ------------------------------------------------------------------------ utils.h
+using ForwardKinematicsFun = std::function<std::tuple<double, double, double>(double *)>;
+using JacobianFun = std::function<void(double *, double *)>;          // out: 3 x N row-major, in: q
+using InverseKinematics = std::function<int(double *, double, double, double)>;
+
+struct RobotBall {
+  RobotBall(ForwardKinematicsFun fk_, JacobianFun jac_, double radius_, bool is_gripper_ = false)
+      : fk(std::move(fk_)), jacobian(std::move(jac_)), radius(radius_), is_gripper(is_gripper_) {}
+  ForwardKinematicsFun fk;
+  JacobianFun jacobian;
+  double radius;
+  bool is_gripper;
+};
+
+// n x n matrix with a on the diagonal and b on the +-diagonal_num diagonals for rows >= offset
+// (both triangles are emitted, as the reference does)
+inline QPMatrixSparse triDiagonalMatrix(double a, double b, int n, int offset = 0, int diagonal_num = 1) {
+  std::map<std::pair<long long, long long>, double> cells;          // (col, row) -> value : CSC order
+  for (int i = offset; i < n; ++i) {
+    cells[{i, i}] = a;
+    if (i + diagonal_num < n) cells[{i + diagonal_num, i}] = b;
+    if (i - diagonal_num >= offset) cells[{i - diagonal_num, i}] = b;
+  }
+  QPMatrixSparse M;
+  M.rows = M.cols = n;
+  M.outer.assign(n + 1, 0);
+  for (const auto &[cr, v] : cells) { M.outer[cr.first + 1]++; M.inner.push_back(cr.second); M.values.push_back(v); }
+  for (int j = 0; j < n; ++j) M.outer[j + 1] += M.outer[j];
+  return M;
+}
+
+template <size_t N>
+QPVector linspace(const Vec<N> &a, const Vec<N> &b, size_t n_steps) {
+  QPVector res(N * n_steps);
+  for (size_t s = 0; s < n_steps; ++s)
+    for (size_t j = 0; j < N; ++j) res[s * N + j] = (b[j] - a[j]) / double(n_steps - 1) * double(s) + a[j];
+  return res;
+}
+
+// positions of a joint trajectory (first half of the vector) -> xyz, fk called once per waypoint in order
+template <size_t N>
+QPVector mapJointTrajectoryToXYZ(const QPVector &trajectory, const ForwardKinematicsFun &mapper) {
+  const size_t waypoints = trajectory.size() / 2 / N;
+  QPVector xyz(3 * waypoints);
+  for (size_t w = 0; w < waypoints; ++w) {
+    Vec<N> q;
+    for (size_t j = 0; j < N; ++j) q[j] = trajectory[w * N + j];
+    auto [x, y, z] = mapper(q.data());
+    xyz[3 * w] = x; xyz[3 * w + 1] = y; xyz[3 * w + 2] = z;
+  }
+  return xyz;
+}
+
+// -------------------------------------------------------------- horizontal-line.h
+class HorizontalLine {
+ public:
+  HorizontalLine(const std::array<double, 2> &direction, const Point &point, bool bypass_from_below = false)
+      : A_(point), below_(bypass_from_below) {
+    const double nrm = std::hypot(direction[0], direction[1]);
+    D_ = {direction[0] / nrm, direction[1] / nrm, 0.0};
+  }
+  // perpendicular from P to the line: X - P with X = A + ((P-A).D) D
+  Point getDistanceVec(const Point &P) const {
+    double t = 0.0;
+    for (int k = 0; k < 3; ++k) t += (P[k] - A_[k]) * D_[k];
+    return {A_[0] + t * D_[0] - P[0], A_[1] + t * D_[1] - P[1], A_[2] + t * D_[2] - P[2]};
+  }
+  std::array<double, 2> getDistanceVecXY(const Point &P) const { Point d = getDistanceVec(P); return {d[0], d[1]}; }
+  double getDistanceXY(const Point &P) const { auto d = getDistanceVecXY(P); return std::hypot(d[0], d[1]); }
+  Point operator[](const Point &P) const { Point d = getDistanceVec(P); return {P[0] + d[0], P[1] + d[1], P[2] + d[2]}; }
+  bool areOnOppositeSides(const Point &P, const Point &Q) const {
+    auto a = getDistanceVecXY(P), b = getDistanceVecXY(Q);
+    return a[0] * b[0] + a[1] * b[1] < 0;
+  }
+  bool isClose(const Point &P, const RobotBall &b) const { return getDistanceXY(P) < b.radius; }
+  bool hasCollision(int waypoint, const QPVector &xyz, const RobotBall &b) const {
+    const int waypoints = (int)xyz.size() / 3;
+    auto at = [&](int w) { return Point{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]}; };
+    const Point p = at(waypoint);
+    if (isClose(p, b)) return true;
+    if (waypoint > 0 && areOnOppositeSides(at(waypoint - 1), p)) return true;
+    if (waypoint + 1 < waypoints && areOnOppositeSides(p, at(waypoint + 1))) return true;
+    return false;
+  }
+  bool isAbove(const Point &P, const RobotBall &b) const {
+    return below_ ? (P[Z] - A_[Z]) <= -b.radius + ERROR : (P[Z] - A_[Z]) >= b.radius - ERROR;
+  }
+  bool bypassFromBelow() const { return below_; }
+
+ private:
+  Point D_{}, A_;
+  bool below_;
+};
+
+// ------------------------------------------------------------- constraint-builder.h
+// Rows: (W-1)*D velocity<->position links, then per variable boxes (positions W*D, velocities
+// (W-1)*D, accelerations (W-2)*D), then D*W*(3 + |obstacles|*|balls|) rows for the linearised
+// end-effector / obstacle constraints (allocated even when unused: bounds +-INF).
+template <size_t N_DIM>
+class ConstraintBuilder {
+  using OptPair = std::pair<std::optional<double>, std::optional<double>>;
+
+ public:
+  ConstraintBuilder(size_t waypoints, std::vector<RobotBall> m, std::vector<HorizontalLine> obstacles)
+      : W_(waypoints), balls_(std::move(m)), lines_(std::move(obstacles)) {
+    for (size_t t = 0; t + 1 < W_; ++t)                      // v_t - q_{t+1} + q_t = 0
+      for (size_t j = 0; j < N_DIM; ++j) {
+        lo_.push_back(-INF); up_.push_back(INF);
+        put(lo_.size() - 1, {{nthVelocity(t) + j, 1.0}, {nthPos(t + 1) + j, -1.0}, {nthPos(t) + j, 1.0}}, {0.0, 0.0});
+      }
+    user_off_ = lo_.size();
+    const size_t extra = N_DIM * (W_ + W_ - 1 + W_ - 2 + W_ * (3 + lines_.size() * balls_.size()));
+    lo_.resize(user_off_ + extra, -INF);
+    up_.resize(user_off_ + extra, INF);
+  }
+
+  ConstraintBuilder &position(size_t i, const Constraint<N_DIM> &c) { return positions(i, i, c); }
+  ConstraintBuilder &positions(size_t first, size_t last, const Constraint<N_DIM> &c) { return boxes(nthPos(first), nthPos(last), c); }
+  ConstraintBuilder &velocity(size_t i, const Constraint<N_DIM> &c) { return velocities(i, i, c); }
+  ConstraintBuilder &velocities(size_t first, size_t last, const Constraint<N_DIM> &c) {
+    assert(first <= last && last < W_ - 1);
+    return boxes(nthVelocity(first), nthVelocity(last), c);
+  }
+  ConstraintBuilder &accelerations(size_t first, size_t last, const Constraint<N_DIM> &c) {
+    for (size_t i = first; i <= last; ++i) acceleration(i, c);
+    return *this;
+  }
+  ConstraintBuilder &acceleration(size_t i, const Constraint<N_DIM> &c) {
+    assert(i + 2 < W_);
+    for (size_t j = 0; j < N_DIM; ++j)                          // l <= v_{t+1} - v_t <= u
+      put(user_off_ + nthAcceleration(i) + j, {{nthVelocity(i + 1) + j, 1.0}, {nthVelocity(i) + j, -1.0}}, dim(j, c));
+    return *this;
+  }
+
+  // (re-)linearise the 3-D rows around `trajectory`; the pattern never changes (dummy rows)
+  ConstraintBuilder &withObstacles(const Constraint<3> &con_3d, const QPVector &trajectory) {
+    size_t row = user_off_ + N_DIM * (W_ + W_ - 1 + W_ - 2);
+    for (const RobotBall &ball : balls_) {
+      const QPVector xyz = mapJointTrajectoryToXYZ<N_DIM>(trajectory, ball.fk);
+      for (size_t w = 0; w < W_; ++w) {
+        Vec<N_DIM> q;
+        for (size_t j = 0; j < N_DIM; ++j) q[j] = trajectory[w * N_DIM + j];
+        const Point p{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]};
+        std::array<double, 3 * N_DIM> J{};
+        ball.jacobian(J.data(), q.data());
+        auto Jq = [&](size_t axis) { double s = 0.0; for (size_t j = 0; j < N_DIM; ++j) s += J[axis * N_DIM + j] * q[j]; return s; };
+        if (ball.is_gripper) {
+          for (Axis axis : XYZ_AXES) {
+            double lo = -INF, up = INF;
+            if (con_3d.first) lo = (*con_3d.first)[axis] - p[axis] + Jq(axis);
+            if (con_3d.second) up = (*con_3d.second)[axis] - p[axis] + Jq(axis);
+            axisRow(row++, ball, axis, J, w, lo, up);
+          }
+        }
+        for (const HorizontalLine &line : lines_) {
+          if (line.hasCollision((int)w, xyz, ball)) {
+            const double bound = line[p][Z] - p[Z] + Jq(Z);
+            if (line.bypassFromBelow()) axisRow(row++, ball, Z, J, w, -INF, bound);
+            else axisRow(row++, ball, Z, J, w, bound, INF);
+          } else {
+            axisRow(row++, ball, Z, J, w, -INF, INF);          // dummy: keeps the pattern constant
+          }
+        }
+      }
+    }
+    return *this;
+  }
+
+  QPConstraints build() const {
+    QPMatrixSparse A;
+    A.rows = (long long)lo_.size(); A.cols = (long long)(2 * N_DIM * W_);
+    A.outer.assign(A.cols + 1, 0);
+    for (const auto &[cr, v] : cells_) { A.outer[cr.first + 1]++; A.inner.push_back((long long)cr.second); A.values.push_back(v); }
+    for (long long j = 0; j < A.cols; ++j) A.outer[j + 1] += A.outer[j];
+    return {lo_, A, up_};
+  }
+
+  size_t nthVelocity(size_t i) const { assert(i < W_ - 1); return W_ * N_DIM + i * N_DIM; }
+  size_t nthPos(size_t i) const { assert(i < W_); return i * N_DIM; }
+  size_t nthAcceleration(size_t i) const { assert(i < W_ - 2); return W_ * N_DIM + (W_ - 1) * N_DIM + i * N_DIM; }
+
+ private:
+  size_t W_, user_off_ = 0;
+  std::vector<RobotBall> balls_;
+  std::vector<HorizontalLine> lines_;
+  std::map<std::pair<size_t, size_t>, double> cells_;          // (col, row) -> value: CSC order, last write wins
+  std::vector<double> lo_, up_;
+
+  static OptPair dim(size_t j, const Constraint<N_DIM> &c) {
+    OptPair r;
+    if (c.first) r.first = (*c.first)[j];
+    if (c.second) r.second = (*c.second)[j];
+    return r;
+  }
+  void put(size_t row, std::initializer_list<std::pair<size_t, double>> eq, OptPair b) {
+    for (const auto &[col, coeff] : eq) cells_[{col, row}] = coeff;
+    if (b.first) lo_[row] = *b.first;
+    if (b.second) up_[row] = *b.second;
+    assert(lo_[row] <= up_[row]);
+  }
+  ConstraintBuilder &boxes(size_t first_start, size_t last_start, const Constraint<N_DIM> &c) {
+    for (size_t s = first_start; s <= last_start; s += N_DIM)
+      for (size_t j = 0; j < N_DIM; ++j) put(user_off_ + s + j, {{s + j, 1.0}}, dim(j, c));
+    return *this;
+  }
+  void axisRow(size_t row, const RobotBall &ball, Axis axis, const std::array<double, 3 * N_DIM> &J, size_t waypoint,
+               double low, double upp) {
+    for (size_t j = 0; j < N_DIM; ++j) cells_[{nthPos(waypoint) + j, row}] = J[axis * N_DIM + j];
+    lo_[row] = low + ball.radius;
+    up_[row] = upp - ball.radius;
+    assert(lo_[row] <= up_[row]);
+  }
+};
+
+// ------------------------------------------------------------------- gomp-solver.h
+constexpr int MAX_ITERATIONS = 100;
+constexpr int SEGMENTS = 10;
+
+template <size_t N_DIM, class SolverT = QPSolver>
+class GOMPSolver {
+ public:
+  GOMPSolver(size_t waypoints, double time_step, const Constraint<N_DIM> &pos_con, const Constraint<N_DIM> &vel_con,
+             const Constraint<N_DIM> &acc_con, const Constraint<3> &con_3d, std::vector<HorizontalLine> obstacles,
+             std::vector<RobotBall> m, InverseKinematics gripper_ik = nullptr, bool verbose = false)
+      : max_waypoints(waypoints), time_step(time_step), pos_con(pos_con),
+        vel_con(constraints::scaled<N_DIM>(vel_con, time_step)),
+        acc_con(constraints::scaled<N_DIM>(acc_con, time_step * time_step)), con_3d(con_3d),
+        obstacles(std::move(obstacles)), mappers(std::move(m)), gripper_ik(std::move(gripper_ik)), verbose(verbose) {
+    assert(max_waypoints >= 4);
+  }
+
+  // horizon-shrinking outer loop: SEGMENTS QPs chains of W = max_waypoints * i / SEGMENTS waypoints
+  std::pair<ExitCode, QPVector> run(Ctrl<N_DIM> start_pos, Ctrl<N_DIM> end_pos) {
+    QPVector last_solution = calcWarmStart(start_pos, end_pos);
+    ExitCode last_code = ExitCode::kUnknown;
+    for (int i = SEGMENTS; i >= 1; --i) {
+      const size_t waypoints = max_waypoints * i / SEGMENTS;
+      QPVector warm_start(waypoints * N_DIM * 2);
+      // same slicing as the reference, including its quirk for i < SEGMENTS (the "velocity" half is
+      // taken at offset W*D of the previous, longer solution)
+      for (size_t k = 0; k < waypoints * N_DIM; ++k) {
+        warm_start[k] = last_solution[k];
+        warm_start[waypoints * N_DIM + k] = last_solution[waypoints * N_DIM + k];
+      }
+      auto [exit_code, solution] = run(start_pos, end_pos, waypoints, warm_start);
+      ++segments_run;
+      if (exit_code != ExitCode::kOptimal && exit_code != ExitCode::kUnknown) break;
+      if (exit_code == ExitCode::kOptimal) { last_code = ExitCode::kOptimal; last_solution = solution; }
+    }
+    for (size_t k = last_solution.size() / 2; k < last_solution.size(); ++k) last_solution[k] /= time_step;
+    return {last_code, last_solution};
+  }
+
+  // SQP inner loop for one horizon
+  std::pair<ExitCode, QPVector> run(Ctrl<N_DIM> start_pos, Ctrl<N_DIM> end_pos, size_t waypoints, const QPVector &warm_start) {
+    ConstraintBuilder<N_DIM> builder = initConstraints(start_pos, end_pos, warm_start, waypoints);
+    SolverT qp_solver{builder.build(), triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * waypoints), (int)(waypoints * N_DIM), (int)N_DIM), verbose};
+    qp_solver.setWarmStart(warm_start);
+    QPVector last_solution = warm_start;
+    ExitCode last_code = ExitCode::kUnknown;
+    int i = 0;
+    while (i++ < MAX_ITERATIONS) {
+      auto [exit_code, solution] = qp_solver.solve();
+      ++qp_solves;
+      if (exit_code != ExitCode::kOptimal) { last_solution = solution; break; }      // there are no solutions
+      if (isSolutionOK(solution)) { last_solution = solution; last_code = ExitCode::kOptimal; break; }
+      qp_solver.update(builder.withObstacles(con_3d, solution).build());
+      ++qp_updates;
+    }
+    return {last_code, last_solution};
+  }
+
+  // counters for tests / reporting
+  int segments_run = 0, qp_solves = 0, qp_updates = 0;
+
+ private:
+  const size_t max_waypoints;
+  const double time_step;
+  const Constraint<N_DIM> pos_con, vel_con, acc_con;
+  const Constraint<3> con_3d;
+  const std::vector<HorizontalLine> obstacles;
+  const std::vector<RobotBall> mappers;
+  const InverseKinematics gripper_ik;
+  const bool verbose;
+
+  QPVector calcWarmStart(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos) const {
+    QPVector w = linspace<N_DIM>(start_pos, end_pos, max_waypoints);      // joint-space line, zero velocities
+    w.resize(2 * max_waypoints * N_DIM, 0.0);
+    return w;
+  }
+
+  ConstraintBuilder<N_DIM> initConstraints(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, const QPVector &warm_start,
+                                           size_t waypoints) const {
+    assert(waypoints >= 4);
+    ConstraintBuilder<N_DIM> b{waypoints, mappers, obstacles};
+    b.position(0, constraints::equal<N_DIM>(start_pos))
+        .positions(1, waypoints - 2, pos_con)
+        .position(waypoints - 3, constraints::equal<N_DIM>(end_pos))
+        .velocities(0, waypoints - 4, vel_con)
+        .velocity(waypoints - 3, constraints::eqZero<N_DIM>())
+        .accelerations(0, waypoints - 4, acc_con)
+        .acceleration(waypoints - 3, constraints::eqZero<N_DIM>())
+        .withObstacles(con_3d, warm_start);
+    return b;
+  }
+
+  bool isSolutionOK(const QPVector &q_trajectory) const {
+    bool res = true;
+    for (const RobotBall &ball : mappers) {
+      const QPVector xyz = mapJointTrajectoryToXYZ<N_DIM>(q_trajectory, ball.fk);
+      const int waypoints = (int)xyz.size() / 3;
+      for (int w = 0; w < waypoints; ++w) {
+        const Point p{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]};
+        if (verbose) std::printf("(%f, %f, %f)\n", p[X], p[Y], p[Z]);
+        if (ball.is_gripper) {
+          for (Axis axis : XYZ_AXES) {
+            const double lo = con_3d.first ? (*con_3d.first)[axis] : -INF;
+            const double up = con_3d.second ? (*con_3d.second)[axis] : INF;
+            if (!(lo - ERROR <= p[axis] - ball.radius && p[axis] + ball.radius <= up + ERROR)) res = false;
+          }
+        }
+        for (const HorizontalLine &line : obstacles)
+          if (line.hasCollision(w, xyz, ball) && !line.isAbove(p, ball)) res = false;
+      }
+    }
+    return res;
+  }
+};
+
+}  // namespace miosqp_ref

@@ -82,6 +82,7 @@ class QPSolver {
                          reinterpret_cast<const int64_t *>(A.outer.data()), reinterpret_cast<const int64_t *>(A.inner.data()),
                          A.values.data(), l.data(), u.data(), &s);
     status_ = rc;
+    verbose_ = verbose;
     assert(rc == MI_OSQP_OK);                                              // [REF] :30 (assert only)
     n_ = A.cols;
   }
@@ -101,7 +102,7 @@ class QPSolver {
   void setWarmStart(const QPVector &primal_vector) {
     int rc = (long long)primal_vector.size() == n_ ? mi_osqp_warm_start_x(h_, primal_vector.data())
                                                    : (int)MI_OSQP_ERR_INVALID_DATA;
-    std::cout << "STATUS: " << (rc == MI_OSQP_OK ? "OK" : mi_osqp_error_name(rc)) << std::endl;   // [REF] :47
+    if (verbose_) std::cout << "STATUS: " << (rc == MI_OSQP_OK ? "OK" : mi_osqp_error_name(rc)) << std::endl;   // [REF] :47
     assert(rc == MI_OSQP_OK);
   }
 
@@ -122,6 +123,7 @@ class QPSolver {
   mi_osqp_solver *h_ = nullptr;
   long long n_ = 0;
   int status_ = 0;
+  bool verbose_ = true;
   mi_osqp_info last_{};
 };
 

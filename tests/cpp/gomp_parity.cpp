@@ -1,0 +1,204 @@
+// tests/cpp/gomp_parity.cpp -- TEST PROGRAM (links the oracle; never part of the product).
+//
+//   ./gomp_parity kats    CPU only: replays the reference's own ConstraintBuilder / HorizontalLine
+//                         known-answer tests ([REF] /root/reference/tests/test.cpp:82-100,250-448;
+//                         the joint-space ones are covered in tests/test_builder_kats.py) against
+//                         include/mi_osqp/gomp.hpp.  Expected numbers are the reference's data.
+//   ./gomp_parity parity  GPU: runs GOMPSolver<3> twice on the same inputs -- once on the MI355X
+//                         QPSolver, once on an oracle-backed twin -- and compares trajectories.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "mi_osqp/gomp.hpp"
+extern "C" {
+#include "../../oracle/osqp_oracle.h"
+}
+
+using namespace miosqp_ref;
+
+// QPSolver twin on the CPU oracle (same four methods, same exit-code mapping)
+class OracleQPSolver {
+ public:
+  OracleQPSolver(const QPConstraints &c, const QPMatrixSparse &P, bool = false) {
+    const auto &[l, A, u] = c;
+    oq_settings s; oq_default_settings(&s);
+    oq_int err = 0;
+    w_ = oq_setup(A.cols, A.rows, P.outer.data(), P.inner.data(), P.values.data(), nullptr, A.outer.data(), A.inner.data(),
+                  A.values.data(), l.data(), u.data(), &s, &err);
+    if (!w_) throw std::runtime_error("oracle setup failed");
+    n_ = A.cols;
+  }
+  ~OracleQPSolver() { oq_cleanup(w_); }
+  OracleQPSolver(const OracleQPSolver &) = delete;
+  void update(const QPConstraints &c) {
+    const auto &[l, A, u] = c;
+    if (oq_update_A(w_, A.outer.data(), A.inner.data(), A.values.data())) throw std::invalid_argument("pattern");
+    if (oq_update_bounds(w_, l.data(), u.data())) throw std::invalid_argument("bounds");
+  }
+  void setWarmStart(const QPVector &x) { oq_warm_start_x(w_, x.data()); }
+  std::pair<OsqpExitCode, QPVector> solve() {
+    const oq_int st = oq_solve(w_);
+    QPVector x(n_);
+    oq_get_solution(w_, x.data(), nullptr);
+    OsqpExitCode c = OsqpExitCode::kUnknown;
+    switch (st) {
+      case 1: c = OsqpExitCode::kOptimal; break;
+      case 2: c = OsqpExitCode::kOptimalInaccurate; break;
+      case -3: c = OsqpExitCode::kPrimalInfeasible; break;
+      case 3: c = OsqpExitCode::kPrimalInfeasibleInaccurate; break;
+      case -4: c = OsqpExitCode::kDualInfeasible; break;
+      case 4: c = OsqpExitCode::kDualInfeasibleInaccurate; break;
+      case -2: c = OsqpExitCode::kMaxIterations; break;
+      case -7: c = OsqpExitCode::kNonConvex; break;
+      default: break;
+    }
+    return {c, x};
+  }
+ private:
+  oq_work *w_ = nullptr;
+  long long n_ = 0;
+};
+
+static int fails = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); fails++; } } while (0)
+static bool near(double a, double b, double tol = 1e-12) { return std::fabs(a - b) <= tol * (1.0 + std::fabs(b)); }
+
+static std::vector<std::vector<double>> dense_rows(const QPMatrixSparse &A, size_t r0, size_t nr) {
+  std::vector<std::vector<double>> M(nr, std::vector<double>(A.cols, 0.0));
+  for (long long j = 0; j < A.cols; ++j)
+    for (long long k = A.outer[j]; k < A.outer[j + 1]; ++k)
+      if ((size_t)A.inner[k] >= r0 && (size_t)A.inner[k] < r0 + nr) M[A.inner[k] - r0][j] = A.values[k];
+  return M;
+}
+
+static int run_kats() {
+  // LineUtilTest.XAxis ([REF] tests/test.cpp:82-100)
+  {
+    HorizontalLine line{{2, 0}, {1, 1, 1}};
+    auto nrm = [](const Point &p) { return std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]); };
+    CHECK(nrm(line.getDistanceVec({2, 1, 1})) == 0);
+    CHECK(nrm(line.getDistanceVec({1, 2, 1})) == 1);
+    CHECK(nrm(line.getDistanceVec({1, 1, 2})) == 1);
+    CHECK(near(nrm(line.getDistanceVec({1, 2, 2})), std::sqrt(2.0)));
+    CHECK(line.getDistanceXY({2, 1, 1}) == 0);
+    CHECK(line.getDistanceXY({1, 2, 1}) == 1);
+    CHECK(line.getDistanceXY({1, 1, 2}) == 0);
+    Point c = line[{1.1, 1.2, 1.3}];
+    CHECK(near(c[0], 1.1) && near(c[1], 1.0) && near(c[2], 1.0));
+  }
+  // ConstraintsTest.position3d_* ([REF] tests/test.cpp:250-448): D=3, W=2, one gripper ball of radius 0
+  const size_t D = 3, W = 2;
+  const size_t first3d = (W - 1) * D + W * D + (W - 1) * D + (W - 2) * D;     // [REF] tests/test.cpp:25-43
+  auto con = constraints::inRange<3>(Vec<3>{11, 22, 33}, Vec<3>{44, 55, 66});
+  JacobianFun jac_lin = [](double *o, double *) { for (int k = 0; k < 9; ++k) o[k] = k; };
+  JacobianFun jac_pow = [](double *o, double *) { const double v[9] = {0, 1, 2, 4, 8, 16, 32, 64, 128}; for (int k = 0; k < 9; ++k) o[k] = v[k]; };
+  ForwardKinematicsFun fk_id = [](double *q) { return std::tuple<double, double, double>{q[0], q[1], q[2]}; };
+  {  // position3d_2: stateful FK returning 1,2,4 then 8,16,32 pins "fk once per waypoint, in order"
+    int cnt = 0;
+    ForwardKinematicsFun fk_pow = [&cnt](double *) { double a = 1 << cnt, b = 1 << (cnt + 1), c = 1 << (cnt + 2); cnt += 3; return std::tuple<double, double, double>{a, b, c}; };
+    QPVector traj(W * D * 2, 1.0);
+    auto [l, A, u] = ConstraintBuilder<3>{W, {RobotBall{fk_pow, jac_lin, 0, true}}, {}}.withObstacles(con, traj).build();
+    const double expA[6][12] = {{0, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {3, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0}, {6, 7, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                {0, 0, 0, 0, 1, 2, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 3, 4, 5, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 6, 7, 8, 0, 0, 0, 0, 0, 0}};
+    auto M = dense_rows(A, first3d, 6);
+    for (int r = 0; r < 6; ++r) for (int c2 = 0; c2 < 12; ++c2) CHECK(M[r][c2] == expA[r][c2]);
+    const double lx = 11 + 0 + 1 + 2, ly = 22 + 3 + 4 + 5, lz = 33 + 6 + 7 + 8, ux = 44 + 3, uy = 55 + 12, uz = 66 + 21;
+    const double el[6] = {lx - 1, ly - 2, lz - 4, lx - 8, ly - 16, lz - 32}, eu[6] = {ux - 1, uy - 2, uz - 4, ux - 8, uy - 16, uz - 32};
+    for (int r = 0; r < 6; ++r) { CHECK(near(l[first3d + r], el[r])); CHECK(near(u[first3d + r], eu[r])); }
+  }
+  {  // position3d_1: identity FK at q = 1
+    QPVector traj(W * D * 2, 1.0);
+    auto [l, A, u] = ConstraintBuilder<3>{W, {RobotBall{fk_id, jac_lin, 0, true}}, {}}.withObstacles(con, traj).build();
+    const double el[3] = {11 - 1 + 3, 22 - 1 + 12, 33 - 1 + 21}, eu[3] = {44 - 1 + 3, 55 - 1 + 12, 66 - 1 + 21};
+    for (int r = 0; r < 6; ++r) { CHECK(near(l[first3d + r], el[r % 3])); CHECK(near(u[first3d + r], eu[r % 3])); }
+  }
+  {  // position3d_jac_pow2 and ignore_velocity_trajectory: q = 2 (velocities must not matter)
+    for (int variant = 0; variant < 2; ++variant) {
+      QPVector traj(W * D * 2, 2.0);
+      if (variant) for (size_t k = W * D; k < 2 * W * D; ++k) traj[k] = 1024.0;
+      auto [l, A, u] = ConstraintBuilder<3>{W, {RobotBall{fk_id, jac_pow, 0, true}}, {}}.withObstacles(con, traj).build();
+      const double el[3] = {11 - 2 + 0 + 2 + 4, 22 - 2 + 8 + 16 + 32, 33 - 2 + 64 + 128 + 256};
+      const double eu[3] = {44 - 2 + 0 + 2 + 4, 55 - 2 + 8 + 16 + 32, 66 - 2 + 64 + 128 + 256};
+      for (int r = 0; r < 6; ++r) { CHECK(near(l[first3d + r], el[r % 3])); CHECK(near(u[first3d + r], eu[r % 3])); }
+    }
+  }
+  // triDiagonalMatrix ([REF] src/utils.h:50-64): both triangles, zero rows before `offset`
+  {
+    QPMatrixSparse M = triDiagonalMatrix(2, -1, 8, 4, 2);
+    CHECK(M.values.size() == 4 + 2 * 2);
+    for (long long j = 0; j < 4; ++j) CHECK(M.outer[j + 1] == M.outer[j]);
+  }
+  std::printf(fails ? "KATS FAILED (%d)\n" : "KATS OK\n", fails);
+  return fails ? 1 : 0;
+}
+
+// a 3-DOF arm (yaw, shoulder, elbow) with analytic FK / Jacobian
+static const double L1 = 0.4, L2 = 0.3, Z0 = 0.2;
+static std::tuple<double, double, double> arm_fk(double *q) {
+  const double r = L1 * std::cos(q[1]) + L2 * std::cos(q[1] + q[2]);
+  return {r * std::cos(q[0]), r * std::sin(q[0]), Z0 + L1 * std::sin(q[1]) + L2 * std::sin(q[1] + q[2])};
+}
+static void arm_jac(double *o, double *q) {
+  const double c0 = std::cos(q[0]), s0 = std::sin(q[0]);
+  const double r = L1 * std::cos(q[1]) + L2 * std::cos(q[1] + q[2]);
+  const double dr1 = -L1 * std::sin(q[1]) - L2 * std::sin(q[1] + q[2]), dr2 = -L2 * std::sin(q[1] + q[2]);
+  o[0] = -r * s0; o[1] = c0 * dr1; o[2] = c0 * dr2;
+  o[3] = r * c0;  o[4] = s0 * dr1; o[5] = s0 * dr2;
+  o[6] = 0.0;     o[7] = L1 * std::cos(q[1]) + L2 * std::cos(q[1] + q[2]); o[8] = L2 * std::cos(q[1] + q[2]);
+}
+
+template <class SolverT>
+static std::pair<ExitCode, QPVector> plan(bool with_obstacle, int *counters) {
+  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}};
+  std::vector<HorizontalLine> lines;
+  if (with_obstacle) lines.push_back(HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false));    // cross it from above
+  const double pi = 3.14159265358979323846;
+  GOMPSolver<3, SolverT> g(40, 0.1,
+                           constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi)),
+                           constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi)),
+                           constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180)),
+                           constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF}), lines, balls);
+  auto r = g.run({-0.8, 0.3, 0.4}, {0.8, 0.3, 0.4});
+  counters[0] = g.segments_run; counters[1] = g.qp_solves; counters[2] = g.qp_updates;
+  return r;
+}
+
+static int run_parity() {
+  for (int obst = 0; obst < 2; ++obst) {
+    int cg[3], co[3];
+    auto [code_g, x_g] = plan<QPSolver>(obst, cg);
+    auto [code_o, x_o] = plan<OracleQPSolver>(obst, co);
+    double md = 0.0;
+    CHECK(x_g.size() == x_o.size());
+    for (size_t k = 0; k < x_g.size() && k < x_o.size(); ++k) md = std::fmax(md, std::fabs(x_g[k] - x_o[k]));
+    std::printf("obstacle=%d  gpu: %s segments %d solves %d updates %d | oracle: %s segments %d solves %d updates %d | max|dx| %.3e\n",
+                obst, ToString(code_g).c_str(), cg[0], cg[1], cg[2], ToString(code_o).c_str(), co[0], co[1], co[2], md);
+    CHECK(code_g == code_o);
+    CHECK(cg[0] == co[0] && cg[1] == co[1] && cg[2] == co[2]);
+    CHECK(md <= 1e-6);
+    if (obst) CHECK(cg[2] > 0);            // the obstacle must have forced at least one re-linearisation
+    // start pinned, goal pinned at waypoint W-3 of the final (4-waypoint) segment or of the last optimal one
+    CHECK(std::fabs(x_g[0] - (-0.8)) < 5e-3);
+  }
+  std::printf(fails ? "PARITY FAILED (%d)\n" : "PARITY OK\n", fails);
+  return fails ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1 && !std::strcmp(argv[1], "kats")) return run_kats();
+  if (argc > 1 && !std::strcmp(argv[1], "parity")) return run_parity();
+  if (argc > 1 && !std::strcmp(argv[1], "oracle")) {          // CPU only: the driver on the oracle backend
+    for (int obst = 0; obst < 2; ++obst) {
+      int c[3];
+      auto [code, x] = plan<OracleQPSolver>(obst, c);
+      double zmin = 1e9;
+      for (size_t w = 0; w + 1 < x.size() / 6; ++w) { double q[3] = {x[3 * w], x[3 * w + 1], x[3 * w + 2]}; zmin = std::fmin(zmin, std::get<2>(arm_fk(q))); }
+      std::printf("obstacle=%d %s segments %d solves %d updates %d n=%zu min z %.3f\n", obst, ToString(code).c_str(), c[0], c[1], c[2], x.size(), zmin);
+    }
+    return 0;
+  }
+  std::printf("usage: gomp_parity kats|parity\n");
+  return 2;
+}

@@ -1,0 +1,47 @@
+"""The callers of the path as C++ on top of the QPSolver facade:
+include/mi_osqp/gomp.hpp = ConstraintBuilder (with obstacle rows), HorizontalLine, GOMPSolver.
+
+CPU : the reference's own known-answer tests for the 3-D rows / line geometry
+      ([REF] tests/test.cpp:82-100,250-448, data embedded in tests/cpp/gomp_parity.cpp) and the
+      SQP driver on the oracle backend.
+GPU : the same driver on the MI355X QPSolver vs on the oracle backend -- identical exit codes,
+      identical numbers of QP solves / re-linearisations, trajectories within 1e-6."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    import osqp_solver_amd as M
+    from oracle import oracle as O
+    M.lib(); O.lib()
+    out = tmp_path_factory.mktemp("gomp") / "gomp_parity"
+    libdir, ordir = os.path.join(ROOT, "osqp-solver_amd"), os.path.join(ROOT, "oracle", "_build")
+    cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "gomp_parity.cpp"),
+           "-o", str(out), "-L" + libdir, "-lmi_osqp", "-L" + ordir, "-loracle_osqp", "-fopenmp",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath," + ordir]
+    subprocess.run(cmd, check=True)
+    return str(out)
+
+
+def test_reference_known_answers_for_builder_and_line(exe):
+    r = subprocess.run([exe, "kats"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "KATS OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_sqp_driver_on_oracle_backend(exe):
+    r = subprocess.run([exe, "oracle"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].startswith("obstacle=0 kOptimal segments 10 solves 10 updates 0")
+    assert lines[1].startswith("obstacle=1 kOptimal segments 10") and "updates 0" not in lines[1]
+
+
+@pytest.mark.gpu
+def test_gomp_driver_gpu_matches_oracle_backend(exe):
+    r = subprocess.run([exe, "parity"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PARITY OK" in r.stdout, r.stdout + r.stderr
