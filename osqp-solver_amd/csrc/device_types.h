@@ -31,6 +31,8 @@ struct KernelArgs {
   int *iscal;
   const int *qp_of_slot;                // slot (tile*BT + b) -> global QP id, -1 = empty (compaction during a solve)
   double *x_out, *y_out;                // QP-major [B][n], [B][m]
+  double *xs_global;                    // non-null: the solve vector lives here ([tile][xs_len][BT]) instead of LDS
+  int xs_len;                           // n + m
   // settings (row S)
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
   int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;

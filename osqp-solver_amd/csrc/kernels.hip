@@ -309,7 +309,7 @@ __device__ __forceinline__ void phase_step(const SchedDev &s, const ValSrc &vs, 
 }
 
 // One triangular solve = walk the flat phase table.
-template <int BT, int PF>
+template <int BT, int PF, bool GX>
 __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane) {
   const uint32_t stride = 4u * (uint32_t)s.nw + 1u;
   mi_cptr ph = as_const(s.phase);
@@ -325,7 +325,7 @@ __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, d
     uint32_t nb = s.zero_step, ne = s.zero_step;
     if (p + 1 < s.n_phases) { nb = e[stride]; ne = e[stride + 1]; }
     phase_step<BT, PF, true>(s, vals, xs, nullptr, pa, kind, has, nb, ne, lane);
-    lds_barrier();
+    if constexpr (GX) __syncthreads(); else lds_barrier();
   }
 }
 
@@ -421,27 +421,39 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile)
   return p;
 }
 
+// The solve vector normally lives in LDS.  For KKT systems that do not fit (N*BT*8 B > ~150 KiB, e.g.
+// the reference's own 802-waypoint example, N = 43 284) it lives in a per-tile global buffer instead:
+// same code, generic pointer, full barriers (global stores must complete before other waves read).
+// GX is a compile-time flag on purpose: a runtime-selected generic pointer would turn every access of the
+// LDS variant into FLAT instructions (which also count on vmcnt and would drain the value stream).
+template <int BT, bool GX>
+__device__ __forceinline__ double *solve_vector(const KernelArgs &a, double *smem, int tile, double *&scratch) {
+  if constexpr (GX) { scratch = smem; return a.xs_global + (size_t)tile * (a.xs_len) * BT; }
+  else { scratch = smem + (size_t)a.xs_len * BT; return smem; }
+}
+
 // K solve on the LDS vector: fwd levels, D^-1, bwd levels (row E7)
-template <int BT, int PF>
+template <int BT, int PF, bool GX>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
                                               int tid, int nthr, int wave, int nw, int lane) {
-  run_tri<BT, PF>(a.fwd, p.vfwd, xs, wave, lane);
+  run_tri<BT, PF, GX>(a.fwd, p.vfwd, xs, wave, lane);
   for (int e = tid; e < a.N * BT; e += nthr) xs[e] *= p.dinv[e];
   __syncthreads();
-  run_tri<BT, PF>(a.bwd, p.vbwd, xs, wave, lane);
+  run_tri<BT, PF, GX>(a.bwd, p.vbwd, xs, wave, lane);
 }
 
 // E6-E10 for iterations (iter_begin, iter_end] of one tile.  Lean on purpose: the
 // residual / termination / rho logic lives in check_kernel, so this kernel needs
 // little beyond the rotating prefetch buffer.
-template <int BT, int NT>
+template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
   const int n = a.n, m = a.m, N = a.N;
-  double *xs = smem;
+  double *unused_scratch;
+  double *xs = solve_vector<BT, GX>(a, smem, tile, unused_scratch);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   const int done = p.iscal[IS_DONE * BT + b];
   if (__syncthreads_and(done)) return;
@@ -458,7 +470,7 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
     }
     __syncthreads();
     // ---- E7
-    kkt_solve_lds<BT, MI_PFV>(a, p, xs, tid, nthr, wave, nw, lane);
+    kkt_solve_lds<BT, MI_PFV, GX>(a, p, xs, tid, nthr, wave, nw, lane);
     // ---- E8-E10 (run_tri ends with a barrier)
     for (int e = tid; e < n * BT; e += nthr) {
       const int i = e / BT;
@@ -483,15 +495,15 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
 
 // E11-E14 at iteration iter_end: residuals, termination and infeasibility tests,
 // rho estimate / update request, solution store.  Runs once per segment.
-template <int BT, int NT>
+template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
   const int n = a.n, m = a.m, N = a.N;
-  double *xs = smem;
-  double *red = smem + (size_t)N * BT;
+  double *red;
+  double *xs = solve_vector<BT, GX>(a, smem, tile, red);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   // global QP id of this thread's class: during a solve the QPs still iterating are
   // compacted into the leading tiles (solver.hip), so the id comes from a table
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
 // ---------------------------------------------------------- standalone ops
 
 // Px, A'y, Ax for QP-major x[B][n], y[B][m]  (rows E11 / E14)
-template <int BT, int NT>
+template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__restrict__ gx,
                                                     const double *__restrict__ gy, double *gPx,
                                                     double *gAty, double *gAx) {
@@ -688,7 +700,8 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n, m = a.m;
-  double *xs = smem;
+  double *lds_rest;
+  double *xs = solve_vector<BT, GX>(a, smem, tile, lds_rest);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   // results go to LDS when the launcher provided room for them (op_out_lds), else to the tile's global scratch
   double *res = a.op_out_lds ? smem + (size_t)(n + m) * BT : p.out1;
@@ -712,20 +725,21 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
 }
 
 // sol = K^-1 rhs for QP-major rhs[B][N]  (row E7)
-template <int BT, int NT>
+template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int N = a.N;
-  double *xs = smem;
+  double *lds_rest;
+  double *xs = solve_vector<BT, GX>(a, smem, tile, lds_rest);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   for (int bb = 0; bb < BT; bb++) {           // coalesced QP-major I/O
     const int q = tile * BT + bb;
     for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
   }
   __syncthreads();
-  kkt_solve_lds<BT, MI_PFV>(a, p, xs, tid, nthr, wave, nw, lane);
+  kkt_solve_lds<BT, MI_PFV, GX>(a, p, xs, tid, nthr, wave, nw, lane);
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
     if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
@@ -733,14 +747,15 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
 }
 
 // warm start (row E14): x <- Dinv .* x0 ; z <- A x   (QP-major x0[B][n])
-template <int BT, int NT>
+template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   const int n = a.n, m = a.m;
   const int qp = tile * BT + b;
-  double *xs = smem;
+  double *lds_rest;
+  double *xs = solve_vector<BT, GX>(a, smem, tile, lds_rest);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   for (int e = tid; e < n * BT; e += nthr) {
     double v = qp < a.B ? x0[(size_t)qp * n + e / BT] : 0.0;
@@ -1141,9 +1156,14 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
       return hipGetLastError();                                                                    \
     };                                                                                             \
     if (threads > 512) return hipErrorInvalidValue;                                                \
-    if (BT == 1) return go(&KERNEL<1, 512>);                                                       \
-    if (BT == 2) return go(&KERNEL<2, 512>);                                                       \
-    return go(&KERNEL<4, 512>);                                                                    \
+    if (a.xs_global) {                                                                             \
+      if (BT == 1) return go(&KERNEL<1, 512, true>);                                               \
+      if (BT == 2) return go(&KERNEL<2, 512, true>);                                               \
+      return go(&KERNEL<4, 512, true>);                                                            \
+    }                                                                                              \
+    if (BT == 1) return go(&KERNEL<1, 512, false>);                                                \
+    if (BT == 2) return go(&KERNEL<2, 512, false>);                                                \
+    return go(&KERNEL<4, 512, false>);                                                             \
   } while (0)
 
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {

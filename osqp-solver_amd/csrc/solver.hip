@@ -125,7 +125,8 @@ struct mi_osqp_batch {
   SchedBufs fwd, bwd, chk;
   DevBuf<uint32_t> pinv;
   DevBuf<double> fwd_val, bwd_val, chk_val, dinv, x, z, y, q, l, u, rho_vec, rho_inv, Dsc, Dsc_inv, Esc, Esc_inv;
-  DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out;
+  DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out, xs_global;
+  bool global_xs = false;
   DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
   DevBuf<int> iscal, qp_of_slot, flag, npos;
   DevBuf<int2> pairs;
@@ -186,6 +187,7 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
+  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.N;
   const Settings &s = h->st;
   a.sigma = s.sigma; a.alpha = s.alpha; a.eps_abs = s.eps_abs; a.eps_rel = s.eps_rel;
   a.eps_prim_inf = s.eps_prim_inf; a.eps_dual_inf = s.eps_dual_inf; a.rho_tolerance = s.adaptive_rho_tolerance;
@@ -397,8 +399,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const char *eth = getenv("MI_OSQP_THREADS");
     h->threads = eth ? std::max(64, std::min(512, atoi(eth) / 64 * 64)) : 512;
   }
-  if (2 * (n + m) >= 65535) {
-    g_last_error = "KKT dimension too large for the LDS-resident solve vector / 16-bit gather indices";
+  if (n + m >= 65535 || 2 * n + m >= 65535) {
+    g_last_error = "KKT dimension too large for 16-bit gather / row indices (n + m and 2n + m must stay below 65535)";
     return MI_OSQP_ERR_ALLOC;
   }
   // ---- tile shape (needed by the schedule layout)
@@ -411,10 +413,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   }
   const size_t lds_cap = 160 * 1024;
   while (BT > 1 && lds_bytes((int)(n + m), BT, h->threads) > lds_cap) BT /= 2;
-  if (lds_bytes((int)(n + m), BT, h->threads) > lds_cap) {
-    g_last_error = "KKT dimension too large for the LDS-resident solve vector (n+m <= ~20000 supported)";
-    return MI_OSQP_ERR_ALLOC;
-  }
+  // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
+  h->global_xs = lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
   int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT);
   if (rc) return rc;
   const Analysis &an = h->an;
@@ -428,7 +428,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_last_error = std::string("device is not gfx950: ") + prop.gcnArchName; return MI_OSQP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
-  h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT); h->lds = lds_bytes(an.N, BT, h->threads);
+  h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT);
+  h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.N, BT, h->threads);
   // ---- device arrays
   size_t T = (size_t)h->ntiles * BT;
   if ((rc = h->fwd.upload(an.fwd)) || (rc = h->bwd.upload(an.bwd)) || (rc = h->chk.upload(an.chk))) return rc;
@@ -438,6 +439,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
+  if (h->global_xs) { ALLOC(xs_global, an.N); }
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
   {
@@ -915,7 +917,7 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
   size_t lds = (size_t)(h->an.N + 2 * h->an.n + h->an.m) * h->BT * sizeof(double);
-  a.op_out_lds = lds <= 160 * 1024;
+  a.op_out_lds = !h->global_xs && lds <= 160 * 1024;
   if (!a.op_out_lds) lds = h->lds;
   HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
   HIPCHK(hipStreamSynchronize(s));

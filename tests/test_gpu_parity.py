@@ -347,7 +347,42 @@ def test_config5_style_structured_sparse_qp():
 
 
 def test_too_large_problem_is_refused_loudly():
-    pr = PR.grid_qp(100)          # N = 29 800 > LDS-resident limit
+    pr = PR.grid_qp(150)          # N = 89 700: beyond the 16-bit gather / row indices
     with pytest.raises(M.MiOsqpError) as e:
         M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
     assert e.value.code == 7
+
+
+def test_global_solve_vector_mode_small(monkeypatch):
+    """Same kernels with the solve vector in a per-tile global buffer (used when N*8 B exceeds LDS)."""
+    monkeypatch.setenv("MI_OSQP_GLOBAL_XS", "1")
+    pr = PR.random_box_qp(5, n=96, mg=64, nnz_per_row=6)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    info = s.solve()
+    _compare(info, s.primal(), _oracle_batch(pr, range(5)), range(5))
+    pr = PR.gomp_batch(2, 4, 12)
+    s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
+    s.warm_start_x(pr["warm"])
+    info = s.solve()
+    ref = []
+    for b in range(2):
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, None, A, pr["l"][b], pr["u"][b]); o.set_warm_start(pr["warm"][b])
+        st, x = o.solve(); ref.append((st, x, o.info(), o))
+    _compare(info, s.primal(), ref, range(2))
+
+
+def test_reference_example_horizon_802_waypoints():
+    """The reference's own example size ([REF] examples/solver-example.cpp:12-16: D=6, W=802 ->
+    n=9624, m=33660, N=43284) does not fit LDS: it runs in the global-solve-vector mode."""
+    D, W = 6, 802
+    P, (l, A, u), warm = PR.gomp_qp(D, W, np.zeros(D), np.array([np.pi, 0, 0, 0, 0, 0]))
+    assert A.shape == (33660, 9624)
+    s = M.QPSolver((l, A, u), P)
+    st = s.stats()
+    assert st["N"] == 43284
+    o = O.OracleQPSolver(P, None, A, l, u)
+    s.setWarmStart(warm); o.set_warm_start(warm)
+    code, x = s.solve(); sto, xo = o.solve()
+    assert code == ST2EXIT[sto] and s.info().iter == o.info().iter
+    assert np.max(np.abs(x - xo)) <= TOL_X
