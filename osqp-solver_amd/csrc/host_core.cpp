@@ -627,6 +627,14 @@ static void build_block_factor(Analysis &an) {
     auto &uts = ut_of_level[L];
     std::stable_sort(uts.begin(), uts.end(), [](const UT &a, const UT &b) { return a.te - a.tb > b.te - b.tb; });
     for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.tm, u.te});
+    if (getenv("MI_OSQP_DEBUG_ORDER") && !uts.empty()) {
+      // critical path of the U step with round-robin assignment to 16 waves (rank-1 batches of 8, general triples)
+      std::vector<double> wv(16, 0.0);
+      size_t r1 = 0, gen = 0;
+      for (size_t k = 0; k < uts.size(); k++) { wv[k % 16] += (uts[k].tm - uts[k].tb + 7) / 8 * 1.0 + (uts[k].te - uts[k].tm) * 1.5; r1 += uts[k].tm - uts[k].tb; gen += uts[k].te - uts[k].tm; }
+      fprintf(stderr, "[mi_osqp] factor level %d: %zu update tasks, rank-1 triples %zu, general %zu, biggest task %u, modelled path %.0f units (ideal %.0f)\n",
+              L, uts.size(), r1, gen, uts[0].te - uts[0].tb, *std::max_element(wv.begin(), wv.end()), (r1 / 8.0 + gen * 1.5) / 16);
+    }
     for (int J : cols_of_level[L])
       for (const auto &[I, id] : colblk[J]) {
         if (I == J) bf.dtask.push_back(id);

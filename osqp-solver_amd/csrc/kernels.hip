@@ -787,84 +787,94 @@ __device__ __forceinline__ void wave_sync() {
 template <int BT>
 __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, const double *Dl, double *Ss,
                                            uint32_t t, int lane) {
+  // lane = (h, i, b): i = row of the <=16-row target block, b = QP of the tile, and h splits the
+  // source work (the k range of a source block / the members of a rank-1 batch) over the 64/(16*BT)
+  // lane groups that would otherwise idle; the partial results are summed at the end.
+  // (Software-pipelining the operand loads across batches was tried: it spills at 128 VGPRs and is slower.)
+  constexpr int H = 64 / (MI_CHUNK * BT);
   mi_cptr ut = as_const(a.utask) + 4 * (size_t)t;
   mi_cptr blk = as_const(a.blk);
   mi_cptr tri = as_const(a.tri);
   const uint32_t tid_blk = ut[0], q0 = ut[1], qm = ut[2], q1 = ut[3];
   const uint32_t off = blk[4 * tid_blk], hw = blk[4 * tid_blk + 3], h = hw >> 8, w = hw & 255u;
-  const int i = lane / BT, b = lane % BT;
-  const bool inw = lane < MI_CHUNK * BT;
-  const bool row_ok = (uint32_t)i < h && inw;
+  const int hh = lane / (MI_CHUNK * BT), i = (lane / BT) % MI_CHUNK, b = lane % BT;
+  const bool row_ok = (uint32_t)i < h;
   double acc[MI_CHUNK];
 #pragma unroll
-  for (int j = 0; j < MI_CHUNK; j++) acc[j] = (row_ok && (uint32_t)j < w) ? Lb[((size_t)off + j * h + i) * BT + b] : 0.0;
-  // ---- rank-1 sources (one-column chunks), 8 per batch: all operand loads of a batch
-  // are in flight together, the 8 scaled B columns go through wave-private LDS
+  for (int j = 0; j < MI_CHUNK; j++) acc[j] = (hh == 0 && row_ok && (uint32_t)j < w) ? Lb[((size_t)off + j * h + i) * BT + b] : 0.0;
+  // ---- rank-1 sources (one-column chunks), 8 per batch: all operand loads of a batch are in flight
+  // together, the 8 scaled B columns go through wave-private LDS; group hh applies members g = hh mod H
   constexpr int G = 8;
   for (uint32_t q = q0; q < ((a.debug_skip & 1) ? q0 : qm); q += G) {
-    double av[G], bv[G];
+    double av[G / H], bv[G / H];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      av[g] = 0.0; bv[g] = 0.0;
+    for (int gg = 0; gg < G / H; gg++) {
+      const int g = gg * H + hh;
+      av[gg] = 0.0; bv[gg] = 0.0;
       if (q + g < qm) {
         const uint32_t ia = tri[2 * (q + g)], ib = tri[2 * (q + g) + 1];
         const uint32_t ao = blk[4 * ia], ah = blk[4 * ia + 3] >> 8, kc0 = blk[4 * ia + 2];
         const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
-        if ((uint32_t)i < ah && inw) av[g] = Lb[((size_t)ao + i) * BT + b];
-        if ((uint32_t)i < bh && inw) bv[g] = Lb[((size_t)bo + i) * BT + b] * Dl[(size_t)kc0 * BT + b];
+        if ((uint32_t)i < ah) av[gg] = Lb[((size_t)ao + i) * BT + b];
+        if ((uint32_t)i < bh) bv[gg] = Lb[((size_t)bo + i) * BT + b] * Dl[(size_t)kc0 * BT + b];
       }
     }
-    if (inw) {
 #pragma unroll
-      for (int g = 0; g < G; g++) Ss[MI_BS(g, b, i)] = bv[g];
-    }
+    for (int gg = 0; gg < G / H; gg++) Ss[MI_BS(gg * H + hh, b, i)] = bv[gg];
     wave_sync();
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(g, b, 0)]);
+    for (int gg = 0; gg < G / H; gg++) {
+      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(gg * H + hh, b, 0)]);
 #pragma unroll
       for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
         const double2 bvv = bs[j2];
-        acc[2 * j2] = fma(-av[g], bvv.x, acc[2 * j2]);
-        acc[2 * j2 + 1] = fma(-av[g], bvv.y, acc[2 * j2 + 1]);
+        acc[2 * j2] = fma(-av[gg], bvv.x, acc[2 * j2]);
+        acc[2 * j2 + 1] = fma(-av[gg], bvv.y, acc[2 * j2 + 1]);
       }
     }
     wave_sync();
   }
-  // ---- general sources (width > 1)
+  // ---- general sources (width > 1): group hh handles the columns k = hh mod H
   for (uint32_t q = qm; q < ((a.debug_skip & 2) ? qm : q1); q++) {
     const uint32_t ia = tri[2 * q], ib = tri[2 * q + 1];
     const uint32_t ao = blk[4 * ia], ahw = blk[4 * ia + 3], ah = ahw >> 8, aw = ahw & 255u, kc0 = blk[4 * ia + 2];
     const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
-    // all operand loads of the triple are issued up front (fixed 16-way unroll, predicated):
-    // lane (i, b) needs row i of A and provides row i of (B .* d) to the wave through LDS
-    const bool brow = (uint32_t)i < bh && inw, arow = (uint32_t)i < ah && inw;
-    double avk[MI_CHUNK], bvk[MI_CHUNK];
+    // all operand loads of the triple are issued up front (fixed unroll, predicated):
+    // lane (hh, i, b) needs A[i, k] and provides (B .* d)[i, k] for its columns k
+    const bool brow = (uint32_t)i < bh, arow = (uint32_t)i < ah;
+    double avk[MI_CHUNK / H], bvk[MI_CHUNK / H];
 #pragma unroll
-    for (int k = 0; k < MI_CHUNK; k++) {
-      avk[k] = (arow && (uint32_t)k < aw) ? Lb[((size_t)ao + k * ah + i) * BT + b] : 0.0;
-      bvk[k] = (brow && (uint32_t)k < aw) ? Lb[((size_t)bo + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b] : 0.0;
+    for (int kk = 0; kk < MI_CHUNK / H; kk++) {
+      const uint32_t k = (uint32_t)(kk * H + hh);
+      avk[kk] = (arow && k < aw) ? Lb[((size_t)ao + k * ah + i) * BT + b] : 0.0;
+      bvk[kk] = (brow && k < aw) ? Lb[((size_t)bo + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b] : 0.0;
     }
-    if (inw) {
 #pragma unroll
-      for (int k = 0; k < MI_CHUNK; k++) Ss[MI_BS(k, b, i)] = bvk[k];
-    }
+    for (int kk = 0; kk < MI_CHUNK / H; kk++) Ss[MI_BS(kk * H + hh, b, i)] = bvk[kk];
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < MI_CHUNK; k++) {
-      if ((uint32_t)k < aw) {
-        const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(k, b, 0)]);
+    for (int kk = 0; kk < MI_CHUNK / H; kk++) {
+      if ((uint32_t)(kk * H) < aw) {          // uniform over the wave (some groups may run one zero column extra)
+        const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(kk * H + hh, b, 0)]);
 #pragma unroll
         for (int j2 = 0; j2 < MI_CHUNK / 2; j2++) {
           const double2 bvv = bs[j2];
-          acc[2 * j2] = fma(-avk[k], bvv.x, acc[2 * j2]);
-          acc[2 * j2 + 1] = fma(-avk[k], bvv.y, acc[2 * j2 + 1]);
+          acc[2 * j2] = fma(-avk[kk], bvv.x, acc[2 * j2]);
+          acc[2 * j2 + 1] = fma(-avk[kk], bvv.y, acc[2 * j2 + 1]);
         }
       }
     }
     wave_sync();
   }
-  if (row_ok) {
+  // ---- combine the H partial results
+  if constexpr (H > 1) {
+#pragma unroll
+    for (int j = 0; j < MI_CHUNK; j++) {
+      if constexpr (H == 4) acc[j] += shfl_xor_d(acc[j], 16);
+      acc[j] += shfl_xor_d(acc[j], 32);
+    }
+  }
+  if (hh == 0 && row_ok) {
 #pragma unroll
     for (int j = 0; j < MI_CHUNK; j++) if ((uint32_t)j < w) Lb[((size_t)off + j * h + i) * BT + b] = acc[j];
   }
