@@ -216,6 +216,14 @@ int mi_osqp_debug_host_block_factor(int64_t n, int64_t m,
                                     const double *l, const double *u, const mi_osqp_settings *settings,
                                     double *max_rel_diff_L, double *max_rel_diff_Dinv, int64_t *counts);
 
+/* Device diagnostics (tile 2, LDS mode only): one KKT solve of the whole batch with
+ * per-phase / per-wave shader-clock stamps of two tiles (first, middle).
+ * which = 0: run the traced solve; trace receives 2 * dims[3] words (see kkt_trace_kernel).
+ * which = 1 / 2: copy the forward / backward phase table (dims[0|1] rows of 4*dims[2]+1 words) instead.
+ * dims[4] = {forward phases, backward phases, waves per tile, trace words per tile}. */
+int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double *d_rhs, double *d_sol,
+                                  uint32_t *out, int64_t out_capacity_words, int64_t *dims);
+
 #ifdef __cplusplus
 }
 #endif

@@ -289,6 +289,25 @@ class BatchSolver:
         _chk(lib().mi_osqp_batch_spmv(self._h, p(x), p(y), p(Px), p(Aty), p(Ax),
                                       None if stream is None else C.c_void_p(stream)), "spmv")
 
+    def debug_trace_kkt_solve(self, rhs, sol):
+        """Diagnostics (tile 2 only): returns (stamps[2 tiles], fwd phase table, bwd phase table, dims)."""
+        import numpy as np
+        L = lib()
+        L.mi_osqp_debug_trace_kkt_solve.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                    C.POINTER(C.c_int64)]
+        dims = (C.c_int64 * 4)()
+        _chk(L.mi_osqp_debug_trace_kkt_solve(self._h, 0, None, None, None, 0, dims), "trace dims")
+        fp, bp, nw, words = (int(v) for v in dims)
+        tr = np.zeros(2 * words, dtype=np.uint32)
+        _chk(L.mi_osqp_debug_trace_kkt_solve(self._h, 0, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()),
+                                             tr.ctypes.data_as(C.c_void_p), tr.size, dims), "trace")
+        tabs = []
+        for which, rows in ((1, fp), (2, bp)):
+            t = np.zeros(rows * (4 * nw + 1), dtype=np.uint32)
+            _chk(L.mi_osqp_debug_trace_kkt_solve(self._h, which, None, None, t.ctypes.data_as(C.c_void_p), t.size, dims), "trace table")
+            tabs.append(t.reshape(rows, 4 * nw + 1))
+        return tr.reshape(2, words), tabs[0], tabs[1], (fp, bp, nw, words)
+
     def kkt_solve_device(self, rhs, sol, stream=None):
         _chk(lib().mi_osqp_batch_kkt_solve(self._h, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()),
                                            None if stream is None else C.c_void_p(stream)), "kkt_solve")

@@ -9,9 +9,11 @@ namespace miosqp {
 
 // device view of one host_core.hpp Schedule (tables are shared by all tiles)
 struct SchedDev {
-  const uint32_t *phase, *step, *idxw, *bstep0;
-  int n_phases, nw, sb;
-  uint32_t n_steps, phys_steps, zero_step, n_slots;
+  const uint32_t *step, *idxw;          // per step: descriptor (sched_format.h); per slot: index word
+  const uint32_t *bstep0, *bsteps;      // per block task: first step, number of steps
+  const uint32_t *lvl_pos, *tail_bar;   // (n_levels+1) x nw stream positions; per wave: barriers owed after the last step
+  int n_phases, nw, n_levels;
+  uint32_t n_steps, n_slots;
 };
 
 // per-QP double scalars, laid out [tile][DS_COUNT][BT]
@@ -39,7 +41,6 @@ struct KernelArgs {
   int iter_begin, iter_end;             // this launch runs iterations (iter_begin, iter_end]
   int op_out_lds;                       // spmv op: results staged in LDS (the launcher sized it)
   int info_at_end;                      // a check_kernel follows: store delta_x / delta_y of the last iteration
-  int chk_lvl[4];                       // first phase of the P x / A'y / A x levels of the check schedule (+ end)
 };
 
 // device block refactorisation (row E13); tables are host_core.hpp BlockFactor
@@ -64,6 +65,8 @@ hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size
                        const double *x, const double *y, double *Px, double *Aty, double *Ax);
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                             const double *rhs, double *sol);
+hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                            const double *rhs, double *sol, uint32_t *trace, uint32_t words);
 hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                              const double *x0);
 hipError_t launch_interleave(const double *src, double *dst, const int *ids, int nq, int len, int BT, hipStream_t st);

@@ -1,6 +1,7 @@
 // host_core.cpp -- see host_core.hpp.  Citations: [REF] = /root/reference,
 // "row Ex" = SURVEY.md section 8(a).
 #include "host_core.hpp"
+#include "sched_format.h"
 
 #include <algorithm>
 #include <cmath>
@@ -270,19 +271,21 @@ struct LevelWork { std::vector<RowWork> rowsA; std::vector<BlockWork> blocksB; }
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt) {
+// Builds one schedule.  Work is first laid out as phases (per level: one A phase of row steps spread over
+// the waves, then B phases with at most one block task per wave); the steps are then numbered WAVE-MAJOR:
+// wave w's steps of all phases are contiguous in memory and form the linear stream the device walks
+// (sched_format.h); phase boundaries survive only as barrier counts in the descriptors.
+void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers) {
   sch = Schedule();
   sch.n_levels = (int)levels.size();
-  sch.nw = nw; sch.bt = bt; sch.sb = (kChunk - 1 + bt - 1) / bt;
+  sch.nw = nw; sch.bt = bt; sch.barriers = barriers;
   // a unit = work that must stay on one wave, in order
   struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; };
   struct Unit { std::vector<StepSpec> steps; };
-  // step 0 is the all-zero padding step: empty ranges point at it
-  sch.zero_step = 0; sch.n_steps = 1;
-  sch.idx.assign(64, 0u); sch.src.assign(64, -1); sch.step.push_back(0u);
-  struct PhaseRec { int kind; std::vector<uint32_t> wave; };   // wave: 4 per wave
+  struct StepRec { uint32_t type = MI_D_TYPE_ROW; StepSpec a; uint32_t task = 0, s = 0; bool first = false, last = false; };
+  struct PhaseRec { int kind; std::vector<std::vector<StepRec>> wave; };
   std::vector<PhaseRec> phases;
-  std::vector<std::vector<const BlockWork *>> level_blocks(levels.size());
+  std::vector<const BlockWork *> tasks;                 // block tasks in processing order
   for (size_t L = 0; L < levels.size(); L++) {
     const LevelWork &lw = levels[L];
     sch.level_first_phase.push_back((int)phases.size());
@@ -339,98 +342,128 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
         load[w] += (int)units[k].steps.size();
         mine[w].push_back(k);
       }
-      PhaseRec ph; ph.kind = 0;
-      for (int w = 0; w < nw; w++) {
-        uint32_t begin = sch.n_steps;
+      PhaseRec ph; ph.kind = 0; ph.wave.resize(nw);
+      for (int w = 0; w < nw; w++)
         for (size_t k : mine[w])
-          for (const StepSpec &st : units[k].steps) {
-            uint32_t stepno = sch.n_steps++;
-            uint32_t base = stepno * 64u;
-            sch.idx.resize((size_t)sch.n_steps * 64, 0u);
-            sch.src.resize((size_t)sch.n_steps * 64, -1);
-            int T = 1 << st.lt;
-            for (int g = 0; g < (int)st.rows.size(); g++) {
-              const auto &ent = st.rows[g]->ent;
-              for (int e = st.first_entry; e < std::min<int>((int)ent.size(), st.first_entry + T); e++) {
-                uint32_t slot = base + (uint32_t)(g * T + (e - st.first_entry));
-                sch.idx[slot] = ent[e].first; sch.src[slot] = ent[e].second;
-              }
-            }
-            uint32_t ob = 0;
-            if (st.flush) {
-              ob = (uint32_t)sch.outA.size();
-              for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
-            }
-            sch.step.push_back((uint32_t)st.lt | ((uint32_t)st.flush << 3) | (ob << 4));
-          }
-        uint32_t end = sch.n_steps;
-        if (end == begin) begin = end = sch.zero_step;
-        ph.wave.insert(ph.wave.end(), {begin, end, 0u, 0u});
-      }
+          for (StepSpec &st : units[k].steps) { StepRec r; r.a = std::move(st); ph.wave[w].push_back(std::move(r)); }
       phases.push_back(std::move(ph));
     }
-    // block tasks: at most one per wave per B phase
+    // block tasks: at most one per wave per B phase; a task of r rows owns ceil((r-1)/bt) steps
     std::vector<const BlockWork *> blks;
     for (const BlockWork &bw : lw.blocksB) if (bw.rows.size() >= 2) blks.push_back(&bw);
-    level_blocks[L] = blks;
     for (size_t i = 0; i < blks.size(); i += nw) {
-      PhaseRec ph; ph.kind = 1;
-      for (int w = 0; w < nw; w++) {
-        if (i + w < blks.size()) ph.wave.insert(ph.wave.end(), {0xFFFFFFFFu, (uint32_t)(i + w), (uint32_t)L, 0u});   // patched below
-        else ph.wave.insert(ph.wave.end(), {sch.zero_step, sch.zero_step, 0u, 0u});
+      PhaseRec ph; ph.kind = 1; ph.wave.resize(nw);
+      for (int w = 0; w < nw && i + w < blks.size(); w++) {
+        const uint32_t task = (uint32_t)tasks.size();
+        tasks.push_back(blks[i + w]);
+        const int ns = ((int)blks[i + w]->rows.size() - 1 + bt - 1) / bt;
+        for (int s2 = 0; s2 < ns; s2++) {
+          StepRec r; r.type = MI_D_TYPE_BLOCK; r.task = task; r.s = (uint32_t)s2; r.first = s2 == 0; r.last = s2 == ns - 1;
+          ph.wave[w].push_back(std::move(r));
+        }
       }
       phases.push_back(std::move(ph));
     }
   }
   sch.level_first_phase.push_back((int)phases.size());
-  // logical slots / physical steps of the block tasks (after all A steps)
-  sch.n_slots = sch.n_steps * 64u;
-  std::vector<std::vector<uint32_t>> task_of(levels.size());
-  sch.bstep0.push_back(sch.n_steps);
-  for (size_t L = 0; L < levels.size(); L++)
-    for (const BlockWork *bw : level_blocks[L]) {
-      uint32_t task = sch.n_taskB++;
-      task_of[L].push_back(task);
-      int r = (int)bw->rows.size();
-      sch.bstep0.push_back(sch.bstep0.back() + (uint32_t)((r - 1 + bt - 1) / bt));
-      uint32_t base = sch.n_slots;
-      sch.n_slots += (uint32_t)(kChunk * (kChunk - 1));
-      sch.src.resize(sch.n_slots, -1);
-      for (int p = 0; p < r - 1; p++)
-        for (int i = p + 1; i < r; i++) sch.src[base + p * kChunk + i] = bw->tri[p * r + i];
-      for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < r ? bw->rows[i] : kNoRow);
-    }
-  // device index words
-  sch.idxw.assign((size_t)sch.phys_steps() * 64, 0xFFFF0000u);
-  for (uint32_t st = 0; st < sch.n_steps; st++) {
-    const uint32_t d = sch.step[st], lt = d & 7u, flush = (d >> 3) & 1u, ob = d >> 4;
-    for (uint32_t ln = 0; ln < 64; ln++) {
-      uint32_t row = 0xFFFFu;
-      if (flush) { uint32_t r = sch.outA[ob + (ln >> lt)]; row = r == kNoRow ? 0xFFFFu : r; }
-      sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
-    }
-  }
-  for (uint32_t task = 0; task < sch.n_taskB; task++)
-    for (int i = 0; i < kChunk; i++)
-      for (int b = 0; b < bt; b++) {
-        uint32_t r = sch.outB[task * kChunk + i];
-        sch.idxw[(size_t)sch.bstep0[task] * 64 + i * bt + b] = (r == kNoRow ? 0xFFFFu : r) << 16;
-      }
-  if (getenv("MI_OSQP_DEBUG_ORDER"))
-    fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu A-steps %u block tasks %u (x%d steps) outA %zu\n", levels.size(),
-            phases.size(), sch.n_steps, sch.n_taskB, sch.sb, sch.outA.size());
   sch.n_phases = (int)phases.size();
-  for (PhaseRec &ph : phases) {
-    sch.phase.push_back((uint32_t)ph.kind);
-    for (int w = 0; w < nw; w++) {
-      uint32_t *e = &ph.wave[4 * w];
-      if (ph.kind == 1 && e[0] == 0xFFFFFFFFu) {
-        uint32_t task = task_of[e[2]][e[1]];
-        e[0] = sch.bstep0[task]; e[1] = sch.bstep0[task + 1]; e[2] = task * kChunk; e[3] = 1u;
+  sch.n_taskB = (uint32_t)tasks.size();
+  sch.bstep0.assign(tasks.size() + 1, 0u);
+  for (const BlockWork *bw : tasks)
+    for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < (int)bw->rows.size() ? bw->rows[i] : kNoRow);
+  // ---- wave-major numbering
+  sch.phase.assign((size_t)sch.n_phases * sch.phase_stride(), 0u);
+  sch.lvl_pos.assign((size_t)(levels.size() + 1) * nw, 0u);
+  sch.tail_bar.assign(nw, 0u);
+  sch.wave_range.assign(2 * (size_t)nw, 0u);
+  for (int w = 0; w < nw; w++) {
+    sch.wave_range[2 * w] = sch.n_steps;
+    int last_phase = 0;        // phase of the wave's previous step: barriers owed = phase boundaries crossed since
+    size_t L = 0;
+    for (int p = 0; p < sch.n_phases; p++) {
+      while (L < levels.size() && sch.level_first_phase[L] == p) sch.lvl_pos[L++ * nw + w] = sch.n_steps;   // (empty levels share a phase index)
+      uint32_t *e = &sch.phase[(size_t)p * sch.phase_stride() + 1 + 4 * w];
+      sch.phase[(size_t)p * sch.phase_stride()] = (uint32_t)phases[p].kind;
+      e[0] = sch.n_steps;
+      std::vector<StepRec> &recs = phases[p].wave[w];
+      for (size_t k = 0; k < recs.size(); k++) {
+        const StepRec &r = recs[k];
+        const uint32_t stepno = sch.n_steps++;
+        sch.idx.resize((size_t)sch.n_steps * 64, 0u);
+        sch.src.resize((size_t)sch.n_steps * 64, -1);
+        uint32_t nbar = 0;
+        if (barriers && k == 0) { nbar = (uint32_t)(p - last_phase); last_phase = p; }
+        uint32_t d = nbar << 12, ob = 0;
+        if (r.type == MI_D_TYPE_ROW) {
+          const StepSpec &st = r.a;
+          const int T = 1 << st.lt;
+          for (int g = 0; g < (int)st.rows.size(); g++) {
+            const auto &ent = st.rows[g]->ent;
+            for (int en = st.first_entry; en < std::min<int>((int)ent.size(), st.first_entry + T); en++) {
+              const uint32_t slot = stepno * 64u + (uint32_t)(g * T + (en - st.first_entry));
+              sch.idx[slot] = ent[en].first; sch.src[slot] = ent[en].second;
+            }
+          }
+          if (st.flush) {
+            ob = (uint32_t)sch.outA.size();
+            for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
+            d |= MI_D_FLUSH;
+          }
+          d |= (uint32_t)st.lt;
+        } else {
+          if (r.first) { sch.bstep0[r.task] = stepno; e[2] = r.task * kChunk; e[3] = 1u; }
+          d |= (MI_D_TYPE_BLOCK << 4) | (r.s << 6) | (r.first ? MI_D_FIRST : 0u) | (r.last ? MI_D_LAST : 0u);
+          ob = r.task;
+        }
+        sch.step.push_back(d);
+        sch.step_ob.push_back(ob);
       }
-      sch.phase.insert(sch.phase.end(), e, e + 4);
+      e[1] = sch.n_steps;
+    }
+    while (L < levels.size()) sch.lvl_pos[L++ * nw + w] = sch.n_steps;
+    sch.lvl_pos[levels.size() * nw + w] = sch.n_steps;
+    sch.wave_range[2 * w + 1] = sch.n_steps;
+    // every wave passes exactly n_phases barriers per walk (the last one publishes the final phase)
+    sch.tail_bar[w] = barriers ? (uint32_t)(sch.n_phases - last_phase) : 0u;
+  }
+  // bstep0[task + 1] is only used as "end of the task's steps": tasks are numbered in phase order but laid
+  // out wave-major, so keep an explicit count instead
+  sch.bsteps.assign(tasks.size(), 0u);
+  for (size_t t = 0; t < tasks.size(); t++) sch.bsteps[t] = (uint32_t)(((int)tasks[t]->rows.size() - 1 + bt - 1) / bt);
+  // logical slots of the block tasks (after the per-step slots)
+  sch.n_slots = sch.n_steps * 64u;
+  for (size_t t = 0; t < tasks.size(); t++) {
+    const BlockWork *bw = tasks[t];
+    const int r = (int)bw->rows.size();
+    const uint32_t base = sch.n_slots;
+    sch.n_slots += (uint32_t)(kChunk * (kChunk - 1));
+    sch.src.resize(sch.n_slots, -1);
+    for (int p = 0; p < r - 1; p++)
+      for (int i = p + 1; i < r; i++) sch.src[base + p * kChunk + i] = bw->tri[p * r + i];
+  }
+  // device index words
+  sch.idxw.assign((size_t)sch.n_steps * 64, 0xFFFF0000u);
+  for (uint32_t st = 0; st < sch.n_steps; st++) {
+    const uint32_t d = sch.step[st];
+    if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
+      const uint32_t lt = MI_D_LT(d), ob = sch.step_ob[st];
+      for (uint32_t ln = 0; ln < 64; ln++) {
+        uint32_t row = 0xFFFFu;
+        if (d & MI_D_FLUSH) { uint32_t r = sch.outA[ob + (ln >> lt)]; row = r == kNoRow ? 0xFFFFu : r; }
+        sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
+      }
+    } else {
+      const uint32_t task = sch.step_ob[st];
+      for (int i = 0; i < kChunk; i++)
+        for (int b = 0; b < bt; b++) {
+          uint32_t r = sch.outB[task * kChunk + i];
+          sch.idxw[(size_t)st * 64 + i * bt + b] = (r == kNoRow ? 0xFFFFu : r) << 16;
+        }
     }
   }
+  if (getenv("MI_OSQP_DEBUG_ORDER"))
+    fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu steps %u block tasks %u outA %zu\n", levels.size(),
+            phases.size(), sch.n_steps, sch.n_taskB, sch.outA.size());
 }
 }  // namespace
 
@@ -466,7 +499,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
       }
       if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
-    pack_schedule(lw, an.fwd, nw, bt);
+    pack_schedule(lw, an.fwd, nw, bt, true);
   }
   // ---- backward: columns descending, sources are rows j > column
   {
@@ -494,7 +527,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
       }
       if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
-    pack_schedule(lw, an.bwd, nw, bt);
+    pack_schedule(lw, an.bwd, nw, bt, true);
   }
 }
 
@@ -519,7 +552,7 @@ static void build_chk_schedule(Analysis &an, int nw, int bt) {
       ax[r].ent.push_back({(uint32_t)c, nnzP + k});
     }
   lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
-  pack_schedule(lw, an.chk, nw, bt);
+  pack_schedule(lw, an.chk, nw, bt, false);
 }
 
 // ------------------------------------------------ block factor (device refactor)
@@ -968,69 +1001,90 @@ void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs
 
 size_t phys_index(const Schedule &s, uint32_t slot, int b) {
   const uint32_t nA = s.n_steps * 64u;
-  if (slot < nA) return (size_t)slot * s.bt + b;
+  if (slot < nA) return MI_D_TYPE(s.step[slot >> 6]) == MI_D_TYPE_BLOCK ? (size_t)-1 : (size_t)slot * s.bt + b;
   const uint32_t r = slot - nA, task = r / (kChunk * (kChunk - 1)), rem = r % (kChunk * (kChunk - 1));
   const uint32_t k = rem / kChunk, i = rem % kChunk;
-  if (k / s.bt >= s.bstep0[task + 1] - s.bstep0[task]) return (size_t)-1;
+  if (k / s.bt >= s.bsteps[task]) return (size_t)-1;
   return ((size_t)(s.bstep0[task] + k / s.bt) * 64 + (size_t)i * s.bt + b) * s.bt + k % s.bt;
 }
 
-// sequential interpreter of one schedule (tests): walks the phase table exactly as the device does
-static void replay(const Schedule &s, const double *canon, double *xs, bool subtract, double *out) {
-  const size_t stride = s.phase_stride();
+// Sequential interpreter of one schedule (tests): every wave walks its stream exactly as the device does;
+// waves are interleaved epoch by epoch (epoch = number of barriers passed).  Returns false when the streams
+// are not race-free / deadlock-free: barrier totals differ between waves, or within one epoch an entry of the
+// solve vector is gathered and written, or written twice (the only read allowed next to a write is the
+// writer's own read-modify-write) -- this is also what lets the device issue gathers ahead of flushes.
+static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs_len, bool subtract, double *out) {
   const uint32_t nA = s.n_steps * 64u;
-  for (int ph = 0; ph < s.n_phases; ph++) {
-    const uint32_t *pr = &s.phase[ph * stride];
-    const uint32_t kind = pr[0];
-    for (int w = 0; w < s.nw; w++) {
-      const uint32_t *e = pr + 1 + 4 * w;
-      if (kind == 0) {
-        double acc[64];
-        for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
-        for (uint32_t st = e[0]; st < e[1]; st++) {
-          const uint32_t d = s.step[st], lt = d & 7u, flush = (d >> 3) & 1u, ob = d >> 4, T = 1u << lt;
+  const int nw = s.nw;
+  std::vector<uint32_t> pos(nw), epoch(nw, 0u);
+  for (int w = 0; w < nw; w++) pos[w] = s.wave_range[2 * w];
+  std::vector<int64_t> wr_epoch(subtract ? xs_len : 0, -1), rd_epoch(subtract ? xs_len : 0, -1);
+  std::vector<std::vector<double>> acc(nw, std::vector<double>(64, 0.0)), accb(nw, std::vector<double>(kChunk, 0.0));
+  bool ok = true;
+  int64_t cur = 0;
+  auto gather = [&](uint32_t e) { if (subtract) { if (wr_epoch[e] == cur) ok = false; rd_epoch[e] = cur; } return xs[e]; };
+  auto store = [&](uint32_t e, double v) {
+    if (subtract) { if (wr_epoch[e] == cur || rd_epoch[e] == cur) ok = false; wr_epoch[e] = cur; xs[e] = v; }
+    else out[e] = v;
+  };
+  for (;; cur++) {
+    bool done = true;
+    for (int w = 0; w < nw; w++) {
+      while (pos[w] < s.wave_range[2 * w + 1]) {
+        const uint32_t st = pos[w], d = s.step[st];
+        if ((int64_t)epoch[w] + MI_D_NBAR(d) > cur) break;          // the wave waits at a barrier
+        epoch[w] += MI_D_NBAR(d);
+        if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
+          const uint32_t lt = MI_D_LT(d), T = 1u << lt;
           for (uint32_t ln = 0; ln < 64; ln++) {
-            uint32_t slot = st * 64 + ln;
-            double v = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
-            acc[ln] += v * xs[s.idx[slot]];
+            const uint32_t slot = st * 64 + ln;
+            if (s.src[slot] >= 0) acc[w][ln] += canon[s.src[slot]] * gather(s.idx[slot]);
           }
-          if (flush) {
+          if (d & MI_D_FLUSH) {
             for (uint32_t g = 0; g < 64 / T; g++) {
               double sum = 0.0;
-              for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[ln];
-              uint32_t row = s.outA[ob + g];
-              if (row != kNoRow) { if (subtract) xs[row] -= sum; else out[row] = sum; }
+              for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[w][ln];
+              const uint32_t row = s.outA[s.step_ob[st] + g];
+              if (row != kNoRow) store(row, subtract ? xs[row] - sum : sum);
             }
-            for (int ln = 0; ln < 64; ln++) acc[ln] = 0.0;
+            std::fill(acc[w].begin(), acc[w].end(), 0.0);
           }
-        }
-      } else if (e[3]) {
-        const uint32_t task = e[2] / kChunk, base = nA + task * (kChunk * (kChunk - 1));
-        double acc[kChunk];
-        uint32_t rows[kChunk];
-        for (int i = 0; i < kChunk; i++) { rows[i] = s.outB[e[2] + i]; acc[i] = rows[i] != kNoRow ? xs[rows[i]] : 0.0; }
-        for (int p = 0; p < kChunk - 1; p++) {
-          double v = acc[p];
-          for (int i = 0; i < kChunk; i++) {
-            uint32_t slot = base + p * kChunk + i;
-            double lv2 = s.src[slot] >= 0 ? canon[s.src[slot]] : 0.0;
-            acc[i] -= lv2 * v;
+        } else if (MI_D_TYPE(d) == MI_D_TYPE_BLOCK) {
+          const uint32_t task = s.step_ob[st], base = nA + task * (kChunk * (kChunk - 1));
+          const uint32_t *rows = &s.outB[task * kChunk];
+          if (d & MI_D_FIRST) for (int i = 0; i < kChunk; i++) accb[w][i] = rows[i] != kNoRow ? xs[rows[i]] : 0.0;
+          for (int kk = 0; kk < s.bt; kk++) {
+            const int p = (int)MI_D_S(d) * s.bt + kk;
+            if (p >= kChunk - 1) break;
+            const double v = accb[w][p];
+            for (int i = 0; i < kChunk; i++) {
+              const uint32_t slot = base + p * kChunk + i;
+              if (s.src[slot] >= 0) accb[w][i] -= canon[s.src[slot]] * v;
+            }
           }
+          if (d & MI_D_LAST) for (int i = 0; i < kChunk; i++) if (rows[i] != kNoRow) store(rows[i], accb[w][i]);
         }
-        for (int i = 0; i < kChunk; i++) if (rows[i] != kNoRow) xs[rows[i]] = acc[i];
+        pos[w]++;
       }
+      if (pos[w] < s.wave_range[2 * w + 1]) done = false;
     }
+    if (done) break;
+    if (cur > (int64_t)s.n_phases + 1) return false;             // some wave waits for a barrier that never comes
   }
+  if (s.barriers)
+    for (int w = 0; w < nw; w++) if (epoch[w] + s.tail_bar[w] != (uint32_t)s.n_phases) ok = false;
+  return ok;
 }
 
-void replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
+bool replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
   int N = an.N;
   std::vector<double> xs(N);
   for (int k = 0; k < N; k++) xs[k] = rhs[an.perm[k]];
-  replay(an.fwd, qp.Lx.data(), xs.data(), true, nullptr);
+  bool ok = replay(an.fwd, qp.Lx.data(), xs.data(), (size_t)N, true, nullptr);
   for (int k = 0; k < N; k++) xs[k] *= qp.Dlinv[k];
-  replay(an.bwd, qp.Lx.data(), xs.data(), true, nullptr);
+  ok = replay(an.bwd, qp.Lx.data(), xs.data(), (size_t)N, true, nullptr) && ok;
   for (int k = 0; k < N; k++) sol[an.perm[k]] = xs[k];
+  return ok;
 }
 
 int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric &qp, QPNumeric &out) {
@@ -1102,7 +1156,7 @@ void replay_spmv(const Analysis &an, const QPNumeric &qp, const double *x, const
   std::copy(x, x + n, xs.begin()); std::copy(y, y + m, xs.begin() + n);
   std::copy(qp.Pv.begin(), qp.Pv.end(), pa.begin());
   std::copy(qp.Av.begin(), qp.Av.end(), pa.begin() + qp.Pv.size());
-  replay(an.chk, pa.data(), xs.data(), false, out.data());
+  replay(an.chk, pa.data(), xs.data(), xs.size(), false, out.data());
   std::copy(out.begin(), out.begin() + n, Px);
   std::copy(out.begin() + n, out.begin() + 2 * n, Aty);
   std::copy(out.begin() + 2 * n, out.end(), Ax);

@@ -33,40 +33,43 @@ int validate_settings(const Settings &s);   // 0 ok
 
 // One pull-schedule: every target row t gets  xs[t] -= sum_k val[k] * xs[idx[k]].
 //
-// The schedule is a flat list of PHASES separated by workgroup barriers; in every
-// phase each of the nw waves owns exactly one (possibly empty) contiguous range of
-// wave-steps (64 lanes, one slot per lane).  Two kinds of phase:
-//   A  row steps.  A step carries (lt, flush, out_base): groups of T = 2^lt lanes
-//      accumulate one target row; on a flush step the groups are reduced and
-//      applied to the 64/T rows listed at out_base.  Long rows span several steps
-//      (flush on the last one), short rows are one flush step each.
-//   B  the dense in-chunk triangle of a <=16-row chunk of a supernode, solved
-//      column by column inside ONE wave (lane = (row i, QP b)); its 15 values per
-//      lane are stored in the same step format (element k of lane (i,b) is
-//      component k % BT of step k / BT), so one prefetch routine serves both kinds.
-// A wave's steps of a phase are contiguous in memory: its values stream from HBM
-// and are prefetched, unconditionally, one phase ahead.
+// Work is organised as PHASES separated by workgroup barriers (per elimination level: one A phase, then B
+// phases); in every phase each of the nw waves owns one (possibly empty) contiguous range of wave-steps
+// (64 lanes, one slot per lane).  Two kinds of step (descriptor layout: sched_format.h):
+//   row    groups of T = 2^lt lanes accumulate one target row; on a flush step the groups are reduced
+//          and applied to their rows.  Long rows span several steps (flush on the last one).
+//   block  the dense in-chunk triangle of a <=16-row chunk of a supernode, solved column by column inside
+//          ONE wave (lane = (row i, QP b)); element k of lane (i,b) is component k % BT of the task's step
+//          k / BT, so the value stream has one format.
+// Steps are numbered WAVE-MAJOR: all steps of wave 0 (phase after phase), then wave 1, ...  A wave therefore
+// walks ONE linear stream per solve, its loads run a fixed number of steps ahead regardless of phase
+// boundaries, and a phase boundary is nothing but a barrier count in the descriptor of the next step.
 //
-// Logical slots (what `src`, `idx` index): A steps: step*64 + lane; B tasks:
-// 64*n_steps + task*240 + k*16 + i.  Physical position of QP b's double inside a
-// tile: A: slot*BT + b ; B: ((bstep0[task] + k/BT)*64 + i*BT + b)*BT + k%BT for k < BT * (steps of the task).
+// Logical slots (what `src`, `idx` index): step*64 + lane for every step (block steps: no entries there);
+// block-task entries: 64*n_steps + task*240 + k*16 + i.  Physical position of QP b's double inside a tile:
+// row slot: slot*BT + b ; block entry: ((bstep0[task] + k/BT)*64 + i*BT + b)*BT + k%BT for k/BT < bsteps[task].
 struct Schedule {
-  int n_phases = 0, nw = 0, bt = 1, sb = 15;
-  std::vector<uint32_t> phase;  // per phase, stride 4*nw+1: kind(0=A,1=B) then per wave (begin, end, out_base, 0)
-  std::vector<int> level_first_phase;   // for replay/diagnostics: first phase of every level (+ end)
-  std::vector<uint32_t> step;   // per A step: lt | flush << 3 | out_base << 4
+  int n_phases = 0, nw = 0, bt = 1;
+  bool barriers = true;          // false: the check-SpMV schedule (independent rows, no barriers at all)
+  std::vector<uint32_t> phase;  // diagnostics / host replay: per phase, stride 4*nw+1: kind(0=A,1=B) then per wave (begin, end, task*16, has block)
+  std::vector<int> level_first_phase;   // first phase of every level (+ end)
+  std::vector<uint32_t> step;   // per step: descriptor (sched_format.h)
+  std::vector<uint32_t> step_ob;  // per step: row steps: first entry of outA on a flush ; block steps: task
   std::vector<uint32_t> outA;   // target rows of flush steps (64/T each), kNoRow = none
   std::vector<uint32_t> outB;   // kChunk rows per block task, processing order
-  std::vector<uint32_t> idx;    // per A slot: gather index into the LDS vector
-  std::vector<uint32_t> idxw;   // DEVICE index words, one per physical slot (phys_steps*64): low 16 bits = gather
-                                // index, high 16 bits = target row of the lane's group on flush steps / of lane
-                                // (i,b) in the first step of a block task (0xFFFF = none)
+  std::vector<uint32_t> idx;    // per row slot: gather index into the solve vector
+  std::vector<uint32_t> idxw;   // DEVICE index words, one per slot (n_steps*64): low 16 bits = gather index, high 16
+                                // bits = target row of the lane's group on flush steps / of lane (i,b) in the
+                                // steps of a block task (0xFFFF = none)
   std::vector<int32_t> src;     // per logical slot: canonical value index, -1 = structural zero
   uint32_t n_slots = 0;         // logical slots
-  uint32_t n_steps = 0;         // A steps (incl. the all-zero padding step `zero_step`)
-  uint32_t n_taskB = 0, zero_step = 0;
-  std::vector<uint32_t> bstep0;  // per block task: first physical step (n_taskB + 1 entries); a task of r rows owns ceil((r-1)/bt) steps
-  uint32_t phys_steps() const { return bstep0.empty() ? n_steps : bstep0.back(); }
+  uint32_t n_steps = 0;         // all steps (row and block)
+  uint32_t n_taskB = 0;
+  std::vector<uint32_t> bstep0, bsteps;  // per block task: first step, number of steps (= ceil((rows-1)/bt))
+  std::vector<uint32_t> wave_range;      // 2 per wave: [begin, end) of its stream
+  std::vector<uint32_t> lvl_pos;         // (n_levels+1) x nw: stream position of wave w at the start of level L
+  std::vector<uint32_t> tail_bar;        // per wave: barriers still owed after its last step (all waves pass n_phases)
+  uint32_t phys_steps() const { return n_steps; }
   size_t phase_stride() const { return 4 * (size_t)nw + 1; }
   int n_levels = 0;
 };
@@ -151,7 +154,7 @@ int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector
 // reference solve with the canonical factor (natural order in/out)
 void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
 // sequential interpreter of the device schedules (tests only; see mi_osqp.h)
-void replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
+bool replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);   // false: the streams are not race- / deadlock-free
 // host interpreter of the device block factorisation (tests only): fills Lx/Dlinv
 // of `out` from qp's scaled data and rho vector exactly as factor_kernel does
 int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric &qp, QPNumeric &out);

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "device_types.h"
+#include "sched_format.h"
 
 namespace miosqp {
 
@@ -107,11 +108,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // (host twin: host_core.cpp phys_index)
 __device__ __forceinline__ size_t phys_index(const SchedDev &s, uint32_t slot, int b, int BT) {
   const uint32_t nA = s.n_steps * 64u;
-  if (slot < nA) return (size_t)slot * BT + b;
+  if (slot < nA) return MI_D_TYPE(s.step[slot >> 6]) == MI_D_TYPE_BLOCK ? (size_t)-1 : (size_t)slot * BT + b;   // block steps are addressed through their task
   const uint32_t r = slot - nA, task = r / (MI_CHUNK * (MI_CHUNK - 1)), rem = r % (MI_CHUNK * (MI_CHUNK - 1));
   const uint32_t k = rem / MI_CHUNK, i = rem % MI_CHUNK;
   const uint32_t st0 = s.bstep0[task];
-  if (k / BT >= s.bstep0[task + 1] - st0) return (size_t)-1;      // no storage: the task has fewer rows
+  if (k / BT >= s.bsteps[task]) return (size_t)-1;      // no storage: the task has fewer rows
   return ((size_t)(st0 + k / BT) * 64 + (size_t)i * BT + b) * BT + k % BT;
 }
 
@@ -185,168 +186,141 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
   }
 }
 
-// ---- per-wave step programs with register rotation --------------------------------
-// Every wave owns one contiguous step range per phase.  Its first PF steps live in a
-// register buffer; right after step st of the CURRENT phase has been consumed, the
-// same registers are refilled with step st of the wave's NEXT-phase range.  So about
-// PF steps per wave are in flight at any time, across the LDS-only barriers, and the
-// HBM pipe never drains between phases.  No vector load other than the stream itself
-// is issued on this path (in-order VMEM would make waiting for it drain the stream):
-// tables come through SMEM, target rows ride in the high half of the index word.
-#define MI_NORANGE 0xFFFFFFFFu
-// prefetch depth in wave-steps: 15 covers a 450-entry row on 32 lanes (the dense
-// chunks of BASELINE config 3) and is what fits 256 VGPRs at BT = 4
+// ---- per-wave step streams with a register ring -------------------------------------
+// Every wave walks ONE linear stream of wave-steps per schedule (host_core.hpp Schedule,
+// sched_format.h).  The next PF steps of the stream live in a register ring: right after
+// step q has been consumed, its registers are refilled with step q + PF.  So PF steps
+// (PF KiB at BT = 2) per wave are in flight at all times, across phase boundaries -- a
+// phase boundary is just a number of LDS-only barriers the descriptor of the next step
+// asks for.  No vector load other than the stream itself is issued on this path (VMEM
+// returns in order: waiting for anything else would drain the ring); descriptors ride
+// in one VGPR per ring revolution (lane st = step st) and are read with v_readlane,
+// target rows ride in the high half of the index word.  The refill is one unconditional
+// straight-line site: reads past the end of a stream hit the next wave's steps or the
+// buffer bound (which returns 0) and are never consumed, so there is no branch around a
+// load and the compiler keeps ONE copy of the ring.
 #ifndef MI_PFV
 #define MI_PFV 15
 #endif
 template <int BT, int PF>
-struct PrefA { double v[PF][BT]; uint32_t gi[PF]; uint32_t desc; uint32_t begin, end; };
-struct ValSrc { mi_rsrc vals, idx, step; };     // one tile's value stream + the shared index words / step table
+struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t desc; };
+struct ValSrc { mi_rsrc vals, idx, step; };     // one tile's value stream + the shared index words / descriptors
 
 template <int BT>
 __device__ __forceinline__ void load_step(const ValSrc &vs, uint32_t stepno, int lane, double (&v)[BT], uint32_t &gi) {
   gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, (uint32_t)lane * 4u, stepno * 256u, 0);
   buf_load_bt<BT>(vs.vals, (uint32_t)lane * (uint32_t)(BT * 8), stepno * (uint32_t)(64 * BT * 8), v);
 }
-// lane st gets the descriptor of step begin+st (0 past the end; block-task ranges lie
-// outside the step table, for which the buffer unit returns 0)
-__device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t begin, uint32_t n, int lane) {
-  const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(vs.step, (uint32_t)lane * 4u, begin * 4u, 0);
-  return (uint32_t)lane < n ? d : 0u;
+// lane st gets the descriptor of step pos + st, a no-op at and past `end`
+__device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t pos, uint32_t end, int lane) {
+  const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(vs.step, (uint32_t)lane * 4u, pos * 4u, 0);
+  return pos + (uint32_t)lane < end ? d : MI_D_NOOP;
 }
 
-template <int BT, int PF>
-__device__ __forceinline__ void prefetch_all(const SchedDev &s, const ValSrc &vs, uint32_t begin, uint32_t end, int lane,
-                                             PrefA<BT, PF> &p) {
-  p.begin = begin; p.end = end;
-  const uint32_t n = end - begin;
-  p.desc = load_desc(vs, begin, n, lane);
-#pragma unroll
-  for (int st = 0; st < PF; st++)   // steps past the end read the all-zero padding step: no branch
-    load_step<BT>(vs, (uint32_t)st < n ? begin + (uint32_t)st : s.zero_step, lane, p.v[st], p.gi[st]);
-}
-
-// One phase of a wave.  The buffer `p` is only READ inside branches; its refill (the
-// loads of the wave's next-phase range) is ONE unconditional straight-line site, so
-// that the compiler keeps a single copy of the buffer and does not have to merge
-// differently-defined versions of it (which would cost register copies behind a
-// vmcnt(0) at every phase).
-//   kind 0: per step {gather, fma, optional flush}, then the step's registers are
-//           refilled -> about PF steps per wave stay in flight at all times;
-//   kind 1: the block task (if this wave has one) reads the buffer first, then the
-//           same refill sequence runs.
-template <int BT, int PF, bool SUB>
-__device__ __forceinline__ void phase_step(const SchedDev &s, const ValSrc &vs, double *xs, double *out,
-                                           PrefA<BT, PF> &p, uint32_t kind, uint32_t has_block,
-                                           uint32_t nbegin, uint32_t nend, int lane) {
-  const uint32_t n = p.end - p.begin, nn = nend - nbegin;
-  const uint32_t dnext = load_desc(vs, nbegin, nn, lane);     // older than every refill below
+// Walk the stream [begin, end) of this wave, then pass `tail` more barriers.
+//   SUB  = true : xs[row] -= sum (triangular solves); false: out[row] = sum (SpMV, no block steps)
+//   BAR  = the schedule has barriers (GX: full __syncthreads, the vector is in global memory)
+//   TR   = debug instantiation: lane 0 logs the shader clock before / after every barrier into
+//          tr[(ordinal of the barrier * nw + wave) * 2 + {0, 1}]
+template <int BT, int PF, bool SUB, bool BAR, bool GX, bool TR = false>
+__device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs,
+                                           double *out, int lane, uint32_t *tr = nullptr, int wave = 0, int nw = 0) {
   double *base = SUB ? xs : out;
-  if (kind != 0 && has_block) {
-    // ---- block task: lane = (i, b); 15 values in v[k / BT][k % BT], target row in the first index word
-    static_assert(PF * BT >= MI_CHUNK - 1, "prefetch buffer too small for a block task");
-    const int b = lane % BT;
-    const uint32_t row = lane < MI_CHUNK * BT ? p.gi[0] >> 16 : 0xFFFFu;
-    const bool valid = row != 0xFFFFu;
-    double accb = valid ? xs[(size_t)row * BT + b] : 0.0;
-    // broadcast of local row k to the lanes of the same QP: v_readlane (constant lane ids,
-    // SGPR results) + a select on b -- no LDS round trip in the 15-step dependent chain
+  Ring<BT, PF> r;
+  r.desc = load_desc(vs, begin, end, lane);
 #pragma unroll
-    for (int k = 0; k < MI_CHUNK - 1; k++) {
-      double vb[BT];
+  for (int st = 0; st < PF; st++) load_step<BT>(vs, begin + (uint32_t)st, lane, r.v[st], r.gi[st]);
+  double acc[BT], xq[BT];
 #pragma unroll
-      for (int bb = 0; bb < BT; bb++) {
-        const int lo = __builtin_amdgcn_readlane(__double2loint(accb), k * BT + bb);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(accb), k * BT + bb);
-        vb[bb] = __hiloint2double(hi, lo);
-      }
-      double v = vb[0];
-      if constexpr (BT >= 2) v = (b & 1) ? vb[1] : v;
-      if constexpr (BT == 4) { const double v2 = (b & 1) ? vb[3] : vb[2]; v = (b & 2) ? v2 : v; }
-      accb = fma(-p.v[k / BT][k % BT], v, accb);
-    }
-    if (valid) xs[(size_t)row * BT + b] = accb;
-  }
-  double acc[BT];
-#pragma unroll
-  for (int b = 0; b < BT; b++) acc[b] = 0.0;
-#pragma unroll
-  for (int st = 0; st < PF; st++) {
-    if (kind == 0) {
-      const uint32_t w = p.gi[st];
-      double xv[BT];
-      load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
-#pragma unroll
-      for (int b = 0; b < BT; b++) acc[b] = fma(p.v[st][b], xv[b], acc[b]);
-      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)p.desc, st);
-      if (d & 8u) {
-        reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
-#pragma unroll
-        for (int b = 0; b < BT; b++) acc[b] = 0.0;
-      }
-    }
-    // rotate: this slot now carries step st of the next phase (steps past the end read the zero step)
-    load_step<BT>(vs, (uint32_t)st < nn ? nbegin + (uint32_t)st : s.zero_step, lane, p.v[st], p.gi[st]);
-  }
-  // ranges longer than the buffer (rare): the tail is loaded on the fly
-  if (kind == 0) {
-    for (uint32_t st = PF; st < n; st++) {
-      double v[BT], xv[BT];
-      uint32_t w;
-      load_step<BT>(vs, p.begin + st, lane, v, w);
-      load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xv);
-#pragma unroll
-      for (int b = 0; b < BT; b++) acc[b] = fma(v[b], xv[b], acc[b]);
-      const uint32_t d = as_const(s.step)[p.begin + st];
-      if (d & 8u) {
-        reduce_write<BT, SUB>(acc, d & 7u, w >> 16, base, lane);
-#pragma unroll
-        for (int b = 0; b < BT; b++) acc[b] = 0.0;
-      }
-    }
-  }
-  p.begin = nbegin; p.end = nend; p.desc = dnext;
-}
-
-// One triangular solve = walk the flat phase table.
-template <int BT, int PF, bool GX>
-__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane) {
-  const uint32_t stride = 4u * (uint32_t)s.nw + 1u;
-  mi_cptr ph = as_const(s.phase);
-  PrefA<BT, PF> pa;
-  {
-    mi_cptr e = ph + 1 + 4 * wave;
-    prefetch_all<BT, PF>(s, vals, e[0], e[1], lane, pa);
-  }
-  for (int p = 0; p < s.n_phases; p++) {
-    mi_cptr pr = ph + (size_t)p * stride;
-    mi_cptr e = pr + 1 + 4 * wave;
-    const uint32_t kind = pr[0], has = e[3];
-    uint32_t nb = s.zero_step, ne = s.zero_step;
-    if (p + 1 < s.n_phases) { nb = e[stride]; ne = e[stride + 1]; }
-    phase_step<BT, PF, true>(s, vals, xs, nullptr, pa, kind, has, nb, ne, lane);
+  for (int b = 0; b < BT; b++) { acc[b] = 0.0; xq[b] = 0.0; }
+  double accb = 0.0;          // block task: this lane's row of the running solution
+  bool pre = false;           // xq already holds the gather of the step about to run
+  uint32_t nbar_seen = 0;
+  auto barrier = [&]() {
+    if constexpr (TR) { if (lane == 0) tr[((size_t)nbar_seen * nw + wave) * 2] = (uint32_t)__builtin_amdgcn_s_memtime(); }
     if constexpr (GX) __syncthreads(); else lds_barrier();
+    if constexpr (TR) { if (lane == 0) tr[((size_t)nbar_seen * nw + wave) * 2 + 1] = (uint32_t)__builtin_amdgcn_s_memtime(); nbar_seen++; }
+  };
+  for (uint32_t pos = begin; pos < end; pos += PF) {
+    const uint32_t npos = pos + PF;
+    const uint32_t dnext = load_desc(vs, npos, end, lane);     // older than every refill below
+#pragma unroll
+    for (int st = 0; st < PF; st++) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st);
+      if constexpr (BAR) { for (uint32_t nb = MI_D_NBAR(d); nb; nb--) barrier(); }
+      const uint32_t type = MI_D_TYPE(d);
+      if (type == MI_D_TYPE_ROW) {
+        const uint32_t w = r.gi[st];
+        double xv[BT];
+        if (!pre) load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xq);
+#pragma unroll
+        for (int b = 0; b < BT; b++) xv[b] = xq[b];
+        // gather of the next step ahead of this step's flush: inside one phase no step reads what another
+        // one writes (pull schedule; checked by the host replay), so the read may pass the write
+        pre = false;
+        if (st + 1 < PF) {
+          const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st + 1 < PF ? st + 1 : 0);
+          pre = (dn & ~0xFu) == 0u;                 // a row step without barriers in front of it
+          if (pre) load_bt<BT>(xs + (size_t)(r.gi[st + 1 < PF ? st + 1 : 0] & 0xFFFFu) * BT, xq);
+        }
+#pragma unroll
+        for (int b = 0; b < BT; b++) acc[b] = fma(r.v[st][b], xv[b], acc[b]);
+        if (d & MI_D_FLUSH) {
+          reduce_write<BT, SUB>(acc, MI_D_LT(d), w >> 16, base, lane);
+#pragma unroll
+          for (int b = 0; b < BT; b++) acc[b] = 0.0;
+        }
+      } else if (SUB && type == MI_D_TYPE_BLOCK) {
+        // ---- block step: lane = (i, b); columns k = s*BT + kk of the in-chunk triangle, value of column k in
+        // v[kk]; local row k is broadcast to the lanes of the same QP with v_readlane (SGPR lane select)
+        pre = false;
+        const int b = lane % BT;
+        const uint32_t row = r.gi[st] >> 16;
+        const bool valid = row != 0xFFFFu;
+        if (d & MI_D_FIRST) accb = valid ? xs[(size_t)row * BT + b] : 0.0;
+        const int k0 = (int)MI_D_S(d) * BT;
+#pragma unroll
+        for (int kk = 0; kk < BT; kk++) {
+          double vb[BT];
+#pragma unroll
+          for (int bb = 0; bb < BT; bb++) {
+            const int lo = __builtin_amdgcn_readlane(__double2loint(accb), (k0 + kk) * BT + bb);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(accb), (k0 + kk) * BT + bb);
+            vb[bb] = __hiloint2double(hi, lo);
+          }
+          double v = vb[0];
+          if constexpr (BT >= 2) v = (b & 1) ? vb[1] : v;
+          if constexpr (BT == 4) { const double v2 = (b & 1) ? vb[3] : vb[2]; v = (b & 2) ? v2 : v; }
+          accb = fma(-r.v[st][kk], v, accb);
+        }
+        if ((d & MI_D_LAST) && valid) xs[(size_t)row * BT + b] = accb;
+      } else {
+        pre = false;
+      }
+      // ring refill: this slot now carries step npos + st
+      load_step<BT>(vs, npos + (uint32_t)st, lane, r.v[st], r.gi[st]);
+    }
+    r.desc = dnext;
   }
+  if constexpr (BAR) { for (uint32_t nb = tail; nb; nb--) barrier(); }
 }
 
-// SpMV with the same step programs: phases [p0, p1) of the check schedule, no barriers
+// One triangular solve: this wave's whole stream of the schedule.
+template <int BT, int PF, bool GX, bool TR = false>
+__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane,
+                                        uint32_t *tr = nullptr) {
+  mi_cptr lp = as_const(s.lvl_pos);
+  const uint32_t begin = lp[wave], end = lp[(size_t)s.n_levels * s.nw + wave], tail = as_const(s.tail_bar)[wave];
+  run_stream<BT, PF, true, true, GX, TR>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw);
+}
+
+// SpMV with the same streams: levels [l0, l1) of the check schedule (independent rows, no barriers)
 template <int BT, int PF>
 __device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc &vals, double *xs, double *out, int wave,
-                                         int lane, int p0, int p1) {
-  if (p1 <= p0) return;
-  const uint32_t stride = 4u * (uint32_t)s.nw + 1u;
-  mi_cptr ph = as_const(s.phase);
-  PrefA<BT, PF> pa;
-  {
-    mi_cptr e = ph + (size_t)p0 * stride + 1 + 4 * wave;
-    prefetch_all<BT, PF>(s, vals, e[0], e[1], lane, pa);
-  }
-  for (int p = p0; p < p1; p++) {
-    mi_cptr e = ph + (size_t)p * stride + 1 + 4 * wave;
-    uint32_t nb = s.zero_step, ne = s.zero_step;
-    if (p + 1 < p1) { nb = e[stride]; ne = e[stride + 1]; }
-    phase_step<BT, PF, false>(s, vals, xs, out, pa, 0u, 0u, nb, ne, lane);
-  }
+                                         int lane, int l0, int l1) {
+  mi_cptr lp = as_const(s.lvl_pos);
+  const uint32_t begin = lp[(size_t)l0 * s.nw + wave], end = lp[(size_t)l1 * s.nw + wave];
+  run_stream<BT, PF, false, false, false>(vals, begin, end, 0u, xs, out, lane);
 }
 
 // --------------------------------------------------------- block reductions
@@ -399,9 +373,9 @@ template <int BT>
 __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile) {
   TilePtrs<BT> p;
   const size_t n = a.n, m = a.m, N = a.N, t = tile;
-  p.fwd_val = a.fwd_val + t * a.fwd.phys_steps * 64 * BT;
-  p.bwd_val = a.bwd_val + t * a.bwd.phys_steps * 64 * BT;
-  p.chk_val = a.chk_val + t * a.chk.phys_steps * 64 * BT;
+  p.fwd_val = a.fwd_val + t * a.fwd.n_steps * 64 * BT;
+  p.bwd_val = a.bwd_val + t * a.bwd.n_steps * 64 * BT;
+  p.chk_val = a.chk_val + t * a.chk.n_steps * 64 * BT;
   p.dinv = a.dinv + t * N * BT;
   p.x = a.x + t * n * BT; p.z = a.z + t * m * BT; p.y = a.y + t * m * BT;
   p.q = a.q + t * n * BT; p.l = a.l + t * m * BT; p.u = a.u + t * m * BT;
@@ -412,11 +386,11 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile)
   p.out1 = a.out1 + t * (2 * n + m) * BT; p.out2 = a.out2 + t * (2 * n + m) * BT;
   p.dscal = a.dscal + t * DS_COUNT * BT;
   p.iscal = a.iscal + t * IS_COUNT * BT;
-  p.vfwd.vals = make_rsrc(p.fwd_val, a.fwd.phys_steps * (uint32_t)(64 * BT * 8)); p.vfwd.idx = make_rsrc(a.fwd.idxw, a.fwd.phys_steps * 256u);
+  p.vfwd.vals = make_rsrc(p.fwd_val, a.fwd.n_steps * (uint32_t)(64 * BT * 8)); p.vfwd.idx = make_rsrc(a.fwd.idxw, a.fwd.n_steps * 256u);
   p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
-  p.vbwd.vals = make_rsrc(p.bwd_val, a.bwd.phys_steps * (uint32_t)(64 * BT * 8)); p.vbwd.idx = make_rsrc(a.bwd.idxw, a.bwd.phys_steps * 256u);
+  p.vbwd.vals = make_rsrc(p.bwd_val, a.bwd.n_steps * (uint32_t)(64 * BT * 8)); p.vbwd.idx = make_rsrc(a.bwd.idxw, a.bwd.n_steps * 256u);
   p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
-  p.vchk.vals = make_rsrc(p.chk_val, a.chk.phys_steps * (uint32_t)(64 * BT * 8)); p.vchk.idx = make_rsrc(a.chk.idxw, a.chk.phys_steps * 256u);
+  p.vchk.vals = make_rsrc(p.chk_val, a.chk.n_steps * (uint32_t)(64 * BT * 8)); p.vchk.idx = make_rsrc(a.chk.idxw, a.chk.n_steps * 256u);
   p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
   return p;
 }
@@ -524,7 +498,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
   __syncthreads();
   // residual vectors and the norms termination + rho estimate need
   double mx[14];
@@ -578,7 +552,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
     si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
   }
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3);
   __syncthreads();
   for (int e = tid; e < n * BT; e += nthr) {
     const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
@@ -713,7 +687,7 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
     for (int i = tid; i < m; i += nthr) xs[((size_t)n + i) * BT + bb] = (ok && gy) ? gy[(size_t)q * m + i] : 0.0;
   }
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, res, wave, lane, a.chk_lvl[0], a.chk_lvl[3]);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, res, wave, lane, 0, 3);
   __syncthreads();
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
@@ -746,6 +720,43 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
   }
 }
 
+// Debug twin of kkt_solve_kernel<2, 512, false> (MI_OSQP trace entry point, scripts/trace_phases.py): same
+// solve, plus per-phase / per-wave shader-clock stamps of tiles {0, gridDim/2} copied to trace[2][words].
+// Layout of one tile's words: [0..3] = memtime / memrealtime at start and end (low words),
+// then fwd stamps [n_phases_fwd][nw][2], then bwd stamps.
+__global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol,
+                                                       uint32_t *trace, uint32_t words) {
+  constexpr int BT = 2;
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+  const int N = a.N;
+  double *lds_rest;
+  double *xs = solve_vector<BT, false>(a, smem, tile, lds_rest);
+  uint32_t *tr = reinterpret_cast<uint32_t *>(xs + (size_t)a.xs_len * BT);
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  for (uint32_t i = tid; i < words; i += nthr) tr[i] = 0;
+  for (int bb = 0; bb < BT; bb++) {
+    const int q = tile * BT + bb;
+    for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
+  }
+  __syncthreads();
+  if (tid == 0) { tr[0] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+  uint32_t *trf = tr + 4, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
+  run_tri<BT, MI_PFV, false, true>(a.fwd, p.vfwd, xs, wave, lane, trf);
+  for (int e = tid; e < N * BT; e += nthr) xs[e] *= p.dinv[e];
+  __syncthreads();
+  run_tri<BT, MI_PFV, false, true>(a.bwd, p.vbwd, xs, wave, lane, trb);
+  if (tid == 0) { tr[2] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+  for (int bb = 0; bb < BT; bb++) {
+    const int q = tile * BT + bb;
+    if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
+  }
+  __syncthreads();
+  const int sel = tile == 0 ? 0 : (tile == (int)gridDim.x / 2 ? 1 : -1);
+  if (sel >= 0) for (uint32_t i = tid; i < words; i += nthr) trace[(size_t)sel * words + i] = tr[i];
+}
+
 // warm start (row E14): x <- Dinv .* x0 ; z <- A x   (QP-major x0[B][n])
 template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const doub
   }
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, a.chk_lvl[2], a.chk_lvl[3]);
+  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3);
   __syncthreads();
   for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
@@ -1015,7 +1026,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag && !(a.debug_skip & 16)) {
-    double *fv = a.fwd_val + (size_t)tile * a.fwd.phys_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.phys_steps * 64 * BT;
+    double *fv = a.fwd_val + (size_t)tile * a.fwd.n_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.n_steps * 64 * BT;
     for (size_t e = tid; e < (size_t)a.fwd.n_slots * BT; e += nthr) {
       const uint32_t sl = (uint32_t)(e / BT);
       const int32_t mp = a.fwd_srcblk[sl];
@@ -1073,7 +1084,7 @@ __global__ void scatter_kernel(const double *__restrict__ src, double *dst, cons
   const uint32_t s = (uint32_t)(g % slots);
   const int q = ids ? ids[j] : j;
   const int mp = map[s];
-  const size_t tile_doubles = (size_t)sd.phys_steps * 64 * BT;
+  const size_t tile_doubles = (size_t)sd.n_steps * 64 * BT;
   const size_t ph = phys_index(sd, s, q % BT, BT);
   if (ph != (size_t)-1) dst[(size_t)(q / BT) * tile_doubles + ph] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
 }
@@ -1099,18 +1110,18 @@ __global__ void swap_int_kernel(int *base, const int2 *pairs, int npairs, int le
   const int t = *pa; *pa = *pb; *pb = t;
 }
 __global__ void swap_sched_kernel(double *base, const int2 *pairs, int npairs, SchedDev sd, int BT) {
-  // per-QP element index u: A region u = slot (n_steps*64 of them); block region: (step, i, c)
-  const size_t nA = (size_t)sd.n_steps * 64, nB = (size_t)(sd.phys_steps - sd.n_steps) * MI_CHUNK * BT;
-  const size_t per = nA + nB;
+  // 64 elements per QP and step.  Row steps: element j = lane j, component b of the lane's BT-vector;
+  // block steps: element j = (i = j / BT, c = j % BT) lives in lane i*BT + b, component c.
+  const size_t per = (size_t)sd.n_steps * 64;
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)npairs * per) return;
   const int2 pr = pairs[g / per];
-  const size_t u = g % per;
-  const size_t tile_doubles = (size_t)sd.phys_steps * 64 * BT;
+  const size_t u = g % per, step = u / 64, j = u % 64;
+  const size_t tile_doubles = (size_t)sd.n_steps * 64 * BT;
   size_t ea, eb;
-  if (u < nA) { ea = u * BT + pr.x % BT; eb = u * BT + pr.y % BT; }
+  if (MI_D_TYPE(sd.step[step]) != MI_D_TYPE_BLOCK) { ea = u * BT + pr.x % BT; eb = u * BT + pr.y % BT; }
   else {
-    const size_t r = u - nA, step = sd.n_steps + r / (MI_CHUNK * BT), rem = r % (MI_CHUNK * BT), i = rem / BT, c = rem % BT;
+    const size_t i = j / BT, c = j % BT;
     ea = ((step * 64) + i * BT + pr.x % BT) * BT + c; eb = ((step * 64) + i * BT + pr.y % BT) * BT + c;
   }
   double *pa = base + (size_t)(pr.x / BT) * tile_doubles + ea;
@@ -1190,6 +1201,17 @@ hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads,
                             const double *rhs, double *sol) {
   MI_DISPATCH(kkt_solve_kernel, a, rhs, sol);
 }
+hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
+                            const double *rhs, double *sol, uint32_t *trace, uint32_t words) {
+  if (BT != 2 || a.xs_global || threads != 512) return hipErrorInvalidValue;
+  const size_t total = (size_t)a.xs_len * BT * sizeof(double) + (size_t)words * 4;
+  if (total > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
+  if (e != hipSuccess) return e;
+  (void)lds;
+  hipLaunchKernelGGL(kkt_trace_kernel, dim3(tiles), dim3(threads), total, st, a, rhs, sol, trace, words);
+  return hipGetLastError();
+}
 hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st, const double *x0) {
   MI_DISPATCH(warm_start_kernel, a, x0);
 }
@@ -1219,7 +1241,7 @@ hipError_t launch_swap_int(int *base, const int2 *pairs, int npairs, int len, in
 }
 hipError_t launch_swap_sched(double *base, const int2 *pairs, int npairs, const SchedDev &sd, int BT, hipStream_t st) {
   if (!npairs) return hipSuccess;
-  const size_t per = (size_t)sd.n_steps * 64 + (size_t)(sd.phys_steps - sd.n_steps) * MI_CHUNK * BT;
+  const size_t per = (size_t)sd.n_steps * 64;
   hipLaunchKernelGGL(swap_sched_kernel, dim3(nblk((size_t)npairs * per, 256)), dim3(256), 0, st, base, pairs, npairs, sd, BT);
   return hipGetLastError();
 }

@@ -98,18 +98,18 @@ struct DevBuf {
 };
 
 struct SchedBufs {
-  DevBuf<uint32_t> phase, step, idxw, bstep0;
+  DevBuf<uint32_t> step, idxw, bstep0, bsteps, lvl_pos, tail_bar;
   DevBuf<int32_t> src;
   int upload(const Schedule &s) {
     int rc;
-    if ((rc = phase.upload(s.phase)) || (rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src)) ||
-        (rc = bstep0.upload(s.bstep0))) return rc;
+    if ((rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src)) || (rc = bstep0.upload(s.bstep0)) ||
+        (rc = bsteps.upload(s.bsteps)) || (rc = lvl_pos.upload(s.lvl_pos)) || (rc = tail_bar.upload(s.tail_bar))) return rc;
     return 0;
   }
   SchedDev view(const Schedule &s) const {
-    SchedDev d; d.phase = phase.p; d.step = step.p; d.idxw = idxw.p; d.bstep0 = bstep0.p;
-    d.n_phases = s.n_phases; d.nw = s.nw; d.sb = s.sb;
-    d.n_steps = s.n_steps; d.phys_steps = s.phys_steps(); d.zero_step = s.zero_step; d.n_slots = s.n_slots;
+    SchedDev d; d.step = step.p; d.idxw = idxw.p; d.bstep0 = bstep0.p; d.bsteps = bsteps.p; d.lvl_pos = lvl_pos.p; d.tail_bar = tail_bar.p;
+    d.n_phases = s.n_phases; d.nw = s.nw; d.n_levels = s.n_levels;
+    d.n_steps = s.n_steps; d.n_slots = s.n_slots;
     return d;
   }
 };
@@ -194,7 +194,6 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.check_termination = (int)s.check_termination; a.rho_interval = (int)s.adaptive_rho_interval;
   a.max_iter = (int)s.max_iter; a.scaled_termination = (int)s.scaled_termination; a.scaling = s.scaling ? 1 : 0;
   a.adaptive_rho = (int)s.adaptive_rho; a.iter_begin = 0; a.iter_end = 0; a.info_at_end = 1;
-  for (int k = 0; k < 4; k++) a.chk_lvl[k] = h->an.chk.level_first_phase[k];
   return a;
 }
 
@@ -933,6 +932,32 @@ int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol
   return MI_OSQP_OK;
 }
 
+int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double *d_rhs, double *d_sol, uint32_t *out,
+                                  int64_t cap, int64_t *dims) {
+  if (!h || !dims) return MI_OSQP_ERR_NULL;
+  const int nw = h->threads / 64;
+  const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 4 + (fp + bp) * nw * 2;
+  dims[0] = fp; dims[1] = bp; dims[2] = nw; dims[3] = words;
+  if (!out) return MI_OSQP_OK;
+  if (which == 1 || which == 2) {
+    const Schedule &sc = which == 1 ? h->an.fwd : h->an.bwd;
+    if ((int64_t)sc.phase.size() > cap) { g_last_error = "trace: output too small"; return MI_OSQP_ERR_INVALID_DATA; }
+    std::copy(sc.phase.begin(), sc.phase.end(), out);
+    return MI_OSQP_OK;
+  }
+  if (!d_rhs || !d_sol) return MI_OSQP_ERR_NULL;
+  if (2 * words > cap) { g_last_error = "trace: output too small"; return MI_OSQP_ERR_INVALID_DATA; }
+  uint32_t *d_tr = nullptr;
+  HIPCHK(hipMalloc(&d_tr, (size_t)2 * words * 4));
+  KernelArgs a = make_args(h);
+  hipError_t e = launch_kkt_trace(a, h->BT, h->ntiles, h->threads, h->lds, h->stream, d_rhs, d_sol, d_tr, (uint32_t)words);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d_tr, (size_t)2 * words * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_tr);
+  HIPCHK(e);
+  return MI_OSQP_OK;
+}
+
 // ------------------------------------------------------------------ single QP
 
 int mi_osqp_setup(mi_osqp_solver **out, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const double *Pv,
@@ -986,7 +1011,9 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const 
   std::vector<double> w;
   if ((rc = factor_qp(an, s, Q, w))) return rc;
   if (sol_direct) direct_kkt_solve(an, Q, rhs, sol_direct);
-  if (sol_schedule) replay_kkt_solve(an, Q, rhs, sol_schedule);
+  if (sol_schedule && !replay_kkt_solve(an, Q, rhs, sol_schedule)) {
+    g_last_error = "schedule streams are not race-free / deadlock-free"; return MI_OSQP_ERR_INVALID_DATA;
+  }
   if (st) {
     memset(st, 0, sizeof(*st));
     st->n = n; st->m = m; st->N = an.N; st->batch = 1; st->tile = 1; st->n_tiles = 1;
