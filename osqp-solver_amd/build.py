@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmi_osqp.so")
 SOURCES = ["solver.hip", "kernels.hip", "host_core.cpp"]
-HEADERS = ["device_types.h", "host_core.hpp", os.path.join("..", "..", "include", "mi_osqp.h")]
+HEADERS = ["device_types.h", "sched_format.h", "host_core.hpp", os.path.join("..", "..", "include", "mi_osqp.h")]
 
 
 def needs_build():
@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     for f in SOURCES:
         obj = os.path.join(CSRC, f + ".o")
         cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
-               "-c", os.path.join(CSRC, f), "-o", obj]
+               "-c", os.path.join(CSRC, f), "-o", obj] + os.environ.get("MI_OSQP_CXXFLAGS", "").split()
         if f.endswith(".cpp"):
             cmd.insert(1, "-x"); cmd.insert(2, "c++")
         if verbose:

@@ -10,7 +10,6 @@ namespace miosqp {
 // device view of one host_core.hpp Schedule (tables are shared by all tiles)
 struct SchedDev {
   const uint32_t *step, *idxw;          // per step: descriptor (sched_format.h); per slot: index word
-  const uint32_t *bstep0, *bsteps;      // per block task: first step, number of steps
   const uint32_t *lvl_pos, *tail_bar;   // (n_levels+1) x nw stream positions; per wave: barriers owed after the last step
   int n_phases, nw, n_levels;
   uint32_t n_steps, n_slots;
@@ -24,7 +23,8 @@ enum { IS_STATUS = 0, IS_ITER, IS_RHO_UPDATES, IS_DONE, IS_NEED_REFACTOR, IS_COU
 struct KernelArgs {
   int n, m, N, B;
   SchedDev fwd, bwd, chk;
-  const uint32_t *pinv;                 // natural index -> position in the permuted LDS vector
+  const uint32_t *pinv;                 // natural index -> position in the permuted solve vector
+  const uint32_t *xloc;                 // permuted row -> position of its forward result / backward input (host_core.hpp Analysis::xloc)
   // tile-interleaved value arrays: [tile][len][BT]
   const double *fwd_val, *bwd_val, *chk_val, *dinv;
   double *x, *z, *y;
@@ -34,7 +34,7 @@ struct KernelArgs {
   const int *qp_of_slot;                // slot (tile*BT + b) -> global QP id, -1 = empty (compaction during a solve)
   double *x_out, *y_out;                // QP-major [B][n], [B][m]
   double *xs_global;                    // non-null: the solve vector lives here ([tile][xs_len][BT]) instead of LDS
-  int xs_len;                           // n + m
+  int xs_len;                           // length of the solve vector: Analysis::Next >= n + m
   // settings (row S)
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
   int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;

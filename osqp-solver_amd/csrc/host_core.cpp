@@ -264,17 +264,16 @@ static void postorder(const std::vector<int> &parent, std::vector<int> &post) {
 // ------------------------------------------------------------ schedule packing
 
 namespace {
-struct RowWork { uint32_t row; std::vector<std::pair<uint32_t, int32_t>> ent; };
-struct BlockWork { std::vector<uint32_t> rows; std::vector<int32_t> tri; };  // tri[p*r+i]
-struct LevelWork { std::vector<RowWork> rowsA; std::vector<BlockWork> blocksB; };
+struct RowWork { uint32_t row; std::vector<std::pair<uint32_t, int32_t>> ent; };   // ent: (gather index, value source)
+struct LevelWork { std::vector<RowWork> rowsA, rowsB; };                           // B rows: store instead of subtract
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-// Builds one schedule.  Work is first laid out as phases (per level: one A phase of row steps spread over
-// the waves, then B phases with at most one block task per wave); the steps are then numbered WAVE-MAJOR:
-// wave w's steps of all phases are contiguous in memory and form the linear stream the device walks
-// (sched_format.h); phase boundaries survive only as barrier counts in the descriptors.
+// Builds one schedule.  Work is first laid out as phases (per level: one phase for rowsA, one for rowsB, each
+// spread over the waves); the steps are then numbered WAVE-MAJOR: wave w's steps of all phases are contiguous
+// in memory and form the linear stream the device walks (sched_format.h); phase boundaries survive only as
+// barrier counts in the descriptors.
 void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers) {
   sch = Schedule();
   sch.n_levels = (int)levels.size();
@@ -282,19 +281,16 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
   // a unit = work that must stay on one wave, in order
   struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; };
   struct Unit { std::vector<StepSpec> steps; };
-  struct StepRec { uint32_t type = MI_D_TYPE_ROW; StepSpec a; uint32_t task = 0, s = 0; bool first = false, last = false; };
-  struct PhaseRec { int kind; std::vector<std::vector<StepRec>> wave; };
+  struct PhaseRec { int kind; std::vector<std::vector<StepSpec>> wave; };
   std::vector<PhaseRec> phases;
-  std::vector<const BlockWork *> tasks;                 // block tasks in processing order
-  for (size_t L = 0; L < levels.size(); L++) {
-    const LevelWork &lw = levels[L];
-    sch.level_first_phase.push_back((int)phases.size());
+  auto pack_rows = [&](const std::vector<RowWork> &rows, int kind) {
+    if (rows.empty()) return;
     std::vector<Unit> units;
     std::vector<const RowWork *> longs;
     // short rows (<= 64 entries): lane-group width T and step count S <= 4 chosen to minimise the
     // padded slots T*S (ties -> fewer steps); rows with equal (T,S) are packed 64/T per unit
     std::vector<std::vector<const RowWork *>> byTS(7 * 4);
-    for (const RowWork &rw : lw.rowsA) {
+    for (const RowWork &rw : rows) {
       int len = std::max<int>(1, (int)rw.ent.size());
       if (len > 64) { longs.push_back(&rw); continue; }
       int bestlt = 6, bestS = 1, bestcost = 1 << 30;
@@ -330,47 +326,30 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
           units.push_back(std::move(u));
         }
       }
-    if (!units.empty()) {
-      // longest-processing-time assignment of units to waves
-      std::vector<size_t> order(units.size());
-      std::iota(order.begin(), order.end(), 0);
-      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
-      std::vector<int> load(nw, 0);
-      std::vector<std::vector<size_t>> mine(nw);
-      for (size_t k : order) {
-        int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        load[w] += (int)units[k].steps.size();
-        mine[w].push_back(k);
-      }
-      PhaseRec ph; ph.kind = 0; ph.wave.resize(nw);
-      for (int w = 0; w < nw; w++)
-        for (size_t k : mine[w])
-          for (StepSpec &st : units[k].steps) { StepRec r; r.a = std::move(st); ph.wave[w].push_back(std::move(r)); }
-      phases.push_back(std::move(ph));
+    // longest-processing-time assignment of units to waves
+    std::vector<size_t> order(units.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
+    std::vector<int> load(nw, 0);
+    std::vector<std::vector<size_t>> mine(nw);
+    for (size_t k : order) {
+      int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+      load[w] += (int)units[k].steps.size();
+      mine[w].push_back(k);
     }
-    // block tasks: at most one per wave per B phase; a task of r rows owns ceil((r-1)/bt) steps
-    std::vector<const BlockWork *> blks;
-    for (const BlockWork &bw : lw.blocksB) if (bw.rows.size() >= 2) blks.push_back(&bw);
-    for (size_t i = 0; i < blks.size(); i += nw) {
-      PhaseRec ph; ph.kind = 1; ph.wave.resize(nw);
-      for (int w = 0; w < nw && i + w < blks.size(); w++) {
-        const uint32_t task = (uint32_t)tasks.size();
-        tasks.push_back(blks[i + w]);
-        const int ns = ((int)blks[i + w]->rows.size() - 1 + bt - 1) / bt;
-        for (int s2 = 0; s2 < ns; s2++) {
-          StepRec r; r.type = MI_D_TYPE_BLOCK; r.task = task; r.s = (uint32_t)s2; r.first = s2 == 0; r.last = s2 == ns - 1;
-          ph.wave[w].push_back(std::move(r));
-        }
-      }
-      phases.push_back(std::move(ph));
-    }
+    PhaseRec ph; ph.kind = kind; ph.wave.resize(nw);
+    for (int w = 0; w < nw; w++)
+      for (size_t k : mine[w])
+        for (StepSpec &st : units[k].steps) ph.wave[w].push_back(std::move(st));
+    phases.push_back(std::move(ph));
+  };
+  for (size_t L = 0; L < levels.size(); L++) {
+    sch.level_first_phase.push_back((int)phases.size());
+    pack_rows(levels[L].rowsA, 0);
+    pack_rows(levels[L].rowsB, 1);
   }
   sch.level_first_phase.push_back((int)phases.size());
   sch.n_phases = (int)phases.size();
-  sch.n_taskB = (uint32_t)tasks.size();
-  sch.bstep0.assign(tasks.size() + 1, 0u);
-  for (const BlockWork *bw : tasks)
-    for (int i = 0; i < kChunk; i++) sch.outB.push_back(i < (int)bw->rows.size() ? bw->rows[i] : kNoRow);
   // ---- wave-major numbering
   sch.phase.assign((size_t)sch.n_phases * sch.phase_stride(), 0u);
   sch.lvl_pos.assign((size_t)(levels.size() + 1) * nw, 0u);
@@ -385,35 +364,27 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       uint32_t *e = &sch.phase[(size_t)p * sch.phase_stride() + 1 + 4 * w];
       sch.phase[(size_t)p * sch.phase_stride()] = (uint32_t)phases[p].kind;
       e[0] = sch.n_steps;
-      std::vector<StepRec> &recs = phases[p].wave[w];
+      const std::vector<StepSpec> &recs = phases[p].wave[w];
       for (size_t k = 0; k < recs.size(); k++) {
-        const StepRec &r = recs[k];
+        const StepSpec &st = recs[k];
         const uint32_t stepno = sch.n_steps++;
         sch.idx.resize((size_t)sch.n_steps * 64, 0u);
-        sch.src.resize((size_t)sch.n_steps * 64, -1);
+        sch.src.resize((size_t)sch.n_steps * 64, MI_SRC_ZERO);
         uint32_t nbar = 0;
         if (barriers && k == 0) { nbar = (uint32_t)(p - last_phase); last_phase = p; }
-        uint32_t d = nbar << 12, ob = 0;
-        if (r.type == MI_D_TYPE_ROW) {
-          const StepSpec &st = r.a;
-          const int T = 1 << st.lt;
-          for (int g = 0; g < (int)st.rows.size(); g++) {
-            const auto &ent = st.rows[g]->ent;
-            for (int en = st.first_entry; en < std::min<int>((int)ent.size(), st.first_entry + T); en++) {
-              const uint32_t slot = stepno * 64u + (uint32_t)(g * T + (en - st.first_entry));
-              sch.idx[slot] = ent[en].first; sch.src[slot] = ent[en].second;
-            }
+        uint32_t d = (nbar << 12) | (uint32_t)st.lt | (phases[p].kind == 1 ? MI_D_STORE : 0u), ob = 0;
+        const int T = 1 << st.lt;
+        for (int g = 0; g < (int)st.rows.size(); g++) {
+          const auto &ent = st.rows[g]->ent;
+          for (int en = st.first_entry; en < std::min<int>((int)ent.size(), st.first_entry + T); en++) {
+            const uint32_t slot = stepno * 64u + (uint32_t)(g * T + (en - st.first_entry));
+            sch.idx[slot] = ent[en].first; sch.src[slot] = ent[en].second;
           }
-          if (st.flush) {
-            ob = (uint32_t)sch.outA.size();
-            for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
-            d |= MI_D_FLUSH;
-          }
-          d |= (uint32_t)st.lt;
-        } else {
-          if (r.first) { sch.bstep0[r.task] = stepno; e[2] = r.task * kChunk; e[3] = 1u; }
-          d |= (MI_D_TYPE_BLOCK << 4) | (r.s << 6) | (r.first ? MI_D_FIRST : 0u) | (r.last ? MI_D_LAST : 0u);
-          ob = r.task;
+        }
+        if (st.flush) {
+          ob = (uint32_t)sch.outA.size();
+          for (int g = 0; g < 64 / T; g++) sch.outA.push_back(g < (int)st.rows.size() ? st.rows[g]->row : kNoRow);
+          d |= MI_D_FLUSH;
         }
         sch.step.push_back(d);
         sch.step_ob.push_back(ob);
@@ -426,44 +397,20 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     // every wave passes exactly n_phases barriers per walk (the last one publishes the final phase)
     sch.tail_bar[w] = barriers ? (uint32_t)(sch.n_phases - last_phase) : 0u;
   }
-  // bstep0[task + 1] is only used as "end of the task's steps": tasks are numbered in phase order but laid
-  // out wave-major, so keep an explicit count instead
-  sch.bsteps.assign(tasks.size(), 0u);
-  for (size_t t = 0; t < tasks.size(); t++) sch.bsteps[t] = (uint32_t)(((int)tasks[t]->rows.size() - 1 + bt - 1) / bt);
-  // logical slots of the block tasks (after the per-step slots)
   sch.n_slots = sch.n_steps * 64u;
-  for (size_t t = 0; t < tasks.size(); t++) {
-    const BlockWork *bw = tasks[t];
-    const int r = (int)bw->rows.size();
-    const uint32_t base = sch.n_slots;
-    sch.n_slots += (uint32_t)(kChunk * (kChunk - 1));
-    sch.src.resize(sch.n_slots, -1);
-    for (int p = 0; p < r - 1; p++)
-      for (int i = p + 1; i < r; i++) sch.src[base + p * kChunk + i] = bw->tri[p * r + i];
-  }
   // device index words
   sch.idxw.assign((size_t)sch.n_steps * 64, 0xFFFF0000u);
   for (uint32_t st = 0; st < sch.n_steps; st++) {
-    const uint32_t d = sch.step[st];
-    if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
-      const uint32_t lt = MI_D_LT(d), ob = sch.step_ob[st];
-      for (uint32_t ln = 0; ln < 64; ln++) {
-        uint32_t row = 0xFFFFu;
-        if (d & MI_D_FLUSH) { uint32_t r = sch.outA[ob + (ln >> lt)]; row = r == kNoRow ? 0xFFFFu : r; }
-        sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
-      }
-    } else {
-      const uint32_t task = sch.step_ob[st];
-      for (int i = 0; i < kChunk; i++)
-        for (int b = 0; b < bt; b++) {
-          uint32_t r = sch.outB[task * kChunk + i];
-          sch.idxw[(size_t)st * 64 + i * bt + b] = (r == kNoRow ? 0xFFFFu : r) << 16;
-        }
+    const uint32_t d = sch.step[st], lt = MI_D_LT(d), ob = sch.step_ob[st];
+    for (uint32_t ln = 0; ln < 64; ln++) {
+      uint32_t row = 0xFFFFu;
+      if (d & MI_D_FLUSH) { uint32_t r = sch.outA[ob + (ln >> lt)]; row = r == kNoRow ? 0xFFFFu : r; }
+      sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
     }
   }
   if (getenv("MI_OSQP_DEBUG_ORDER"))
-    fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu steps %u block tasks %u outA %zu\n", levels.size(),
-            phases.size(), sch.n_steps, sch.n_taskB, sch.outA.size());
+    fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu steps %u outA %zu\n", levels.size(), phases.size(), sch.n_steps,
+            sch.outA.size());
 }
 }  // namespace
 
@@ -472,7 +419,17 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
   int nch = (int)an.chunk_start.size() - 1;
   std::vector<int> chunk_of(N);
   for (int c = 0; c < nch; c++) for (int j = an.chunk_start[c]; j < an.chunk_start[c + 1]; j++) chunk_of[j] = c;
-  // ---- forward: rows ascending, sources are columns j < row
+  // inverted diagonal blocks and the second vector position of the rows of multi-row chunks
+  an.inv_off.assign(nch, -1); an.n_inv = 0;
+  an.xloc.resize(N); an.Next = N;
+  for (int c = 0; c < nch; c++) {
+    int c0 = an.chunk_start[c], r = an.chunk_start[c + 1] - c0;
+    if (r >= 2) { an.inv_off[c] = an.n_inv; an.n_inv += r * (r - 1) / 2; }
+    for (int i = 0; i < r; i++) an.xloc[c0 + i] = r >= 2 ? an.Next++ : c0 + i;
+  }
+  // ---- forward: rows ascending, sources are columns j < row.  Row i of a chunk: phase A subtracts the
+  // couplings to earlier chunks in place (position i); phase B stores inv(L_cc) t at position xloc[i],
+  // which is where every later row gathers it.
   {
     std::vector<int> lev(nch, 0);
     int maxlev = 0;
@@ -486,22 +443,25 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
     std::vector<LevelWork> lw(maxlev + 1);
     for (int c = 0; c < nch; c++) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
-      BlockWork bw;
-      if (r >= 2) { bw.rows.resize(r); bw.tri.assign((size_t)r * r, -1); for (int i = 0; i < r; i++) bw.rows[i] = (uint32_t)(c0 + i); }
       for (int i = c0; i < c1; i++) {
         RowWork rw; rw.row = (uint32_t)i;
         for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) {
           int j = an.Rj[t];
-          if (j < c0) rw.ent.push_back({(uint32_t)j, an.Rpos[t]});
-          else bw.tri[(size_t)(j - c0) * r + (i - c0)] = an.Rpos[t];
+          if (j < c0) rw.ent.push_back({(uint32_t)an.xloc[j], an.Rpos[t]});
         }
         if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
+        if (r >= 2) {
+          RowWork rb; rb.row = (uint32_t)an.xloc[i];
+          for (int k = c0; k < i; k++) rb.ent.push_back({(uint32_t)k, an.inv_index(c, i - c0, k - c0)});
+          rb.ent.push_back({(uint32_t)i, MI_SRC_ONE});
+          lw[lev[c]].rowsB.push_back(std::move(rb));
+        }
       }
-      if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
     pack_schedule(lw, an.fwd, nw, bt, true);
   }
-  // ---- backward: columns descending, sources are rows j > column
+  // ---- backward: columns descending, sources are rows j > column.  Column k of a chunk: phase A works in
+  // place at xloc[k] (where the scaled forward result lives), phase B stores inv(L_cc)' t at position k.
   {
     std::vector<int> lev(nch, 0);
     int maxlev = 0;
@@ -514,18 +474,20 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
     std::vector<LevelWork> lw(maxlev + 1);
     for (int c = nch - 1; c >= 0; c--) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
-      BlockWork bw;
-      if (r >= 2) { bw.rows.resize(r); bw.tri.assign((size_t)r * r, -1); for (int i = 0; i < r; i++) bw.rows[i] = (uint32_t)(c1 - 1 - i); }
       for (int col = c1 - 1; col >= c0; col--) {
-        RowWork rw; rw.row = (uint32_t)col;
+        RowWork rw; rw.row = (uint32_t)an.xloc[col];
         for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
           int j = an.Li[p];
           if (j >= c1) rw.ent.push_back({(uint32_t)j, p});
-          else bw.tri[(size_t)(c1 - 1 - j) * r + (c1 - 1 - col)] = p;
         }
         if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
+        if (r >= 2) {
+          RowWork rb; rb.row = (uint32_t)col;
+          rb.ent.push_back({(uint32_t)an.xloc[col], MI_SRC_ONE});
+          for (int i = col + 1; i < c1; i++) rb.ent.push_back({(uint32_t)an.xloc[i], an.inv_index(c, i - c0, col - c0)});
+          lw[lev[c]].rowsB.push_back(std::move(rb));
+        }
       }
-      if (r >= 2) lw[lev[c]].blocksB.push_back(std::move(bw));
     }
     pack_schedule(lw, an.bwd, nw, bt, true);
   }
@@ -689,11 +651,18 @@ static void build_block_factor(Analysis &an) {
   for (int k = 0; k < an.Ap[n]; k++) bf.asm_src[an.AtoK[k]] = ((uint32_t)ASM_A << 29) | (uint32_t)k;
   for (int r = 0; r < m; r++) bf.asm_src[an.rhotoK[r]] = ((uint32_t)ASM_NEG_RHOINV << 29) | (uint32_t)r;
   // canonical L entry -> storage position, and the schedule maps composed with it
-  bf.lpos.assign(an.nnzL(), 0);
+  bf.lpos.assign(an.nnzLx(), 0);
   for (int j = 0; j < N; j++) for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) bf.lpos[p] = (int32_t)pos_of(an.Li[p], j);
+  for (int c = 0; c < nch; c++) {
+    const int c0 = an.chunk_start[c], r = cw(c);
+    if (r < 2) continue;
+    const uint32_t id = find_blk(c, c), off = bf.blk[4 * id];
+    for (int k = 0; k < r; k++) for (int i = k + 1; i < r; i++) bf.lpos[an.inv_index(c, i, k)] = (int32_t)(off + (uint32_t)i * r + (uint32_t)k);
+    (void)c0;
+  }
   auto compose = [&](const Schedule &s, std::vector<int32_t> &out) {
     out.resize(s.src.size());
-    for (size_t k = 0; k < s.src.size(); k++) out[k] = s.src[k] >= 0 ? bf.lpos[s.src[k]] : -1;
+    for (size_t k = 0; k < s.src.size(); k++) out[k] = s.src[k] >= 0 ? bf.lpos[s.src[k]] : s.src[k];   // MI_SRC_ZERO / MI_SRC_ONE pass through
   };
   compose(an.fwd, an.fwd_srcblk);
   compose(an.bwd, an.bwd_srcblk);
@@ -702,7 +671,7 @@ static void build_block_factor(Analysis &an) {
 // --------------------------------------------------------------------- analyze
 
 int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves, int bt) {
+            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows) {
   if (nwaves < 1 || nwaves > 16 || (bt != 1 && bt != 2 && bt != 4)) return MI_OSQP_ERR_INVALID_SETTINGS;
   if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
   int n = (int)n64, m = (int)m64, N = n + m;
@@ -749,6 +718,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   for (int r = 0; r < m; r++) { int pos = nxt[n + r]++; an.Ki[pos] = n + r; an.rhotoK[r] = pos; }
   // ---- ordering: two candidates, chosen by the modelled time of one KKT solve on the device
   // (phases cost ~1.5 us each, the factor streams at ~18 GB/s per CU)
+  if (max_extra_rows < 0 || max_extra_rows > 65534 - N) max_extra_rows = std::max(0, 65534 - N);
   auto finalize = [&](const std::vector<int> &perm0, double &cost) {
     an.perm = perm0;
     an.pinv.assign(N, 0);
@@ -788,9 +758,18 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
       if (!join) an.sn_start.push_back(j + 1);
     }
     an.sn_start.push_back(N);
+    // <=16-column chunks of supernodes.  Every row of a multi-row chunk needs a second position in the solve
+    // vector (phase B reads t and writes x); when the budget of extra positions (LDS capacity / 16-bit
+    // indices) is used up, the remaining supernodes are cut into one-row chunks (more levels, no phase B).
     an.chunk_start.clear();
+    int extra_left = max_extra_rows;
     for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
-      for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) an.chunk_start.push_back(c);
+      for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) {
+        const int r = std::min(kChunk, an.sn_start[s + 1] - c);
+        if (r >= 2 && r > extra_left) { for (int j = c; j < c + r; j++) an.chunk_start.push_back(j); continue; }
+        if (r >= 2) extra_left -= r;
+        an.chunk_start.push_back(c);
+      }
     an.chunk_start.push_back(N);
     // forward chunk levels (the backward sweep has the same depth)
     int nch = (int)an.chunk_start.size() - 1, depth = 0;
@@ -802,11 +781,11 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
         for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0) L = std::max(L, lev[chunk_of[j]] + 1); }
       lev[c] = L; depth = std::max(depth, L + 1);
     }
-    // phases of one sweep: one A phase per level + ceil(block tasks of the level / waves) B phases
+    // phases of one sweep: one A phase per level + one B phase where the level has multi-row chunks
     std::vector<int> blocks_at(depth, 0);
     for (int c = 0; c < nch; c++) if (an.chunk_start[c + 1] - an.chunk_start[c] >= 2) blocks_at[lev[c]]++;
     int phases = depth;
-    for (int L = 0; L < depth; L++) phases += (blocks_at[L] + nwaves - 1) / nwaves;
+    for (int L = 0; L < depth; L++) phases += blocks_at[L] ? 1 : 0;
     cost = 2.0 * phases * 1.5e-6 + 2.0 * 8.0 * bt * 1.3 * (double)an.Lp[N] / 18e9;
   };
   {
@@ -958,6 +937,29 @@ void apply_rho(const Analysis &an, QPNumeric &qp, double rho_new) {
 
 // Left-looking LDL' on the permuted KKT using the precomputed pattern of L
 // (sorted columns + row view).  work: N doubles, zero on entry and exit.
+// inv(L_cc) of every multi-row chunk (unit lower triangular), appended to the canonical factor array:
+// column k of the inverse by forward substitution on e_k
+static void invert_diag_blocks(const Analysis &an, double *Lx) {
+  const int nch = (int)an.chunk_start.size() - 1;
+  double Lc[kChunk][kChunk], V[kChunk];
+  for (int c = 0; c < nch; c++) {
+    const int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
+    if (r < 2) continue;
+    for (int i = 0; i < r; i++) for (int k = 0; k < r; k++) Lc[i][k] = 0.0;
+    for (int j = c0; j < c1; j++)
+      for (int p = an.Lp[j]; p < an.Lp[j + 1] && an.Li[p] < c1; p++) Lc[an.Li[p] - c0][j - c0] = Lx[p];
+    for (int k = 0; k + 1 < r; k++) {
+      V[k] = 1.0;
+      for (int i = k + 1; i < r; i++) {
+        double v = 0.0;
+        for (int p = k; p < i; p++) v = std::fma(-Lc[i][p], V[p], v);
+        V[i] = v;
+        Lx[an.inv_index(c, i, k)] = v;
+      }
+    }
+  }
+}
+
 int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector<double> &w) {
   int n = an.n, m = an.m, N = an.N, nnzP = an.Pp[n], nnzA = an.Ap[n];
   // permuted lower KKT values
@@ -966,7 +968,7 @@ int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector
   for (int pos : an.sigmaOnlyK) Kl[an.KtoKl[pos]] = st.sigma;
   for (int k = 0; k < nnzA; k++) Kl[an.KtoKl[an.AtoK[k]]] = qp.Av[k];
   for (int r = 0; r < m; r++) Kl[an.KtoKl[an.rhotoK[r]]] = -qp.rho_inv[r];
-  qp.Lx.assign(an.nnzL(), 0.0); qp.Dl.assign(N, 0.0); qp.Dlinv.assign(N, 0.0);
+  qp.Lx.assign(an.nnzLx(), 0.0); qp.Dl.assign(N, 0.0); qp.Dlinv.assign(N, 0.0);
   if ((int)w.size() < N) w.assign(N, 0.0);
   int positive = 0;
   for (int j = 0; j < N; j++) {
@@ -986,6 +988,7 @@ int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector
     qp.Dlinv[j] = dinv;
     for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int i = an.Li[p]; qp.Lx[p] = w[i] * dinv; w[i] = 0.0; }
   }
+  invert_diag_blocks(an, qp.Lx.data());
   return positive == n ? MI_OSQP_OK : MI_OSQP_ERR_NONCONVEX;
 }
 
@@ -999,32 +1002,24 @@ void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs
   for (int k = 0; k < N; k++) sol[an.perm[k]] = b[k];
 }
 
-size_t phys_index(const Schedule &s, uint32_t slot, int b) {
-  const uint32_t nA = s.n_steps * 64u;
-  if (slot < nA) return MI_D_TYPE(s.step[slot >> 6]) == MI_D_TYPE_BLOCK ? (size_t)-1 : (size_t)slot * s.bt + b;
-  const uint32_t r = slot - nA, task = r / (kChunk * (kChunk - 1)), rem = r % (kChunk * (kChunk - 1));
-  const uint32_t k = rem / kChunk, i = rem % kChunk;
-  if (k / s.bt >= s.bsteps[task]) return (size_t)-1;
-  return ((size_t)(s.bstep0[task] + k / s.bt) * 64 + (size_t)i * s.bt + b) * s.bt + k % s.bt;
-}
+size_t phys_index(const Schedule &s, uint32_t slot, int b) { return (size_t)slot * s.bt + b; }
 
 // Sequential interpreter of one schedule (tests): every wave walks its stream exactly as the device does;
 // waves are interleaved epoch by epoch (epoch = number of barriers passed).  Returns false when the streams
 // are not race-free / deadlock-free: barrier totals differ between waves, or within one epoch an entry of the
 // solve vector is gathered and written, or written twice (the only read allowed next to a write is the
 // writer's own read-modify-write) -- this is also what lets the device issue gathers ahead of flushes.
-static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs_len, bool subtract, double *out) {
-  const uint32_t nA = s.n_steps * 64u;
+static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs_len, bool tri, double *out) {
   const int nw = s.nw;
   std::vector<uint32_t> pos(nw), epoch(nw, 0u);
   for (int w = 0; w < nw; w++) pos[w] = s.wave_range[2 * w];
-  std::vector<int64_t> wr_epoch(subtract ? xs_len : 0, -1), rd_epoch(subtract ? xs_len : 0, -1);
-  std::vector<std::vector<double>> acc(nw, std::vector<double>(64, 0.0)), accb(nw, std::vector<double>(kChunk, 0.0));
+  std::vector<int64_t> wr_epoch(tri ? xs_len : 0, -1), rd_epoch(tri ? xs_len : 0, -1);
+  std::vector<std::vector<double>> acc(nw, std::vector<double>(64, 0.0));
   bool ok = true;
   int64_t cur = 0;
-  auto gather = [&](uint32_t e) { if (subtract) { if (wr_epoch[e] == cur) ok = false; rd_epoch[e] = cur; } return xs[e]; };
+  auto gather = [&](uint32_t e) { if (tri) { if (wr_epoch[e] == cur) ok = false; rd_epoch[e] = cur; } return xs[e]; };
   auto store = [&](uint32_t e, double v) {
-    if (subtract) { if (wr_epoch[e] == cur || rd_epoch[e] == cur) ok = false; wr_epoch[e] = cur; xs[e] = v; }
+    if (tri) { if (wr_epoch[e] == cur || rd_epoch[e] == cur) ok = false; wr_epoch[e] = cur; xs[e] = v; }
     else out[e] = v;
   };
   for (;; cur++) {
@@ -1038,31 +1033,17 @@ static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs
           const uint32_t lt = MI_D_LT(d), T = 1u << lt;
           for (uint32_t ln = 0; ln < 64; ln++) {
             const uint32_t slot = st * 64 + ln;
-            if (s.src[slot] >= 0) acc[w][ln] += canon[s.src[slot]] * gather(s.idx[slot]);
+            if (s.src[slot] != MI_SRC_ZERO) acc[w][ln] += (s.src[slot] == MI_SRC_ONE ? 1.0 : canon[s.src[slot]]) * gather(s.idx[slot]);
           }
           if (d & MI_D_FLUSH) {
             for (uint32_t g = 0; g < 64 / T; g++) {
               double sum = 0.0;
               for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[w][ln];
               const uint32_t row = s.outA[s.step_ob[st] + g];
-              if (row != kNoRow) store(row, subtract ? xs[row] - sum : sum);
+              if (row != kNoRow) store(row, (tri && !(d & MI_D_STORE)) ? xs[row] - sum : sum);
             }
             std::fill(acc[w].begin(), acc[w].end(), 0.0);
           }
-        } else if (MI_D_TYPE(d) == MI_D_TYPE_BLOCK) {
-          const uint32_t task = s.step_ob[st], base = nA + task * (kChunk * (kChunk - 1));
-          const uint32_t *rows = &s.outB[task * kChunk];
-          if (d & MI_D_FIRST) for (int i = 0; i < kChunk; i++) accb[w][i] = rows[i] != kNoRow ? xs[rows[i]] : 0.0;
-          for (int kk = 0; kk < s.bt; kk++) {
-            const int p = (int)MI_D_S(d) * s.bt + kk;
-            if (p >= kChunk - 1) break;
-            const double v = accb[w][p];
-            for (int i = 0; i < kChunk; i++) {
-              const uint32_t slot = base + p * kChunk + i;
-              if (s.src[slot] >= 0) accb[w][i] -= canon[s.src[slot]] * v;
-            }
-          }
-          if (d & MI_D_LAST) for (int i = 0; i < kChunk; i++) if (rows[i] != kNoRow) store(rows[i], accb[w][i]);
         }
         pos[w]++;
       }
@@ -1078,11 +1059,11 @@ static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs
 
 bool replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
   int N = an.N;
-  std::vector<double> xs(N);
+  std::vector<double> xs(an.Next, 0.0);
   for (int k = 0; k < N; k++) xs[k] = rhs[an.perm[k]];
-  bool ok = replay(an.fwd, qp.Lx.data(), xs.data(), (size_t)N, true, nullptr);
-  for (int k = 0; k < N; k++) xs[k] *= qp.Dlinv[k];
-  ok = replay(an.bwd, qp.Lx.data(), xs.data(), (size_t)N, true, nullptr) && ok;
+  bool ok = replay(an.fwd, qp.Lx.data(), xs.data(), xs.size(), true, nullptr);
+  for (int k = 0; k < N; k++) xs[an.xloc[k]] *= qp.Dlinv[k];
+  ok = replay(an.bwd, qp.Lx.data(), xs.data(), xs.size(), true, nullptr) && ok;
   for (int k = 0; k < N; k++) sol[an.perm[k]] = xs[k];
   return ok;
 }
@@ -1143,8 +1124,22 @@ int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric 
         }
     }
   }
-  out.Lx.resize(an.nnzL()); out.Dl = D; out.Dlinv.resize(N);
-  for (int p = 0; p < an.nnzL(); p++) out.Lx[p] = S[bf.lpos[p]];
+  // inverted diagonal blocks, exactly as factor_kernel stores them: inv(L_JJ)[i,k] (i > k) at (row k, col i) of B(J,J)
+  for (uint32_t t = 0; t < bf.dtask.size(); t++) {
+    uint32_t off, r0, c0, h, w; B(bf.dtask[t], off, r0, c0, h, w);
+    double V[kChunk];
+    for (uint32_t k = 0; k + 1 < w; k++) {
+      V[k] = 1.0;
+      for (uint32_t i = k + 1; i < w; i++) {
+        double v = 0.0;
+        for (uint32_t p2 = k; p2 < i; p2++) v = std::fma(-S[off + p2 * h + i], V[p2], v);
+        V[i] = v;
+      }
+      for (uint32_t i = k + 1; i < w; i++) S[off + i * h + k] = V[i];
+    }
+  }
+  out.Lx.resize(an.nnzLx()); out.Dl = D; out.Dlinv.resize(N);
+  for (int p = 0; p < an.nnzLx(); p++) out.Lx[p] = S[bf.lpos[p]];
   for (int j = 0; j < N; j++) out.Dlinv[j] = 1.0 / D[j];
   return positive == n ? MI_OSQP_OK : MI_OSQP_ERR_NONCONVEX;
 }

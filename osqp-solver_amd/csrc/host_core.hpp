@@ -31,41 +31,38 @@ struct Settings {
 };
 int validate_settings(const Settings &s);   // 0 ok
 
-// One pull-schedule: every target row t gets  xs[t] -= sum_k val[k] * xs[idx[k]].
+// One pull-schedule: every target row t gets  xs[t] -= sum_k val[k] * xs[idx[k]]  (or xs[t] = sum, "store").
 //
-// Work is organised as PHASES separated by workgroup barriers (per elimination level: one A phase, then B
-// phases); in every phase each of the nw waves owns one (possibly empty) contiguous range of wave-steps
-// (64 lanes, one slot per lane).  Two kinds of step (descriptor layout: sched_format.h):
-//   row    groups of T = 2^lt lanes accumulate one target row; on a flush step the groups are reduced
-//          and applied to their rows.  Long rows span several steps (flush on the last one).
-//   block  the dense in-chunk triangle of a <=16-row chunk of a supernode, solved column by column inside
-//          ONE wave (lane = (row i, QP b)); element k of lane (i,b) is component k % BT of the task's step
-//          k / BT, so the value stream has one format.
+// Work is organised as PHASES separated by workgroup barriers; in every phase each of the nw waves owns one
+// (possibly empty) contiguous range of wave-steps (64 lanes, one slot per lane).  A step (descriptor layout:
+// sched_format.h) lets groups of T = 2^lt lanes accumulate one target row each; on a flush step the groups are
+// reduced and applied to their rows.  Long rows span several steps (flush on the last one).
+//
+// Triangular solves: per elimination level of <=16-row chunks of supernodes there are two phases,
+//   A  rows of the level minus their couplings to earlier levels:  t_c = b_c - L[c, earlier] x   (subtract)
+//   B  the in-chunk triangle, applied as a dense product with the INVERTED unit-lower diagonal block:
+//      x_c = inv(L_cc) t_c  (store).  The inverse is part of the factor (Analysis::inv_off): a 15-deep
+//      dependent chain inside one wave becomes <=16 independent 16-entry rows.  Inputs t and outputs x of
+//      phase B live at different positions of the solve vector (Analysis::xloc), so the phase is race-free.
 // Steps are numbered WAVE-MAJOR: all steps of wave 0 (phase after phase), then wave 1, ...  A wave therefore
 // walks ONE linear stream per solve, its loads run a fixed number of steps ahead regardless of phase
 // boundaries, and a phase boundary is nothing but a barrier count in the descriptor of the next step.
 //
-// Logical slots (what `src`, `idx` index): step*64 + lane for every step (block steps: no entries there);
-// block-task entries: 64*n_steps + task*240 + k*16 + i.  Physical position of QP b's double inside a tile:
-// row slot: slot*BT + b ; block entry: ((bstep0[task] + k/BT)*64 + i*BT + b)*BT + k%BT for k/BT < bsteps[task].
+// Logical slot = physical slot = step*64 + lane; QP b's double of a slot sits at slot*BT + b inside a tile.
 struct Schedule {
   int n_phases = 0, nw = 0, bt = 1;
   bool barriers = true;          // false: the check-SpMV schedule (independent rows, no barriers at all)
-  std::vector<uint32_t> phase;  // diagnostics / host replay: per phase, stride 4*nw+1: kind(0=A,1=B) then per wave (begin, end, task*16, has block)
+  std::vector<uint32_t> phase;  // diagnostics: per phase, stride 4*nw+1: kind (0 = A, 1 = B) then per wave (begin, end, 0, 0)
   std::vector<int> level_first_phase;   // first phase of every level (+ end)
   std::vector<uint32_t> step;   // per step: descriptor (sched_format.h)
-  std::vector<uint32_t> step_ob;  // per step: row steps: first entry of outA on a flush ; block steps: task
+  std::vector<uint32_t> step_ob;  // per step: first entry of outA on a flush
   std::vector<uint32_t> outA;   // target rows of flush steps (64/T each), kNoRow = none
-  std::vector<uint32_t> outB;   // kChunk rows per block task, processing order
-  std::vector<uint32_t> idx;    // per row slot: gather index into the solve vector
-  std::vector<uint32_t> idxw;   // DEVICE index words, one per slot (n_steps*64): low 16 bits = gather index, high 16
-                                // bits = target row of the lane's group on flush steps / of lane (i,b) in the
-                                // steps of a block task (0xFFFF = none)
-  std::vector<int32_t> src;     // per logical slot: canonical value index, -1 = structural zero
-  uint32_t n_slots = 0;         // logical slots
-  uint32_t n_steps = 0;         // all steps (row and block)
-  uint32_t n_taskB = 0;
-  std::vector<uint32_t> bstep0, bsteps;  // per block task: first step, number of steps (= ceil((rows-1)/bt))
+  std::vector<uint32_t> idx;    // per slot: gather index into the solve vector
+  std::vector<uint32_t> idxw;   // DEVICE index words, one per slot: low 16 bits = gather index, high 16
+                                // bits = target row of the lane's group on flush steps (0xFFFF = none)
+  std::vector<int32_t> src;     // per slot: canonical value index, MI_SRC_ZERO = structural zero, MI_SRC_ONE = 1.0
+  uint32_t n_slots = 0;         // = n_steps * 64
+  uint32_t n_steps = 0;
   std::vector<uint32_t> wave_range;      // 2 per wave: [begin, end) of its stream
   std::vector<uint32_t> lvl_pos;         // (n_levels+1) x nw: stream position of wave w at the start of level L
   std::vector<uint32_t> tail_bar;        // per wave: barriers still owed after its last step (all waves pass n_phases)
@@ -90,7 +87,8 @@ struct BlockFactor {
   std::vector<uint32_t> ttask;        // 2/task : block id, diagonal block id
   std::vector<uint32_t> asm_dst;      // per natural KKT entry: position in block storage
   std::vector<uint32_t> asm_src;      // per natural KKT entry: (kind << 29) | index
-  std::vector<int32_t> lpos;          // canonical L entry -> position in block storage
+  std::vector<int32_t> lpos;          // canonical factor entry (L, then the inverted diagonal blocks) -> position in block
+                                      // storage; inv(L_JJ)[i,k] (i > k) sits in the unused upper triangle of B(J,J), at (k,i)
   int n_levels = 0;
   size_t n_blocks() const { return blk.size() / 4; }
 };
@@ -114,10 +112,23 @@ struct Analysis {
   std::vector<int> sn_start;       // supernode boundaries
   std::vector<int> chunk_start;    // <=16-column chunks (phase-B blocks)
   std::vector<int> chunk_lev;      // forward level of every chunk
+  // inverted diagonal blocks: chunk c with r >= 2 columns owns r(r-1)/2 canonical values after the nnz(L)
+  // entries of L: entry (i,k), i > k (local), at nnzL() + inv_off[c] + k*(2r-k-1)/2 + (i-k-1); inv_off = -1 for r = 1
+  std::vector<int> inv_off;
+  int n_inv = 0;
+  // position in the solve vector of the FORWARD result / BACKWARD input of permuted row j: j itself for
+  // one-row chunks, N + (running index) for the rows of multi-row chunks (Next = vector length)
+  std::vector<int> xloc;
+  int Next = 0;
   Schedule fwd, bwd, chk;
   BlockFactor bf;
   std::vector<int32_t> fwd_srcblk, bwd_srcblk;   // fwd/bwd slot -> block-storage position (-1 = zero)
   int nnzL() const { return Lp.empty() ? 0 : Lp.back(); }
+  int nnzLx() const { return nnzL() + n_inv; }     // length of the canonical factor array QPNumeric::Lx
+  int inv_index(int c, int i, int k) const {       // canonical index of inv(L_cc)[i,k], i > k local
+    const int r = chunk_start[c + 1] - chunk_start[c];
+    return nnzL() + inv_off[c] + k * (2 * r - k - 1) / 2 + (i - k - 1);
+  }
   int nnzK() const { return Kp.empty() ? 0 : Kp.back(); }
 };
 
@@ -125,10 +136,12 @@ struct Analysis {
 // code of include/mi_osqp.h.
 // `nwaves` = waves per workgroup the device kernels will run with, `bt` = QPs per
 // tile (the step programs are laid out per wave; block tasks depend on bt).
+// `max_extra_rows` = how many rows may get a second position in the solve vector (Analysis::xloc): the caller's
+// LDS capacity / the 16-bit index range minus n + m; negative = as many as the 16-bit range allows.
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1);
+            const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1);
 // physical position (in doubles, inside one tile) of QP b's value of a logical slot
-size_t phys_index(const Schedule &s, uint32_t slot, int b);   // (size_t)-1: the slot has no storage (k beyond the task's steps)
+size_t phys_index(const Schedule &s, uint32_t slot, int b);
 
 // Per-QP numeric state kept on the host (needed for rescaling and refactors).
 struct QPNumeric {
@@ -138,7 +151,7 @@ struct QPNumeric {
   double rho = 0.1;
   std::vector<double> rho_vec, rho_inv;
   std::vector<int8_t> ctype;
-  std::vector<double> Lx, Dl, Dlinv;              // factor (canonical CSC order)
+  std::vector<double> Lx, Dl, Dlinv;              // factor: L in canonical CSC order, then the inverted diagonal blocks (Analysis::nnzLx)
 };
 
 void load_qp(const Analysis &an, const Settings &st, const double *Pval, const double *q,

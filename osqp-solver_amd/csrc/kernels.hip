@@ -104,16 +104,11 @@ __device__ __forceinline__ mi_cptr as_const(const uint32_t *p) { return (mi_cptr
 // (a __syncthreads() would drain vmcnt to 0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// physical position (doubles inside one tile) of QP b's value of a logical slot
-// (host twin: host_core.cpp phys_index)
-__device__ __forceinline__ size_t phys_index(const SchedDev &s, uint32_t slot, int b, int BT) {
-  const uint32_t nA = s.n_steps * 64u;
-  if (slot < nA) return MI_D_TYPE(s.step[slot >> 6]) == MI_D_TYPE_BLOCK ? (size_t)-1 : (size_t)slot * BT + b;   // block steps are addressed through their task
-  const uint32_t r = slot - nA, task = r / (MI_CHUNK * (MI_CHUNK - 1)), rem = r % (MI_CHUNK * (MI_CHUNK - 1));
-  const uint32_t k = rem / MI_CHUNK, i = rem % MI_CHUNK;
-  const uint32_t st0 = s.bstep0[task];
-  if (k / BT >= s.bsteps[task]) return (size_t)-1;      // no storage: the task has fewer rows
-  return ((size_t)(st0 + k / BT) * 64 + (size_t)i * BT + b) * BT + k % BT;
+// physical position (doubles inside one tile) of QP b's value of a slot
+__device__ __forceinline__ size_t phys_index(uint32_t slot, int b, int BT) { return (size_t)slot * BT + b; }
+// value of a slot from its source code (host_core.hpp Schedule::src composed with a position map)
+__device__ __forceinline__ double slot_value(int32_t mp, const double *src, size_t stride, int b) {
+  return mp >= 0 ? src[(size_t)mp * stride + b] : (mp == MI_SRC_ONE ? 1.0 : 0.0);
 }
 
 // ----------------------------------------------------------------- row steps
@@ -123,15 +118,15 @@ __device__ __forceinline__ size_t phys_index(const SchedDev &s, uint32_t slot, i
 // steps every lane carries ONE QP's partial sum), then summed toward the first
 // lanes of the group with DPP row shifts; only the two cross-row steps (16, 32)
 // use ds_bpermute.
-// SUB = true : xs[row] -= sum (triangular solves) ; false: out[row] = sum (SpMV)
-template <int BT, bool SUB>
-__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t row, double *base, int lane) {
+// sub = true : base[row] -= sum ; false: base[row] = sum   (wave-uniform)
+template <int BT>
+__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t row, double *base, int lane, bool sub) {
   const bool has_row = row != 0xFFFFu;
   if (lt == 0) {
     if (has_row) {
       double *dst = base + (size_t)row * BT;
 #pragma unroll
-      for (int b = 0; b < BT; b++) { if (SUB) dst[b] -= acc[b]; else dst[b] = acc[b]; }
+      for (int b = 0; b < BT; b++) { if (sub) dst[b] -= acc[b]; else dst[b] = acc[b]; }
     }
     return;
   }
@@ -147,7 +142,7 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
     if (lt == 1) {                       // groups of 2 lanes: even lane owns QPs 0,1 ; odd lane QPs 2,3
       if (has_row) {
         double *dst = base + (size_t)row * BT + (o0 ? 2 : 0);
-        if (SUB) { dst[0] -= k0; dst[1] -= k1; } else { dst[0] = k0; dst[1] = k1; }
+        if (sub) { dst[0] -= k0; dst[1] -= k1; } else { dst[0] = k0; dst[1] = k1; }
       }
       return;
     }
@@ -182,7 +177,7 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
   if (lt > 5) kp += shfl_down_d(kp, 32);
   if (has_row && ((uint32_t)lane & (T - 1)) < nwr) {
     double *dst = base + (size_t)row * BT + q;
-    if (SUB) *dst -= kp; else *dst = kp;
+    if (sub) *dst -= kp; else *dst = kp;
   }
 }
 
@@ -218,37 +213,51 @@ __device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t pos, ui
 }
 
 // Walk the stream [begin, end) of this wave, then pass `tail` more barriers.
-//   SUB  = true : xs[row] -= sum (triangular solves); false: out[row] = sum (SpMV, no block steps)
+//   SUB  = true : triangular solves (xs[row] -= sum, or xs[row] = sum on store steps); false: out[row] = sum (SpMV)
 //   BAR  = the schedule has barriers (GX: full __syncthreads, the vector is in global memory)
 //   TR   = debug instantiation: lane 0 logs the shader clock before / after every barrier into
 //          tr[(ordinal of the barrier * nw + wave) * 2 + {0, 1}]
 template <int BT, int PF, bool SUB, bool BAR, bool GX, bool TR = false>
 __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs,
-                                           double *out, int lane, uint32_t *tr = nullptr, int wave = 0, int nw = 0) {
+                                           double *out, int lane, uint32_t *tr = nullptr, int wave = 0, int nw = 0,
+                                           uint32_t *tw = nullptr) {
   double *base = SUB ? xs : out;
+  // The ring starts empty (all no-ops) and the first revolution only fills it: there is no separate prologue
+  // whose load order the compiler could permute -- with one, the wait counts of the loop (merged over both
+  // entries) collapse to nearly vmcnt(0) and the ring drains at every step.
   Ring<BT, PF> r;
-  r.desc = load_desc(vs, begin, end, lane);
+  r.desc = MI_D_NOOP;
 #pragma unroll
-  for (int st = 0; st < PF; st++) load_step<BT>(vs, begin + (uint32_t)st, lane, r.v[st], r.gi[st]);
+  for (int st = 0; st < PF; st++) {
+    r.gi[st] = 0u;
+#pragma unroll
+    for (int b = 0; b < BT; b++) r.v[st][b] = 0.0;
+  }
   double acc[BT], xq[BT];
 #pragma unroll
   for (int b = 0; b < BT; b++) { acc[b] = 0.0; xq[b] = 0.0; }
-  double accb = 0.0;          // block task: this lane's row of the running solution
   bool pre = false;           // xq already holds the gather of the step about to run
-  uint32_t nbar_seen = 0;
+  uint32_t nbar_seen = 0, wait_cycles = 0, real_steps = 0;
   auto barrier = [&]() {
     if constexpr (TR) { if (lane == 0) tr[((size_t)nbar_seen * nw + wave) * 2] = (uint32_t)__builtin_amdgcn_s_memtime(); }
     if constexpr (GX) __syncthreads(); else lds_barrier();
     if constexpr (TR) { if (lane == 0) tr[((size_t)nbar_seen * nw + wave) * 2 + 1] = (uint32_t)__builtin_amdgcn_s_memtime(); nbar_seen++; }
   };
-  for (uint32_t pos = begin; pos < end; pos += PF) {
-    const uint32_t npos = pos + PF;
+  for (uint32_t npos = begin; npos < end + PF; npos += PF) {   // this revolution runs steps npos - PF + st, loads npos + st
     const uint32_t dnext = load_desc(vs, npos, end, lane);     // older than every refill below
 #pragma unroll
     for (int st = 0; st < PF; st++) {
       const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st);
       if constexpr (BAR) { for (uint32_t nb = MI_D_NBAR(d); nb; nb--) barrier(); }
       const uint32_t type = MI_D_TYPE(d);
+      if constexpr (TR) {            // time spent waiting for the ring slot of this step (exact count: 2 loads per younger slot + dnext)
+        if (type != 3u) {
+          const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+          wait_cycles += (uint32_t)__builtin_amdgcn_s_memtime() - t0;
+          real_steps++;
+        }
+      }
       if (type == MI_D_TYPE_ROW) {
         const uint32_t w = r.gi[st];
         double xv[BT];
@@ -260,40 +269,16 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
         pre = false;
         if (st + 1 < PF) {
           const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st + 1 < PF ? st + 1 : 0);
-          pre = (dn & ~0xFu) == 0u;                 // a row step without barriers in front of it
+          pre = (dn & ~(0xFu | MI_D_STORE)) == 0u;  // a row step without barriers in front of it
           if (pre) load_bt<BT>(xs + (size_t)(r.gi[st + 1 < PF ? st + 1 : 0] & 0xFFFFu) * BT, xq);
         }
 #pragma unroll
         for (int b = 0; b < BT; b++) acc[b] = fma(r.v[st][b], xv[b], acc[b]);
         if (d & MI_D_FLUSH) {
-          reduce_write<BT, SUB>(acc, MI_D_LT(d), w >> 16, base, lane);
+          reduce_write<BT>(acc, MI_D_LT(d), w >> 16, base, lane, SUB && !(d & MI_D_STORE));
 #pragma unroll
           for (int b = 0; b < BT; b++) acc[b] = 0.0;
         }
-      } else if (SUB && type == MI_D_TYPE_BLOCK) {
-        // ---- block step: lane = (i, b); columns k = s*BT + kk of the in-chunk triangle, value of column k in
-        // v[kk]; local row k is broadcast to the lanes of the same QP with v_readlane (SGPR lane select)
-        pre = false;
-        const int b = lane % BT;
-        const uint32_t row = r.gi[st] >> 16;
-        const bool valid = row != 0xFFFFu;
-        if (d & MI_D_FIRST) accb = valid ? xs[(size_t)row * BT + b] : 0.0;
-        const int k0 = (int)MI_D_S(d) * BT;
-#pragma unroll
-        for (int kk = 0; kk < BT; kk++) {
-          double vb[BT];
-#pragma unroll
-          for (int bb = 0; bb < BT; bb++) {
-            const int lo = __builtin_amdgcn_readlane(__double2loint(accb), (k0 + kk) * BT + bb);
-            const int hi = __builtin_amdgcn_readlane(__double2hiint(accb), (k0 + kk) * BT + bb);
-            vb[bb] = __hiloint2double(hi, lo);
-          }
-          double v = vb[0];
-          if constexpr (BT >= 2) v = (b & 1) ? vb[1] : v;
-          if constexpr (BT == 4) { const double v2 = (b & 1) ? vb[3] : vb[2]; v = (b & 2) ? v2 : v; }
-          accb = fma(-r.v[st][kk], v, accb);
-        }
-        if ((d & MI_D_LAST) && valid) xs[(size_t)row * BT + b] = accb;
       } else {
         pre = false;
       }
@@ -303,15 +288,16 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
     r.desc = dnext;
   }
   if constexpr (BAR) { for (uint32_t nb = tail; nb; nb--) barrier(); }
+  if constexpr (TR) { if (lane == 0) { tw[2 * wave] = wait_cycles; tw[2 * wave + 1] = real_steps; } }
 }
 
 // One triangular solve: this wave's whole stream of the schedule.
 template <int BT, int PF, bool GX, bool TR = false>
 __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane,
-                                        uint32_t *tr = nullptr) {
+                                        uint32_t *tr = nullptr, uint32_t *tw = nullptr) {
   mi_cptr lp = as_const(s.lvl_pos);
   const uint32_t begin = lp[wave], end = lp[(size_t)s.n_levels * s.nw + wave], tail = as_const(s.tail_bar)[wave];
-  run_stream<BT, PF, true, true, GX, TR>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw);
+  run_stream<BT, PF, true, true, GX, TR>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw, tw);
 }
 
 // SpMV with the same streams: levels [l0, l1) of the check schedule (independent rows, no barriers)
@@ -411,7 +397,7 @@ template <int BT, int PF, bool GX>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
                                               int tid, int nthr, int wave, int nw, int lane) {
   run_tri<BT, PF, GX>(a.fwd, p.vfwd, xs, wave, lane);
-  for (int e = tid; e < a.N * BT; e += nthr) xs[e] *= p.dinv[e];
+  for (int e = tid; e < a.N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= p.dinv[e];
   __syncthreads();
   run_tri<BT, PF, GX>(a.bwd, p.vbwd, xs, wave, lane);
 }
@@ -723,7 +709,7 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
 // Debug twin of kkt_solve_kernel<2, 512, false> (MI_OSQP trace entry point, scripts/trace_phases.py): same
 // solve, plus per-phase / per-wave shader-clock stamps of tiles {0, gridDim/2} copied to trace[2][words].
 // Layout of one tile's words: [0..3] = memtime / memrealtime at start and end (low words),
-// then fwd stamps [n_phases_fwd][nw][2], then bwd stamps.
+// then per sweep and wave (cycles spent waiting for ring slots, real steps), then fwd stamps [n_phases_fwd][nw][2], then bwd stamps.
 __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol,
                                                        uint32_t *trace, uint32_t words) {
   constexpr int BT = 2;
@@ -742,11 +728,12 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
   }
   __syncthreads();
   if (tid == 0) { tr[0] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
-  uint32_t *trf = tr + 4, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
-  run_tri<BT, MI_PFV, false, true>(a.fwd, p.vfwd, xs, wave, lane, trf);
-  for (int e = tid; e < N * BT; e += nthr) xs[e] *= p.dinv[e];
+  uint32_t *twf = tr + 4, *twb = twf + 2 * nw;          // per wave: cycles waited for ring slots, real steps
+  uint32_t *trf = twb + 2 * nw, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
+  run_tri<BT, MI_PFV, false, true>(a.fwd, p.vfwd, xs, wave, lane, trf, twf);
+  for (int e = tid; e < N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= p.dinv[e];
   __syncthreads();
-  run_tri<BT, MI_PFV, false, true>(a.bwd, p.vbwd, xs, wave, lane, trb);
+  run_tri<BT, MI_PFV, false, true>(a.bwd, p.vbwd, xs, wave, lane, trb, twb);
   if (tid == 0) { tr[2] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
@@ -922,6 +909,29 @@ __device__ __forceinline__ void fct_diag(const FactorArgs &a, double *Lb, double
   if (ok) {
     for (uint32_t k = 0; k < (uint32_t)i; k++) Lb[((size_t)off + k * w + i) * BT + b] = Ss[MI_BS(k, b, i)];
   }
+  // inv(L_JJ) for the solve schedules (phase B = product with the inverted diagonal block): lane (k, b) owns
+  // column k of the inverse, V[i] = -sum_{p=k}^{i-1} L[i,p] V[p]; all lanes of a QP read the same L[i,p]
+  // (LDS broadcast).  Stored in the unused upper triangle of the block: inv[i,k] at (row k, col i).
+  if (w >= 2) {
+    const uint32_t k = (uint32_t)i;
+    double V[MI_CHUNK];
+#pragma unroll
+    for (int r = 0; r < MI_CHUNK; r++) V[r] = (uint32_t)r == k ? 1.0 : 0.0;
+#pragma unroll
+    for (int r = 1; r < MI_CHUNK; r++) {
+      if ((uint32_t)r < w) {               // uniform
+        double v = 0.0;
+#pragma unroll
+        for (int p2 = 0; p2 < r; p2++) v = fma(-Ss[MI_BS(p2, b, r)], V[p2], v);   // V[p2] = 0 for p2 < k
+        if ((uint32_t)r > k) V[r] = v;
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int r = 1; r < MI_CHUNK; r++)
+        if ((uint32_t)r < w && (uint32_t)r > k) Lb[((size_t)off + r * w + k) * BT + b] = V[r];
+    }
+  }
 }
 
 template <int BT>
@@ -1029,15 +1039,11 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     double *fv = a.fwd_val + (size_t)tile * a.fwd.n_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.n_steps * 64 * BT;
     for (size_t e = tid; e < (size_t)a.fwd.n_slots * BT; e += nthr) {
       const uint32_t sl = (uint32_t)(e / BT);
-      const int32_t mp = a.fwd_srcblk[sl];
-      const size_t ph = phys_index(a.fwd, sl, b, BT);
-      if (ph != (size_t)-1) fv[ph] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+      fv[phys_index(sl, b, BT)] = slot_value(a.fwd_srcblk[sl], Lb, BT, b);
     }
     for (size_t e = tid; e < (size_t)a.bwd.n_slots * BT; e += nthr) {
       const uint32_t sl = (uint32_t)(e / BT);
-      const int32_t mp = a.bwd_srcblk[sl];
-      const size_t ph = phys_index(a.bwd, sl, b, BT);
-      if (ph != (size_t)-1) bv[ph] = mp >= 0 ? Lb[(size_t)mp * BT + b] : 0.0;
+      bv[phys_index(sl, b, BT)] = slot_value(a.bwd_srcblk[sl], Lb, BT, b);
     }
     for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
   }
@@ -1083,14 +1089,11 @@ __global__ void scatter_kernel(const double *__restrict__ src, double *dst, cons
   const int j = (int)(g / slots);
   const uint32_t s = (uint32_t)(g % slots);
   const int q = ids ? ids[j] : j;
-  const int mp = map[s];
   const size_t tile_doubles = (size_t)sd.n_steps * 64 * BT;
-  const size_t ph = phys_index(sd, s, q % BT, BT);
-  if (ph != (size_t)-1) dst[(size_t)(q / BT) * tile_doubles + ph] = mp >= 0 ? src[(size_t)j * srclen + mp] : 0.0;
+  dst[(size_t)(q / BT) * tile_doubles + phys_index(s, q % BT, BT)] = slot_value(map[s], src + (size_t)j * srclen, 1, 0);
 }
 // Compaction support: exchange the complete per-QP contents of slot pairs (slot =
-// tile*BT + b).  Plain arrays are [tile][len][BT]; scheduled value arrays use the
-// physical layout of phys_index (block-task region interleaved differently).
+// tile*BT + b).  Every array is [tile][len][BT].
 __global__ void swap_plain_kernel(double *base, const int2 *pairs, int npairs, int len, int BT) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)npairs * len) return;
@@ -1110,22 +1113,13 @@ __global__ void swap_int_kernel(int *base, const int2 *pairs, int npairs, int le
   const int t = *pa; *pa = *pb; *pb = t;
 }
 __global__ void swap_sched_kernel(double *base, const int2 *pairs, int npairs, SchedDev sd, int BT) {
-  // 64 elements per QP and step.  Row steps: element j = lane j, component b of the lane's BT-vector;
-  // block steps: element j = (i = j / BT, c = j % BT) lives in lane i*BT + b, component c.
   const size_t per = (size_t)sd.n_steps * 64;
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)npairs * per) return;
   const int2 pr = pairs[g / per];
-  const size_t u = g % per, step = u / 64, j = u % 64;
-  const size_t tile_doubles = (size_t)sd.n_steps * 64 * BT;
-  size_t ea, eb;
-  if (MI_D_TYPE(sd.step[step]) != MI_D_TYPE_BLOCK) { ea = u * BT + pr.x % BT; eb = u * BT + pr.y % BT; }
-  else {
-    const size_t i = j / BT, c = j % BT;
-    ea = ((step * 64) + i * BT + pr.x % BT) * BT + c; eb = ((step * 64) + i * BT + pr.y % BT) * BT + c;
-  }
-  double *pa = base + (size_t)(pr.x / BT) * tile_doubles + ea;
-  double *pb = base + (size_t)(pr.y / BT) * tile_doubles + eb;
+  const size_t u = g % per;
+  double *pa = base + ((size_t)(pr.x / BT) * per + u) * BT + pr.x % BT;
+  double *pb = base + ((size_t)(pr.y / BT) * per + u) * BT + pr.y % BT;
   const double t = *pa; *pa = *pb; *pb = t;
 }
 

@@ -98,16 +98,16 @@ struct DevBuf {
 };
 
 struct SchedBufs {
-  DevBuf<uint32_t> step, idxw, bstep0, bsteps, lvl_pos, tail_bar;
+  DevBuf<uint32_t> step, idxw, lvl_pos, tail_bar;
   DevBuf<int32_t> src;
   int upload(const Schedule &s) {
     int rc;
-    if ((rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src)) || (rc = bstep0.upload(s.bstep0)) ||
-        (rc = bsteps.upload(s.bsteps)) || (rc = lvl_pos.upload(s.lvl_pos)) || (rc = tail_bar.upload(s.tail_bar))) return rc;
+    if ((rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src)) ||
+        (rc = lvl_pos.upload(s.lvl_pos)) || (rc = tail_bar.upload(s.tail_bar))) return rc;
     return 0;
   }
   SchedDev view(const Schedule &s) const {
-    SchedDev d; d.step = step.p; d.idxw = idxw.p; d.bstep0 = bstep0.p; d.bsteps = bsteps.p; d.lvl_pos = lvl_pos.p; d.tail_bar = tail_bar.p;
+    SchedDev d; d.step = step.p; d.idxw = idxw.p; d.lvl_pos = lvl_pos.p; d.tail_bar = tail_bar.p;
     d.n_phases = s.n_phases; d.nw = s.nw; d.n_levels = s.n_levels;
     d.n_steps = s.n_steps; d.n_slots = s.n_slots;
     return d;
@@ -123,7 +123,7 @@ struct mi_osqp_batch {
   bool host_bounds_stale = false;
   hipStream_t stream = nullptr;
   SchedBufs fwd, bwd, chk;
-  DevBuf<uint32_t> pinv;
+  DevBuf<uint32_t> pinv, xloc;
   DevBuf<double> fwd_val, bwd_val, chk_val, dinv, x, z, y, q, l, u, rho_vec, rho_inv, Dsc, Dsc_inv, Esc, Esc_inv;
   DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out, xs_global;
   bool global_xs = false;
@@ -180,14 +180,14 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   KernelArgs a{};
   a.n = h->an.n; a.m = h->an.m; a.N = h->an.N; a.B = h->B;
   a.fwd = h->fwd.view(h->an.fwd); a.bwd = h->bwd.view(h->an.bwd); a.chk = h->chk.view(h->an.chk);
-  a.pinv = h->pinv.p;
+  a.pinv = h->pinv.p; a.xloc = h->xloc.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.chk_val = h->chk_val.p; a.dinv = h->dinv.p;
   a.x = h->x.p; a.z = h->z.p; a.y = h->y.p; a.q = h->q.p; a.l = h->l.p; a.u = h->u.p;
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Dsc = h->Dsc.p; a.Dsc_inv = h->Dsc_inv.p;
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
-  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.N;
+  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.Next;
   const Settings &s = h->st;
   a.sigma = s.sigma; a.alpha = s.alpha; a.eps_abs = s.eps_abs; a.eps_rel = s.eps_rel;
   a.eps_prim_inf = s.eps_prim_inf; a.eps_dual_inf = s.eps_dual_inf; a.rho_tolerance = s.adaptive_rho_tolerance;
@@ -244,7 +244,7 @@ static std::vector<double> gather_rows(const std::vector<int> &ids, int len, G &
 // upload factors (canonical Lx + Dlinv on the host) of the listed QPs
 static int upload_factors(mi_osqp_batch *h, const std::vector<int> &ids) {
   const Analysis &an = h->an;
-  int nq = (int)ids.size(), nnzL = an.nnzL(), N = an.N;
+  int nq = (int)ids.size(), nnzL = an.nnzLx(), N = an.N;
   if (!nq) return 0;
   std::vector<double> rows = gather_rows(ids, nnzL, [&](int q) -> const std::vector<double> & { return h->qp[q].Lx; });
   int rc = ensure_stage(h, std::max<size_t>(rows.size(), 1), ids.size());
@@ -414,7 +414,13 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   while (BT > 1 && lds_bytes((int)(n + m), BT, h->threads) > lds_cap) BT /= 2;
   // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
   h->global_xs = lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
-  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT);
+  // rows that may get a second vector position (phase B of the solves): what still fits LDS / 16-bit indices
+  int max_extra = 65534 - (int)(n + m);
+  if (!h->global_xs) {
+    const size_t cap_rows = (lds_cap - lds_bytes(0, BT, h->threads)) / (sizeof(double) * BT);
+    max_extra = (int)std::min<size_t>((size_t)max_extra, cap_rows - (size_t)(n + m));
+  }
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT, max_extra);
   if (rc) return rc;
   const Analysis &an = h->an;
   h->B = (int)B;
@@ -428,17 +434,18 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
   h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT);
-  h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.N, BT, h->threads);
+  h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.Next, BT, h->threads);
   // ---- device arrays
   size_t T = (size_t)h->ntiles * BT;
   if ((rc = h->fwd.upload(an.fwd)) || (rc = h->bwd.upload(an.bwd)) || (rc = h->chk.upload(an.chk))) return rc;
   { std::vector<uint32_t> pv(an.pinv.begin(), an.pinv.end()); if ((rc = h->pinv.upload(pv))) return rc; }
+  { std::vector<uint32_t> xv(an.xloc.begin(), an.xloc.end()); if ((rc = h->xloc.upload(xv))) return rc; }
 #define ALLOC(buf, len) if ((rc = h->buf.alloc((size_t)(len) * T)) || (rc = h->buf.zero(h->stream))) return rc
   ALLOC(fwd_val, (size_t)an.fwd.phys_steps() * 64); ALLOC(bwd_val, (size_t)an.bwd.phys_steps() * 64); ALLOC(chk_val, (size_t)an.chk.phys_steps() * 64); ALLOC(dinv, an.N);
   ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
-  if (h->global_xs) { ALLOC(xs_global, an.N); }
+  if (h->global_xs) { ALLOC(xs_global, an.Next); }
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
   {
@@ -915,7 +922,7 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
   if (!h) return MI_OSQP_ERR_NULL;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
-  size_t lds = (size_t)(h->an.N + 2 * h->an.n + h->an.m) * h->BT * sizeof(double);
+  size_t lds = (size_t)(h->an.Next + 2 * h->an.n + h->an.m) * h->BT * sizeof(double);
   a.op_out_lds = !h->global_xs && lds <= 160 * 1024;
   if (!a.op_out_lds) lds = h->lds;
   HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
@@ -936,7 +943,7 @@ int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double 
                                   int64_t cap, int64_t *dims) {
   if (!h || !dims) return MI_OSQP_ERR_NULL;
   const int nw = h->threads / 64;
-  const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 4 + (fp + bp) * nw * 2;
+  const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 4 + 4 * nw + (fp + bp) * nw * 2;
   dims[0] = fp; dims[1] = bp; dims[2] = nw; dims[3] = words;
   if (!out) return MI_OSQP_OK;
   if (which == 1 || which == 2) {

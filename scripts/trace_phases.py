@@ -21,8 +21,10 @@ for ti in range(2):
     dt_clk = np.uint32(t[2] - t[0]); dt_real = np.uint32(t[3] - t[1])
     mhz = float(dt_clk) / (float(dt_real) / 100.0)      # s_memrealtime ticks at 100 MHz
     print(f"tile sel {ti}: total {float(dt_real)/100.0:.1f} us, memtime clock {mhz:.0f} MHz")
-    off = 4
-    for name, tab, P in (("fwd", ftab, fp), ("bwd", btab, bp)):
+    tw = t[4: 4 + 4 * nw].reshape(2, nw, 2).astype(np.int64)
+    off = 4 + 4 * nw
+    for si, (name, tab, P) in enumerate((("fwd", ftab, fp), ("bwd", btab, bp))):
+        print(f"  {name}: per wave waiting for ring data (us): {[round(float(c) / mhz, 1) for c in tw[si, :, 0]]} steps {tw[si, :, 1].tolist()}")
         st = t[off: off + P * nw * 2].reshape(P, nw, 2).astype(np.int64); off += P * nw * 2
         before, after = st[:, :, 0], st[:, :, 1]
         kind = tab[:, 0]
