@@ -293,6 +293,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     for (const RowWork &rw : rows) {
       int len = std::max<int>(1, (int)rw.ent.size());
       if (len > 64) { longs.push_back(&rw); continue; }
+      if (kind == 1) { byTS[ilog2(kChunk) * 4].push_back(&rw); continue; }   // phase B: <=16 entries, one step, 4 rows per step
       int bestlt = 6, bestS = 1, bestcost = 1 << 30;
       for (int lt = 0; lt <= 6; lt++) {
         int T = 1 << lt, S = (len + T - 1) / T;
@@ -394,6 +395,19 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     while (L < levels.size()) sch.lvl_pos[L++ * nw + w] = sch.n_steps;
     sch.lvl_pos[levels.size() * nw + w] = sch.n_steps;
     sch.wave_range[2 * w + 1] = sch.n_steps;
+    // gather look-ahead flags: a step may issue the gather of the step MI_D_LOOKAHEAD positions later when
+    // no barrier and no level boundary (sub-range walks start there) lies in between
+    {
+      const uint32_t b0 = sch.wave_range[2 * w], e0 = sch.n_steps;
+      std::vector<char> level_start(e0 - b0 + 1, 0);
+      for (size_t l2 = 0; l2 <= levels.size(); l2++) level_start[sch.lvl_pos[l2 * nw + w] - b0] = 1;
+      auto eligible = [&](uint32_t q) { return MI_D_NBAR(sch.step[q]) == 0 && !level_start[q - b0]; };
+      for (uint32_t q = b0; q + MI_D_LOOKAHEAD < e0; q++) {
+        bool okk = true;
+        for (uint32_t j = 1; j <= MI_D_LOOKAHEAD; j++) okk = okk && eligible(q + j);
+        if (okk) { sch.step[q] |= MI_D_AHEAD; sch.step[q + MI_D_LOOKAHEAD] |= MI_D_PRE; }
+      }
+    }
     // every wave passes exactly n_phases barriers per walk (the last one publishes the final phase)
     sch.tail_bar[w] = barriers ? (uint32_t)(sch.n_phases - last_phase) : 0u;
   }

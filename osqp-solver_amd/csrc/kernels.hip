@@ -17,6 +17,7 @@
 //   * The same row-task machinery evaluates P x, A' y and A x for the residuals.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_types.h"
 #include "sched_format.h"
@@ -116,24 +117,59 @@ __device__ __forceinline__ double slot_value(int32_t mp, const double *src, size
 // target row (`row`: every lane of a group carries it, 0xFFFF = none).  The BT
 // per-QP partial sums are "transposed" across lanes on the way (after log2(BT)
 // steps every lane carries ONE QP's partial sum), then summed toward the first
-// lanes of the group with DPP row shifts; only the two cross-row steps (16, 32)
-// use ds_bpermute.
-// sub = true : base[row] -= sum ; false: base[row] = sum   (wave-uniform)
+// lanes of the group with DPP row shifts; the two cross-row steps (16, 32) use the
+// gfx950 v_permlane16_swap / v_permlane32_swap -- no LDS round trip anywhere.
+// sub = true : base[row] = old - sum (old = the row's previous value, fetched by
+// flush_prefetch before the reduction) ; false: base[row] = sum   (wave-uniform)
+
+// value of lane + 16 for rows 0 and 2 / of lane + 32 for lanes 0..31 (other lanes: don't care)
+__device__ __forceinline__ double down16_d(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)rh[1], (int)rl[1]);
+}
+__device__ __forceinline__ double down32_d(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
+// which QP component a lane ends up carrying after the transposition, and how many writer lanes a group has
 template <int BT>
-__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t row, double *base, int lane, bool sub) {
+__device__ __forceinline__ int flush_q(int lane) {
+  if constexpr (BT == 4) return ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+  else if constexpr (BT == 2) return lane & 1;
+  else return 0;
+}
+template <int BT>
+__device__ __forceinline__ void flush_prefetch(uint32_t lt, uint32_t row, const double *base, int lane, double (&oldv)[BT]) {
+#pragma unroll
+  for (int b = 0; b < BT; b++) oldv[b] = 0.0;
+  if (row == 0xFFFFu) return;
+  const double *dst = base + (size_t)row * BT;
+  if (lt == 0) { load_bt<BT>(dst, oldv); return; }
+  if constexpr (BT == 4) {
+    if (lt == 1) { const double2 t = *reinterpret_cast<const double2 *>(dst + ((lane & 1) ? 2 : 0)); oldv[0] = t.x; oldv[1] = t.y; return; }
+  }
+  if (((uint32_t)lane & ((1u << lt) - 1u)) < (uint32_t)BT) oldv[0] = dst[flush_q<BT>(lane)];
+}
+
+template <int BT>
+__device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t row, double *base, int lane, bool sub,
+                                             const double (&oldv)[BT]) {
   const bool has_row = row != 0xFFFFu;
   if (lt == 0) {
     if (has_row) {
       double *dst = base + (size_t)row * BT;
 #pragma unroll
-      for (int b = 0; b < BT; b++) { if (sub) dst[b] -= acc[b]; else dst[b] = acc[b]; }
+      for (int b = 0; b < BT; b++) dst[b] = sub ? oldv[b] - acc[b] : acc[b];
     }
     return;
   }
   const uint32_t T = 1u << lt;
   double kp;
-  int q;            // QP this lane ends up carrying
-  uint32_t nwr;     // number of writer lanes at the start of each group
   if constexpr (BT == 4) {
     const bool o0 = lane & 1;
     const double s0 = o0 ? acc[0] : acc[2], s1 = o0 ? acc[1] : acc[3];
@@ -142,7 +178,7 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
     if (lt == 1) {                       // groups of 2 lanes: even lane owns QPs 0,1 ; odd lane QPs 2,3
       if (has_row) {
         double *dst = base + (size_t)row * BT + (o0 ? 2 : 0);
-        if (sub) { dst[0] -= k0; dst[1] -= k1; } else { dst[0] = k0; dst[1] = k1; }
+        dst[0] = sub ? oldv[0] - k0 : k0; dst[1] = sub ? oldv[1] - k1 : k1;
       }
       return;
     }
@@ -150,8 +186,6 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
     const double sd = o1 ? k0 : k1;
     kp = o1 ? k1 : k0;
     kp += dpp_d<DPP_XOR2>(sd);
-    q = (o0 ? 2 : 0) + (o1 ? 1 : 0);
-    nwr = 4;
     if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
     if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
   } else if constexpr (BT == 2) {
@@ -159,26 +193,20 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
     const double sd = o0 ? acc[0] : acc[1];
     kp = o0 ? acc[1] : acc[0];
     kp += dpp_d<DPP_XOR1>(sd);
-    q = o0 ? 1 : 0;
-    nwr = 2;
     if (lt > 1) kp += dpp_d<DPP_SHL(2)>(kp);
     if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
     if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
   } else {
     kp = acc[0];
-    q = 0;
-    nwr = 1;
     kp += dpp_d<DPP_SHL(1)>(kp);
     if (lt > 1) kp += dpp_d<DPP_SHL(2)>(kp);
     if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
     if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
   }
-  if (lt > 4) kp += shfl_down_d(kp, 16);
-  if (lt > 5) kp += shfl_down_d(kp, 32);
-  if (has_row && ((uint32_t)lane & (T - 1)) < nwr) {
-    double *dst = base + (size_t)row * BT + q;
-    if (sub) *dst -= kp; else *dst = kp;
-  }
+  if (lt > 4) kp += down16_d(kp);
+  if (lt > 5) kp += down32_d(kp);
+  if (has_row && ((uint32_t)lane & (T - 1)) < (uint32_t)BT)
+    base[(size_t)row * BT + flush_q<BT>(lane)] = sub ? oldv[0] - kp : kp;
 }
 
 // ---- per-wave step streams with a register ring -------------------------------------
@@ -215,9 +243,9 @@ __device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t pos, ui
 // Walk the stream [begin, end) of this wave, then pass `tail` more barriers.
 //   SUB  = true : triangular solves (xs[row] -= sum, or xs[row] = sum on store steps); false: out[row] = sum (SpMV)
 //   BAR  = the schedule has barriers (GX: full __syncthreads, the vector is in global memory)
-//   TR   = debug instantiation: lane 0 logs the shader clock before / after every barrier into
-//          tr[(ordinal of the barrier * nw + wave) * 2 + {0, 1}]
-template <int BT, int PF, bool SUB, bool BAR, bool GX, bool TR = false>
+//   TR   = debug instantiations: 1: lane 0 logs the shader clock before / after every barrier into
+//          tr[(ordinal of the barrier * nw + wave) * 2 + {0, 1}]; 2: also the time spent waiting for ring slots
+template <int BT, int PF, bool SUB, bool BAR, bool GX, int TR = 0>
 __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs,
                                            double *out, int lane, uint32_t *tr = nullptr, int wave = 0, int nw = 0,
                                            uint32_t *tw = nullptr) {
@@ -233,10 +261,15 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
 #pragma unroll
     for (int b = 0; b < BT; b++) r.v[st][b] = 0.0;
   }
-  double acc[BT], xq[BT];
+  static_assert(PF % (MI_D_LOOKAHEAD + 1) == 0, "the gather slots must line up across ring revolutions");
+  constexpr int GS = MI_D_LOOKAHEAD + 1;      // gather slots: step q uses slot q % GS
+  double acc[BT], xq[GS][BT];
 #pragma unroll
-  for (int b = 0; b < BT; b++) { acc[b] = 0.0; xq[b] = 0.0; }
-  bool pre = false;           // xq already holds the gather of the step about to run
+  for (int b = 0; b < BT; b++) {
+    acc[b] = 0.0;
+#pragma unroll
+    for (int g = 0; g < GS; g++) xq[g][b] = 0.0;
+  }
   uint32_t nbar_seen = 0, wait_cycles = 0, real_steps = 0;
   auto barrier = [&]() {
     if constexpr (TR) { if (lane == 0) tr[((size_t)nbar_seen * nw + wave) * 2] = (uint32_t)__builtin_amdgcn_s_memtime(); }
@@ -250,7 +283,7 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
       const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st);
       if constexpr (BAR) { for (uint32_t nb = MI_D_NBAR(d); nb; nb--) barrier(); }
       const uint32_t type = MI_D_TYPE(d);
-      if constexpr (TR) {            // time spent waiting for the ring slot of this step (exact count: 2 loads per younger slot + dnext)
+      if constexpr (TR >= 2) {       // time spent waiting for the ring slot of this step (exact count: 2 loads per younger slot + dnext)
         if (type != 3u) {
           const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memtime();
           asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
@@ -260,27 +293,27 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
       }
       if (type == MI_D_TYPE_ROW) {
         const uint32_t w = r.gi[st];
-        double xv[BT];
-        if (!pre) load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xq);
-#pragma unroll
-        for (int b = 0; b < BT; b++) xv[b] = xq[b];
-        // gather of the next step ahead of this step's flush: inside one phase no step reads what another
-        // one writes (pull schedule; checked by the host replay), so the read may pass the write
-        pre = false;
-        if (st + 1 < PF) {
-          const uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st + 1 < PF ? st + 1 : 0);
-          pre = (dn & ~(0xFu | MI_D_STORE)) == 0u;  // a row step without barriers in front of it
-          if (pre) load_bt<BT>(xs + (size_t)(r.gi[st + 1 < PF ? st + 1 : 0] & 0xFFFFu) * BT, xq);
+        // Vector gathers run MI_D_LOOKAHEAD steps ahead of their fma (flags set by the host: no barrier in
+        // between).  Inside one phase no step reads what another one writes (pull schedule; checked by the
+        // host replay), so a gather may pass the flushes of the steps before it.
+        if (!(d & MI_D_PRE)) load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xq[st % GS]);
+        const bool sub = SUB && !(d & MI_D_STORE);
+        const bool flush = d & MI_D_FLUSH;
+        // the old value of the target row (read-modify-write) is fetched before the reduction starts
+        double oldv[BT];
+        const uint32_t lt = MI_D_LT(d), row = w >> 16;
+        if (flush && sub) flush_prefetch<BT>(lt, row, base, lane, oldv);
+        if (d & MI_D_AHEAD) {
+          const int s2 = (st + MI_D_LOOKAHEAD) % PF;         // past the end of this revolution: the slot was refilled already
+          load_bt<BT>(xs + (size_t)(r.gi[s2] & 0xFFFFu) * BT, xq[(st + MI_D_LOOKAHEAD) % GS]);
         }
 #pragma unroll
-        for (int b = 0; b < BT; b++) acc[b] = fma(r.v[st][b], xv[b], acc[b]);
-        if (d & MI_D_FLUSH) {
-          reduce_write<BT>(acc, MI_D_LT(d), w >> 16, base, lane, SUB && !(d & MI_D_STORE));
+        for (int b = 0; b < BT; b++) acc[b] = fma(r.v[st][b], xq[st % GS][b], acc[b]);
+        if (flush) {
+          reduce_write<BT>(acc, lt, row, base, lane, sub, oldv);
 #pragma unroll
           for (int b = 0; b < BT; b++) acc[b] = 0.0;
         }
-      } else {
-        pre = false;
       }
       // ring refill: this slot now carries step npos + st
       load_step<BT>(vs, npos + (uint32_t)st, lane, r.v[st], r.gi[st]);
@@ -288,11 +321,11 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
     r.desc = dnext;
   }
   if constexpr (BAR) { for (uint32_t nb = tail; nb; nb--) barrier(); }
-  if constexpr (TR) { if (lane == 0) { tw[2 * wave] = wait_cycles; tw[2 * wave + 1] = real_steps; } }
+  if constexpr (TR >= 2) { if (lane == 0) { tw[2 * wave] = wait_cycles; tw[2 * wave + 1] = real_steps; } }
 }
 
 // One triangular solve: this wave's whole stream of the schedule.
-template <int BT, int PF, bool GX, bool TR = false>
+template <int BT, int PF, bool GX, int TR = 0>
 __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane,
                                         uint32_t *tr = nullptr, uint32_t *tw = nullptr) {
   mi_cptr lp = as_const(s.lvl_pos);
@@ -710,6 +743,7 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
 // solve, plus per-phase / per-wave shader-clock stamps of tiles {0, gridDim/2} copied to trace[2][words].
 // Layout of one tile's words: [0..3] = memtime / memrealtime at start and end (low words),
 // then per sweep and wave (cycles spent waiting for ring slots, real steps), then fwd stamps [n_phases_fwd][nw][2], then bwd stamps.
+template <int TRL>
 __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol,
                                                        uint32_t *trace, uint32_t words) {
   constexpr int BT = 2;
@@ -730,10 +764,10 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
   if (tid == 0) { tr[0] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
   uint32_t *twf = tr + 4, *twb = twf + 2 * nw;          // per wave: cycles waited for ring slots, real steps
   uint32_t *trf = twb + 2 * nw, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
-  run_tri<BT, MI_PFV, false, true>(a.fwd, p.vfwd, xs, wave, lane, trf, twf);
+  run_tri<BT, MI_PFV, false, TRL>(a.fwd, p.vfwd, xs, wave, lane, trf, twf);
   for (int e = tid; e < N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= p.dinv[e];
   __syncthreads();
-  run_tri<BT, MI_PFV, false, true>(a.bwd, p.vbwd, xs, wave, lane, trb, twb);
+  run_tri<BT, MI_PFV, false, TRL>(a.bwd, p.vbwd, xs, wave, lane, trb, twb);
   if (tid == 0) { tr[2] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
@@ -1200,10 +1234,12 @@ hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads,
   if (BT != 2 || a.xs_global || threads != 512) return hipErrorInvalidValue;
   const size_t total = (size_t)a.xs_len * BT * sizeof(double) + (size_t)words * 4;
   if (total > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&kkt_trace_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
-  if (e != hipSuccess) return e;
   (void)lds;
-  hipLaunchKernelGGL(kkt_trace_kernel, dim3(tiles), dim3(threads), total, st, a, rhs, sol, trace, words);
+  const bool waits = getenv("MI_OSQP_TRACE_WAITS") != nullptr;     // per-step ring-wait timing (slows every step down)
+  auto kern = waits ? &kkt_trace_kernel<2> : &kkt_trace_kernel<1>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), total, st, a, rhs, sol, trace, words);
   return hipGetLastError();
 }
 hipError_t launch_warm_start(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st, const double *x0) {

@@ -9,6 +9,9 @@
 //   bit  3     flush   reduce the groups and apply them to their rows
 //   bits 4-5   type    0 row step, 3 no-op
 //   bit  6     store   flush writes the sum (row = sum) instead of subtracting it (row -= sum)
+//   bit  7     pre     the gather of this step was already issued by the step two positions earlier
+//   bit  8     ahead   issue the gather of the step two positions later (the two steps in between and after
+//                      are row steps of the same level without barriers in front of them)
 //   bits 12-31 nbar    barriers before this step
 #pragma once
 #define MI_D_LT(d) ((d) & 7u)
@@ -17,6 +20,9 @@
 #define MI_D_TYPE_ROW 0u
 #define MI_D_NOOP 0x30u
 #define MI_D_STORE 0x40u
+#define MI_D_PRE 0x80u
+#define MI_D_AHEAD 0x100u
+#define MI_D_LOOKAHEAD 2
 #define MI_D_NBAR(d) ((d) >> 12)
 #define MI_D_NBAR_MAX 0xFFFFFu
 // value-source codes of a slot (Schedule::src and the maps derived from it)
