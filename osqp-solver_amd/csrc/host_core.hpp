@@ -135,7 +135,7 @@ struct Analysis {
 // E1 (pattern part), E4, E5-symbolic and the schedules.  Returns 0 or an error
 // code of include/mi_osqp.h.
 // `nwaves` = waves per workgroup the device kernels will run with, `bt` = QPs per
-// tile (the step programs are laid out per wave; block tasks depend on bt).
+// tile (the step streams are laid out per wave; bt only sizes the physical layout).
 // `max_extra_rows` = how many rows may get a second position in the solve vector (Analysis::xloc): the caller's
 // LDS capacity / the 16-bit index range minus n + m; negative = as many as the 16-bit range allows.
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,

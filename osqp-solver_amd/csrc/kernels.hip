@@ -10,10 +10,12 @@
 //     no grid-wide synchronisation ever exists; the KKT solve vector lives in
 //     LDS (N*BT doubles), the factor streams from HBM in schedule order.
 //   * The triangular solves are "pull" schedules built on the host
-//     (host_core.cpp): per elimination level, phase A = wave tasks that gather
-//     from the LDS vector and butterfly-reduce groups of T lanes into one
-//     target row; phase B = the dense in-chunk triangle of a supernode solved
-//     column-by-column inside one wave with lane broadcasts.
+//     (host_core.cpp): every wave walks one linear stream of wave-steps per
+//     sweep; per elimination level, phase A = steps that gather from the LDS
+//     vector and reduce groups of T lanes into one target row, phase B = the
+//     in-chunk triangle applied as a product with the inverted diagonal block
+//     (same kind of step, "store" flavour); phase boundaries are barrier counts
+//     in the step descriptors (sched_format.h).
 //   * The same row-task machinery evaluates P x, A' y and A x for the residuals.
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -171,6 +171,12 @@ static Settings to_settings(const mi_osqp_settings *s) {
   return t;
 }
 
+// threads per tile of the refactorisation kernel (experiments: MI_OSQP_FACTOR_THREADS)
+static int factor_threads() {
+  const char *e = getenv("MI_OSQP_FACTOR_THREADS");
+  return e ? std::max(64, std::min(1024, atoi(e) / 64 * 64)) : 1024;
+}
+
 static size_t lds_bytes(int N, int BT, int threads) {
   int nw = threads / 64;
   return ((size_t)N * BT + (size_t)nw * 14 * BT + 14 * BT) * sizeof(double);
@@ -632,7 +638,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     if (n_ref) {
       double tr = now_s();
       FactorArgs fa = make_factor_args(h, 0);
-      HIPCHK(launch_factor(fa, BT, ntl, 1024, h->stream));
+      HIPCHK(launch_factor(fa, BT, ntl, factor_threads(), h->stream));
       HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       for (int s = 0; s < ntl * BT; s++)
@@ -909,7 +915,7 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
 int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
   FactorArgs fa = make_factor_args(h, 1);
-  HIPCHK(launch_factor(fa, h->BT, h->ntiles, 1024, h->stream));
+  HIPCHK(launch_factor(fa, h->BT, h->ntiles, factor_threads(), h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int q = 0; q < h->B; q++)
