@@ -731,7 +731,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) { int pos = nxt[n + an.Ai[k]]++; an.Ki[pos] = j; an.AtoK[k] = pos; }
   for (int r = 0; r < m; r++) { int pos = nxt[n + r]++; an.Ki[pos] = n + r; an.rhotoK[r] = pos; }
   // ---- ordering: two candidates, chosen by the modelled time of one KKT solve on the device
-  // (phases cost ~1.5 us each, the factor streams at ~18 GB/s per CU)
+  // (latency-bound regime of one tile, measured with scripts/trace_phases.py: ~0.4 us per phase, ~40 GB/s of factor stream)
   if (max_extra_rows < 0 || max_extra_rows > 65534 - N) max_extra_rows = std::max(0, 65534 - N);
   auto finalize = [&](const std::vector<int> &perm0, double &cost) {
     an.perm = perm0;
@@ -800,7 +800,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     for (int c = 0; c < nch; c++) if (an.chunk_start[c + 1] - an.chunk_start[c] >= 2) blocks_at[lev[c]]++;
     int phases = depth;
     for (int L = 0; L < depth; L++) phases += blocks_at[L] ? 1 : 0;
-    cost = 2.0 * phases * 1.5e-6 + 2.0 * 8.0 * bt * 1.3 * (double)an.Lp[N] / 18e9;
+    cost = 2.0 * phases * 0.4e-6 + 2.0 * 8.0 * bt * 1.15 * (double)an.Lp[N] / 40e9;
   };
   {
     std::vector<int> p_md, p_nd;
