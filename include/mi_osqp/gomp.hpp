@@ -15,6 +15,7 @@
 // The reference prints every waypoint; here printing is off unless `verbose` is set.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cassert>
 #include <cmath>
@@ -230,7 +231,9 @@ class ConstraintBuilder {
     QPMatrixSparse A;
     A.rows = (long long)lo_.size(); A.cols = (long long)(2 * N_DIM * W_);
     A.outer.assign(A.cols + 1, 0);
-    for (const auto &[cr, v] : cells_) { A.outer[cr.first + 1]++; A.inner.push_back((long long)cr.second); A.values.push_back(v); }
+    normalise();
+    A.inner.reserve(cells_.size()); A.values.reserve(cells_.size());
+    for (const Cell &c : cells_) { A.outer[c.col + 1]++; A.inner.push_back((long long)c.row); A.values.push_back(c.v); }
     for (long long j = 0; j < A.cols; ++j) A.outer[j + 1] += A.outer[j];
     return {lo_, A, up_};
   }
@@ -243,7 +246,24 @@ class ConstraintBuilder {
   size_t W_, user_off_ = 0;
   std::vector<RobotBall> balls_;
   std::vector<HorizontalLine> lines_;
-  std::map<std::pair<size_t, size_t>, double> cells_;          // (col, row) -> value: CSC order, last write wins
+  // (col, row) -> value, last write wins ([REF] constraint-builder.h:129).  A write log that is sorted into CSC
+  // order and de-duplicated on demand: the builder runs once per trajectory, segment and re-linearisation,
+  // and a std::map made it the bottleneck of the batched driver.
+  struct Cell { size_t col, row; double v; };
+  mutable std::vector<Cell> cells_;
+  mutable bool sorted_ = true;
+  void set(size_t col, size_t row, double v) { cells_.push_back({col, row, v}); sorted_ = false; }
+  void normalise() const {
+    if (sorted_) return;
+    std::stable_sort(cells_.begin(), cells_.end(), [](const Cell &a, const Cell &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+    size_t o = 0;
+    for (size_t k = 0; k < cells_.size(); ++k) {
+      if (k + 1 < cells_.size() && cells_[k + 1].col == cells_[k].col && cells_[k + 1].row == cells_[k].row) continue;   // a later write wins
+      cells_[o++] = cells_[k];
+    }
+    cells_.resize(o);
+    sorted_ = true;
+  }
   std::vector<double> lo_, up_;
 
   static OptPair dim(size_t j, const Constraint<N_DIM> &c) {
@@ -253,7 +273,7 @@ class ConstraintBuilder {
     return r;
   }
   void put(size_t row, std::initializer_list<std::pair<size_t, double>> eq, OptPair b) {
-    for (const auto &[col, coeff] : eq) cells_[{col, row}] = coeff;
+    for (const auto &[col, coeff] : eq) set(col, row, coeff);
     if (b.first) lo_[row] = *b.first;
     if (b.second) up_[row] = *b.second;
     assert(lo_[row] <= up_[row]);
@@ -265,7 +285,7 @@ class ConstraintBuilder {
   }
   void axisRow(size_t row, const RobotBall &ball, Axis axis, const std::array<double, 3 * N_DIM> &J, size_t waypoint,
                double low, double upp) {
-    for (size_t j = 0; j < N_DIM; ++j) cells_[{nthPos(waypoint) + j, row}] = J[axis * N_DIM + j];
+    for (size_t j = 0; j < N_DIM; ++j) set(nthPos(waypoint) + j, row, J[axis * N_DIM + j]);
     lo_[row] = low + ball.radius;
     up_[row] = upp - ball.radius;
     assert(lo_[row] <= up_[row]);
@@ -372,6 +392,145 @@ class GOMPSolver {
       for (int w = 0; w < waypoints; ++w) {
         const Point p{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]};
         if (verbose) std::printf("(%f, %f, %f)\n", p[X], p[Y], p[Z]);
+        if (ball.is_gripper) {
+          for (Axis axis : XYZ_AXES) {
+            const double lo = con_3d.first ? (*con_3d.first)[axis] : -INF;
+            const double up = con_3d.second ? (*con_3d.second)[axis] : INF;
+            if (!(lo - ERROR <= p[axis] - ball.radius && p[axis] + ball.radius <= up + ERROR)) res = false;
+          }
+        }
+        for (const HorizontalLine &line : obstacles)
+          if (line.hasCollision(w, xyz, ball) && !line.isAbove(p, ball)) res = false;
+      }
+    }
+    return res;
+  }
+};
+
+// ------------------------------------------------------ batched driver ("many trajectories")
+// B independent (start, end) pairs run the same horizon-shrinking / SQP schedule as GOMPSolver::run in
+// LOCK-STEP on one BatchQPSolver: all trajectories of a segment share W, hence one sparsity pattern.  Each
+// trajectory follows exactly the decisions the sequential driver would take for it (same QPs, same updates,
+// same accepted solutions); trajectories that have finished a segment simply keep their constraints while the
+// others re-linearise (their extra solves start from the converged iterate and stop at the first check).
+template <size_t N_DIM, class BatchSolverT = BatchQPSolver>
+class BatchGOMPSolver {
+ public:
+  BatchGOMPSolver(size_t waypoints, double time_step, const Constraint<N_DIM> &pos_con, const Constraint<N_DIM> &vel_con,
+                  const Constraint<N_DIM> &acc_con, const Constraint<3> &con_3d, std::vector<HorizontalLine> obstacles,
+                  std::vector<RobotBall> m, bool verbose = false)
+      : max_waypoints(waypoints), time_step(time_step), pos_con(pos_con),
+        vel_con(constraints::scaled<N_DIM>(vel_con, time_step)),
+        acc_con(constraints::scaled<N_DIM>(acc_con, time_step * time_step)), con_3d(con_3d),
+        obstacles(std::move(obstacles)), mappers(std::move(m)), verbose(verbose) {
+    assert(max_waypoints >= 4);
+  }
+
+  std::vector<std::pair<ExitCode, QPVector>> run(const std::vector<Ctrl<N_DIM>> &starts, const std::vector<Ctrl<N_DIM>> &ends) {
+    const size_t B = starts.size();
+    assert(ends.size() == B && B > 0);
+    std::vector<QPVector> last_solution(B);
+    std::vector<ExitCode> last_code(B, ExitCode::kUnknown);
+    std::vector<char> alive(B, 1);
+    segments_run.assign(B, 0); qp_solves.assign(B, 0); qp_updates.assign(B, 0);
+    batch_solves = 0;
+    for (size_t b = 0; b < B; ++b) {
+      last_solution[b] = linspace<N_DIM>(starts[b], ends[b], max_waypoints);      // joint-space line, zero velocities
+      last_solution[b].resize(2 * max_waypoints * N_DIM, 0.0);
+    }
+    for (int i = SEGMENTS; i >= 1; --i) {
+      const size_t waypoints = max_waypoints * i / SEGMENTS;
+      std::vector<size_t> ids;                                 // batch slot -> trajectory
+      for (size_t b = 0; b < B; ++b) if (alive[b]) ids.push_back(b);
+      if (ids.empty()) break;
+      const size_t K = ids.size();
+      std::vector<QPVector> warm(K), seg_solution(K);
+      std::vector<ExitCode> seg_code(K, ExitCode::kUnknown);
+      std::vector<ConstraintBuilder<N_DIM>> builders;
+      builders.reserve(K);
+      std::vector<QPConstraints> cons(K);
+      for (size_t k = 0; k < K; ++k) {
+        const QPVector &prev = last_solution[ids[k]];
+        warm[k].resize(waypoints * N_DIM * 2);
+        for (size_t t = 0; t < waypoints * N_DIM; ++t) {        // same slicing as GOMPSolver::run
+          warm[k][t] = prev[t];
+          warm[k][waypoints * N_DIM + t] = prev[waypoints * N_DIM + t];
+        }
+        builders.push_back(initConstraints(starts[ids[k]], ends[ids[k]], warm[k], waypoints));
+        cons[k] = builders[k].build();
+        seg_solution[k] = warm[k];
+      }
+      BatchSolverT qp{cons, triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * waypoints), (int)(waypoints * N_DIM), (int)N_DIM), verbose};
+      qp.setWarmStart(warm);
+      std::vector<char> running(K, 1);
+      size_t n_running = K;
+      for (int it = 0; it < MAX_ITERATIONS && n_running; ++it) {
+        auto res = qp.solve();
+        ++batch_solves;
+        bool need_update = false;
+        for (size_t k = 0; k < K; ++k) {
+          if (!running[k]) continue;
+          ++qp_solves[ids[k]];
+          const auto &[exit_code, solution] = res[k];
+          if (exit_code != ExitCode::kOptimal) { seg_solution[k] = solution; running[k] = 0; --n_running; continue; }
+          if (isSolutionOK(solution)) { seg_solution[k] = solution; seg_code[k] = ExitCode::kOptimal; running[k] = 0; --n_running; continue; }
+          if (it + 1 < MAX_ITERATIONS) {
+            cons[k] = builders[k].withObstacles(con_3d, solution).build();
+            ++qp_updates[ids[k]];
+            need_update = true;
+          }
+        }
+        if (need_update && n_running) qp.update(cons);
+      }
+      for (size_t k = 0; k < K; ++k) {
+        const size_t b = ids[k];
+        ++segments_run[b];
+        if (seg_code[k] != ExitCode::kOptimal && seg_code[k] != ExitCode::kUnknown) { alive[b] = 0; continue; }
+        if (seg_code[k] == ExitCode::kOptimal) { last_code[b] = ExitCode::kOptimal; last_solution[b] = seg_solution[k]; }
+      }
+    }
+    std::vector<std::pair<ExitCode, QPVector>> out(B);
+    for (size_t b = 0; b < B; ++b) {
+      for (size_t t = last_solution[b].size() / 2; t < last_solution[b].size(); ++t) last_solution[b][t] /= time_step;
+      out[b] = {last_code[b], last_solution[b]};
+    }
+    return out;
+  }
+
+  // per-trajectory counters (comparable with GOMPSolver's) and the number of batched solves
+  std::vector<int> segments_run, qp_solves, qp_updates;
+  int batch_solves = 0;
+
+ private:
+  const size_t max_waypoints;
+  const double time_step;
+  const Constraint<N_DIM> pos_con, vel_con, acc_con;
+  const Constraint<3> con_3d;
+  const std::vector<HorizontalLine> obstacles;
+  const std::vector<RobotBall> mappers;
+  const bool verbose;
+
+  ConstraintBuilder<N_DIM> initConstraints(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, const QPVector &warm_start,
+                                           size_t waypoints) const {
+    ConstraintBuilder<N_DIM> b{waypoints, mappers, obstacles};
+    b.position(0, constraints::equal<N_DIM>(start_pos))
+        .positions(1, waypoints - 2, pos_con)
+        .position(waypoints - 3, constraints::equal<N_DIM>(end_pos))
+        .velocities(0, waypoints - 4, vel_con)
+        .velocity(waypoints - 3, constraints::eqZero<N_DIM>())
+        .accelerations(0, waypoints - 4, acc_con)
+        .acceleration(waypoints - 3, constraints::eqZero<N_DIM>())
+        .withObstacles(con_3d, warm_start);
+    return b;
+  }
+
+  bool isSolutionOK(const QPVector &q_trajectory) const {
+    bool res = true;
+    for (const RobotBall &ball : mappers) {
+      const QPVector xyz = mapJointTrajectoryToXYZ<N_DIM>(q_trajectory, ball.fk);
+      const int waypoints = (int)xyz.size() / 3;
+      for (int w = 0; w < waypoints; ++w) {
+        const Point p{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]};
         if (ball.is_gripper) {
           for (Axis axis : XYZ_AXES) {
             const double lo = con_3d.first ? (*con_3d.first)[axis] : -INF;

@@ -127,4 +127,105 @@ class QPSolver {
   mi_osqp_info last_{};
 };
 
+// Batched twin of QPSolver on the mi_osqp_batch_* entry points: K QPs that share ONE sparsity pattern (the
+// GOMP situation, [REF] src/constraints/constraint-builder.h:112-116) advance in lock-step on one GPU.  Method
+// set and error behaviour follow QPSolver; everything is per-QP vectors in the order of construction.
+class BatchQPSolver {
+ public:
+  BatchQPSolver(const std::vector<QPConstraints> &cs, const QPMatrixSparse &P, bool verbose = false,
+                const mi_osqp_settings *custom = nullptr)
+      : K_((long long)cs.size()) {
+    assert(!cs.empty());
+    const QPMatrixSparse &A0 = std::get<1>(cs[0]);
+    n_ = A0.cols; m_ = A0.rows;
+    mi_osqp_settings s;
+    mi_osqp_default_settings(&s);
+    if (custom) s = *custom;
+    s.verbose = verbose;
+    std::vector<double> Pv, Av, l, u;
+    bool ok = P.rows == n_ && P.cols == n_;
+    for (const QPConstraints &c : cs) {
+      const auto &[lo, A, up] = c;
+      ok = ok && A.rows == m_ && A.cols == n_ && A.outer == A0.outer && A.inner == A0.inner &&
+           (long long)lo.size() == m_ && (long long)up.size() == m_;
+      if (!ok) break;
+      Pv.insert(Pv.end(), P.values.begin(), P.values.end());
+      Av.insert(Av.end(), A.values.begin(), A.values.end());
+      l.insert(l.end(), lo.begin(), lo.end());
+      u.insert(u.end(), up.begin(), up.end());
+    }
+    int rc = MI_OSQP_ERR_INVALID_DATA;
+    if (ok)
+      rc = mi_osqp_batch_setup(&h_, K_, n_, m_, reinterpret_cast<const int64_t *>(P.outer.data()),
+                               reinterpret_cast<const int64_t *>(P.inner.data()), Pv.data(), nullptr,
+                               reinterpret_cast<const int64_t *>(A0.outer.data()),
+                               reinterpret_cast<const int64_t *>(A0.inner.data()), Av.data(), l.data(), u.data(), &s, -1);
+    status_ = rc;
+    assert(rc == MI_OSQP_OK);
+  }
+  ~BatchQPSolver() { mi_osqp_batch_free(h_); }
+  BatchQPSolver(const BatchQPSolver &) = delete;
+  BatchQPSolver &operator=(const BatchQPSolver &) = delete;
+
+  void update(const std::vector<QPConstraints> &cs) {
+    if ((long long)cs.size() != K_) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_INVALID_DATA));
+    const QPMatrixSparse &A0 = std::get<1>(cs[0]);
+    std::vector<double> Av, l, u;
+    for (const QPConstraints &c : cs) {
+      const auto &[lo, A, up] = c;
+      if (A.outer != A0.outer || A.inner != A0.inner) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_PATTERN_CHANGED));
+      Av.insert(Av.end(), A.values.begin(), A.values.end());
+      l.insert(l.end(), lo.begin(), lo.end());
+      u.insert(u.end(), up.begin(), up.end());
+    }
+    int rc = mi_osqp_batch_update_A(h_, reinterpret_cast<const int64_t *>(A0.outer.data()),
+                                    reinterpret_cast<const int64_t *>(A0.inner.data()), Av.data());
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));
+    rc = mi_osqp_batch_update_bounds(h_, l.data(), u.data());
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));
+  }
+  // bounds only (the joint-space GOMP rows never change A)
+  void updateBounds(const std::vector<QPConstraints> &cs) {
+    std::vector<double> l, u;
+    for (const QPConstraints &c : cs) {
+      l.insert(l.end(), std::get<0>(c).begin(), std::get<0>(c).end());
+      u.insert(u.end(), std::get<2>(c).begin(), std::get<2>(c).end());
+    }
+    int rc = (long long)cs.size() == K_ ? mi_osqp_batch_update_bounds(h_, l.data(), u.data()) : (int)MI_OSQP_ERR_INVALID_DATA;
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));
+  }
+
+  void setWarmStart(const std::vector<QPVector> &xs) {
+    std::vector<double> x;
+    for (const QPVector &v : xs) x.insert(x.end(), v.begin(), v.end());
+    int rc = (long long)x.size() == K_ * n_ ? mi_osqp_batch_warm_start_x(h_, x.data()) : (int)MI_OSQP_ERR_INVALID_DATA;
+    assert(rc == MI_OSQP_OK);
+    (void)rc;
+  }
+
+  std::vector<std::pair<OsqpExitCode, QPVector>> solve() {
+    std::vector<std::pair<OsqpExitCode, QPVector>> out((size_t)K_, {OsqpExitCode::kUnknown, QPVector((size_t)n_)});
+    if (mi_osqp_batch_solve(h_) != MI_OSQP_OK) return out;
+    std::vector<double> x((size_t)(K_ * n_));
+    infos_.resize((size_t)K_);
+    mi_osqp_batch_get_primal(h_, x.data());
+    mi_osqp_batch_get_info(h_, infos_.data());
+    for (long long k = 0; k < K_; k++) {
+      out[(size_t)k].first = static_cast<OsqpExitCode>(infos_[(size_t)k].exit_code);
+      std::copy(x.begin() + k * n_, x.begin() + (k + 1) * n_, out[(size_t)k].second.begin());
+    }
+    return out;
+  }
+
+  int setup_status() const { return status_; }
+  const std::vector<mi_osqp_info> &last_infos() const { return infos_; }
+  long long size() const { return K_; }
+
+ private:
+  mi_osqp_batch *h_ = nullptr;
+  long long K_ = 0, n_ = 0, m_ = 0;
+  int status_ = 0;
+  std::vector<mi_osqp_info> infos_;
+};
+
 }  // namespace miosqp_ref

@@ -900,6 +900,14 @@ void scale_qp(const Analysis &an, const Settings &st, QPNumeric &qp) {
   for (int i = 0; i < m; i++) { qp.l[i] *= qp.E[i]; qp.u[i] *= qp.E[i]; }
 }
 
+// qp holds the same unscaled P, A, q as `rep` did before scale_qp(rep): take over rep's equilibration instead
+// of recomputing it (GOMP batches: every trajectory shares P and A, only the bounds differ)
+void scale_like(const Analysis &an, const QPNumeric &rep, QPNumeric &qp) {
+  qp.Pv = rep.Pv; qp.Av = rep.Av; qp.q = rep.q;
+  qp.D = rep.D; qp.Dinv = rep.Dinv; qp.E = rep.E; qp.Einv = rep.Einv; qp.c = rep.c; qp.cinv = rep.cinv;
+  for (int i = 0; i < an.m; i++) { qp.l[i] *= qp.E[i]; qp.u[i] *= qp.E[i]; }
+}
+
 void unscale_qp(const Analysis &an, QPNumeric &qp) {
   int n = an.n, m = an.m;
   for (int j = 0; j < n; j++)

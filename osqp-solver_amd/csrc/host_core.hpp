@@ -157,6 +157,7 @@ struct QPNumeric {
 void load_qp(const Analysis &an, const Settings &st, const double *Pval, const double *q,
              const double *Aval, const double *l, const double *u, QPNumeric &qp);
 void scale_qp(const Analysis &an, const Settings &st, QPNumeric &qp);       // E2
+void scale_like(const Analysis &an, const QPNumeric &rep, QPNumeric &qp);   // same unscaled P, A, q as rep: reuse its scaling
 void unscale_qp(const Analysis &an, QPNumeric &qp);
 void set_rho_vec(const Analysis &an, const Settings &st, QPNumeric &qp);    // E3
 // returns 1 if any constraint type changed (bounds update path of E13)

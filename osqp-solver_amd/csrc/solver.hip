@@ -426,7 +426,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const size_t cap_rows = (lds_cap - lds_bytes(0, BT, h->threads)) / (sizeof(double) * BT);
     max_extra = (int)std::min<size_t>((size_t)max_extra, cap_rows - (size_t)(n + m));
   }
+  const double ta0 = now_s();
   int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT, max_extra);
+  const double t_analysis = now_s() - ta0;
   if (rc) return rc;
   const Analysis &an = h->an;
   h->B = (int)B;
@@ -482,16 +484,30 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   for (int c0 = 0; c0 < B; c0 += CH) {
     int c1 = (int)std::min<int64_t>(B, c0 + CH);
     double ta = now_s();
-    parallel_for(c1 - c0, [&](int k, int tid) {
+    // QPs whose P, A, q equal those of the chunk's first QP (GOMP: all of them, only bounds differ) reuse its
+    // equilibration and, when their rho vector matches too, its factor
+    std::vector<char> dup(c1 - c0, 0);
+    for (int k = 1; k < c1 - c0; k++) {
+      const int qi = c0 + k;
+      dup[k] = !memcmp(Pv + (size_t)qi * nnzPin, Pv + (size_t)c0 * nnzPin, sizeof(double) * nnzPin) &&
+               !memcmp(Av + (size_t)qi * nnzA, Av + (size_t)c0 * nnzA, sizeof(double) * nnzA) &&
+               (!q || !memcmp(q + (size_t)qi * n, q + (size_t)c0 * n, sizeof(double) * n));
+    }
+    auto numeric = [&](int k, int tid, bool second_pass) {
+      if ((bool)dup[k] != second_pass) return;
       int qi = c0 + k;
       QPNumeric &Q = h->qp[qi];
       load_qp(an, h->st, Pv + (size_t)qi * nnzPin, q ? q + (size_t)qi * n : nullptr, Av + (size_t)qi * nnzA,
               l + (size_t)qi * m, u + (size_t)qi * m, Q);
-      if (h->st.scaling) scale_qp(an, h->st, Q);
+      const QPNumeric &R = h->qp[c0];
+      if (h->st.scaling) { if (second_pass) scale_like(an, R, Q); else scale_qp(an, h->st, Q); }
       set_rho_vec(an, h->st, Q);
+      if (second_pass && Q.rho_vec == R.rho_vec) { Q.Lx = R.Lx; Q.Dl = R.Dl; Q.Dlinv = R.Dlinv; return; }
       int r = factor_qp(an, h->st, Q, works[tid]);
       if (r) fail.store(r);
-    });
+    };
+    parallel_for(c1 - c0, [&](int k, int tid) { numeric(k, tid, false); });
+    if (!fail.load()) parallel_for(c1 - c0, [&](int k, int tid) { numeric(k, tid, true); });
     double tb = now_s();
     t_factor += tb - ta;
     if (fail.load()) return fail.load();
@@ -520,6 +536,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   s.fwd_slots = (int64_t)an.fwd.phys_steps() * 64; s.bwd_slots = (int64_t)an.bwd.phys_steps() * 64; s.chk_slots = (int64_t)an.chk.phys_steps() * 64;
   s.lds_bytes = (int64_t)h->lds; s.threads_per_block = h->threads;
   s.setup_seconds_host = t1 - t0; s.setup_seconds_factor = t_factor; s.setup_seconds_upload = t_upload;
+  if (getenv("MI_OSQP_DEBUG_TIMING"))
+    fprintf(stderr, "[mi_osqp] setup B=%d N=%d: analysis+alloc %.1f ms (analysis %.1f), numeric %.1f ms, upload %.1f ms, rest %.1f ms\n", (int)B, an.N,
+            1e3 * (t1 - t0), 1e3 * t_analysis, 1e3 * t_factor, 1e3 * t_upload, 1e3 * (now_s() - t1 - t_factor - t_upload));
   return MI_OSQP_OK;
 }
 

@@ -4,10 +4,12 @@
 //                         known-answer tests ([REF] /root/reference/tests/test.cpp:82-100,250-448;
 //                         the joint-space ones are covered in tests/test_builder_kats.py) against
 //                         include/mi_osqp/gomp.hpp.  Expected numbers are the reference's data.
+//   ./gomp_parity batch   GPU: BatchGOMPSolver (lock-step on the batch API) vs sequential drivers.
 //   ./gomp_parity parity  GPU: runs GOMPSolver<3> twice on the same inputs -- once on the MI355X
 //                         QPSolver, once on an oracle-backed twin -- and compares trajectories.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -186,8 +188,102 @@ static int run_parity() {
   return fails ? 1 : 0;
 }
 
+// GPU: B trajectories in lock-step on the batch API vs one sequential GOMPSolver per trajectory (GPU QPSolver
+// and oracle twin): same exit codes, same per-trajectory counters, same trajectories.
+static int run_batch() {
+  const double pi = 3.14159265358979323846;
+  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}};
+  std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
+  auto pos = constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi));
+  auto vel = constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi));
+  auto acc = constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180));
+  auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF});
+  std::vector<Ctrl<3>> starts, ends;
+  for (int b = 0; b < 5; ++b) {
+    starts.push_back({-0.8 + 0.1 * b, 0.3 + 0.02 * b, 0.4 - 0.03 * b});
+    ends.push_back({0.8 - 0.05 * b, 0.3, 0.4 + 0.02 * b});
+  }
+  starts.push_back({0.2, 0.5, 0.3}); ends.push_back({0.5, 0.6, 0.2});          // never comes near the line
+  BatchGOMPSolver<3> bg(40, 0.1, pos, vel, acc, c3d, lines, balls);
+  auto rb = bg.run(starts, ends);
+  int total_updates = 0;
+  for (size_t b = 0; b < starts.size(); ++b) {
+    GOMPSolver<3, QPSolver> g(40, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+    auto [code_g, x_g] = g.run(starts[b], ends[b]);
+    GOMPSolver<3, OracleQPSolver> o(40, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+    auto [code_o, x_o] = o.run(starts[b], ends[b]);
+    double md_g = 0.0, md_o = 0.0;
+    CHECK(rb[b].second.size() == x_g.size() && x_g.size() == x_o.size());
+    for (size_t k = 0; k < x_g.size() && k < rb[b].second.size(); ++k) {
+      md_g = std::fmax(md_g, std::fabs(rb[b].second[k] - x_g[k]));
+      md_o = std::fmax(md_o, std::fabs(rb[b].second[k] - x_o[k]));
+    }
+    std::printf("traj %zu batch: %s segments %d solves %d updates %d | sequential gpu: %s %d %d %d | oracle: %s %d %d %d | max|dx| gpu %.3e oracle %.3e\n",
+                b, ToString(rb[b].first).c_str(), bg.segments_run[b], bg.qp_solves[b], bg.qp_updates[b], ToString(code_g).c_str(),
+                g.segments_run, g.qp_solves, g.qp_updates, ToString(code_o).c_str(), o.segments_run, o.qp_solves, o.qp_updates, md_g, md_o);
+    CHECK(rb[b].first == code_g && code_g == code_o);
+    CHECK(bg.segments_run[b] == g.segments_run && bg.qp_solves[b] == g.qp_solves && bg.qp_updates[b] == g.qp_updates);
+    CHECK(g.qp_solves == o.qp_solves && g.qp_updates == o.qp_updates);
+    CHECK(md_g <= 1e-9);
+    CHECK(md_o <= 1e-6);
+    total_updates += bg.qp_updates[b];
+  }
+  CHECK(total_updates > 0);
+  std::printf("batched solves %d for %zu trajectories\n", bg.batch_solves, starts.size());
+  std::printf(fails ? "BATCH FAILED (%d)\n" : "BATCH OK\n", fails);
+  return fails ? 1 : 0;
+}
+
+// GPU: BASELINE config 4 as an end-to-end workload: B joint-space trajectories (7-DOF, W = 100, limits as
+// [REF] examples/solver-example.cpp:44-46 replicated to 7 joints) through the batched driver, timed against
+// the sequential driver on the oracle backend for a sample of them.   usage: gomp_parity bench [B] [W] [sample]
+#include <chrono>
+#include <random>
+static int run_bench(int B, int W, int sample) {
+  const double pi = 3.14159265358979323846;
+  constexpr size_t D = 7;
+  auto pos = constraints::inRange<D>(constraints::of<D>(-2 * pi), constraints::of<D>(2 * pi));
+  auto vel = constraints::inRange<D>(constraints::of<D>(-pi), constraints::of<D>(pi));
+  auto acc = constraints::inRange<D>(constraints::of<D>(-pi * 800 / 180), constraints::of<D>(pi * 800 / 180));
+  auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, -INF}, Vec<3>{INF, INF, INF});
+  std::vector<Ctrl<D>> starts(B), ends(B);
+  for (int b = 0; b < B; ++b) {
+    std::mt19937_64 rng(2000 + b);
+    std::uniform_real_distribution<double> U(-pi, pi);
+    for (size_t j = 0; j < D; ++j) { starts[b][j] = U(rng); ends[b][j] = U(rng); }
+  }
+  using clk = std::chrono::steady_clock;
+  BatchGOMPSolver<D> bg(W, 0.1, pos, vel, acc, c3d, {}, {});
+  auto t0 = clk::now();
+  auto rb = bg.run(starts, ends);
+  const double tg = std::chrono::duration<double>(clk::now() - t0).count();
+  int ok = 0, solves = 0;
+  for (int b = 0; b < B; ++b) { ok += rb[b].first == ExitCode::kOptimal; solves += bg.qp_solves[b]; }
+  std::printf("batched driver: %d trajectories (D=7, W=%d): %.3f s = %.1f trajectories/s, %d QP solves in %d batched solves, %d optimal\n",
+              B, W, tg, B / tg, solves, bg.batch_solves, ok);
+  sample = std::min(sample, B);
+  t0 = clk::now();
+  double md = 0.0;
+  for (int b = 0; b < sample; ++b) {
+    GOMPSolver<D, OracleQPSolver> o(W, 0.1, pos, vel, acc, c3d, {}, {}, nullptr, false);
+    auto [code, x] = o.run(starts[b], ends[b]);
+    CHECK(code == rb[b].first);
+    CHECK(o.qp_solves == bg.qp_solves[b]);
+    for (size_t k = 0; k < x.size(); ++k) md = std::fmax(md, std::fabs(x[k] - rb[b].second[k]));
+  }
+  const double tc = std::chrono::duration<double>(clk::now() - t0).count();
+  std::printf("sequential driver on the oracle (1 thread): %d trajectories: %.3f s = %.1f trajectories/s; max|dx| vs batch %.3e\n",
+              sample, tc, sample / tc, md);
+  CHECK(md <= 1e-6);
+  std::printf(fails ? "BENCH FAILED (%d)\n" : "BENCH OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && !std::strcmp(argv[1], "kats")) return run_kats();
+  if (argc > 1 && !std::strcmp(argv[1], "bench"))
+    return run_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
+  if (argc > 1 && !std::strcmp(argv[1], "batch")) return run_batch();
   if (argc > 1 && !std::strcmp(argv[1], "parity")) return run_parity();
   if (argc > 1 && !std::strcmp(argv[1], "oracle")) {          // CPU only: the driver on the oracle backend
     for (int obst = 0; obst < 2; ++obst) {

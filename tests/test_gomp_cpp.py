@@ -45,3 +45,11 @@ def test_sqp_driver_on_oracle_backend(exe):
 def test_gomp_driver_gpu_matches_oracle_backend(exe):
     r = subprocess.run([exe, "parity"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PARITY OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_batched_gomp_driver_matches_sequential_drivers(exe):
+    """SURVEY 8(f) rank 1, batched: 6 trajectories in lock-step on the batch API take exactly the decisions
+    of 6 sequential GOMPSolver runs (GPU QPSolver and oracle twin)."""
+    r = subprocess.run([exe, "batch"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "BATCH OK" in r.stdout, r.stdout + r.stderr
