@@ -4,6 +4,7 @@
 //                         known-answer tests ([REF] /root/reference/tests/test.cpp:82-100,250-448;
 //                         the joint-space ones are covered in tests/test_builder_kats.py) against
 //                         include/mi_osqp/gomp.hpp.  Expected numbers are the reference's data.
+//   ./gomp_parity ur5e    CPU: UR5e kinematics header + the scenario of examples/gomp_example.cpp on the oracle.
 //   ./gomp_parity batch   GPU: BatchGOMPSolver (lock-step on the batch API) vs sequential drivers.
 //   ./gomp_parity parity  GPU: runs GOMPSolver<3> twice on the same inputs -- once on the MI355X
 //                         QPSolver, once on an oracle-backed twin -- and compares trajectories.
@@ -14,6 +15,7 @@
 #include <stdexcept>
 
 #include "mi_osqp/gomp.hpp"
+#include "mi_osqp/ur5e_kinematics.hpp"
 extern "C" {
 #include "../../oracle/osqp_oracle.h"
 }
@@ -279,8 +281,63 @@ static int run_bench(int B, int W, int sample) {
   return fails ? 1 : 0;
 }
 
+// CPU: include/mi_osqp/ur5e_kinematics.hpp (published DH parameters: the zero pose of a UR5e puts the flange at
+// (-0.8172, -0.2329, 0.0628)), Jacobians against central differences, and the scenario of examples/gomp_example.cpp
+// on the oracle backend.
+static int run_ur5e(int W) {
+  double q0[6] = {0, 0, 0, 0, 0, 0};
+  auto [x0, y0, z0] = forward_kinematics(q0);
+  CHECK(std::fabs(x0 + 0.8172) < 1e-4 && std::fabs(y0 + 0.2329) < 1e-4 && std::fabs(z0 - 0.0628) < 1e-4);
+  auto [xb, yb, zb] = forward_kinematics_6_back(q0);
+  CHECK(std::fabs(std::sqrt((x0 - xb) * (x0 - xb) + (y0 - yb) * (y0 - yb) + (z0 - zb) * (z0 - zb)) - 0.0996) < 1e-12);
+  using FK = std::tuple<double, double, double> (*)(double *);
+  using JF = void (*)(double *, double *);
+  const FK fks[3] = {&forward_kinematics, &forward_kinematics_6_back, &forward_kinematics_elbow_joint};
+  const JF jfs[3] = {&joint_jacobian, &joint_jacobian_6_back, &jacobian_elbow_joint};
+  double q[6] = {0.3, -1.1, 0.9, -0.4, 1.2, 0.5};
+  for (int f = 0; f < 3; ++f) {
+    double J[18];
+    jfs[f](J, q);
+    for (int j = 0; j < 6; ++j) {
+      double qp[6], qm[6];
+      for (int k = 0; k < 6; ++k) { qp[k] = q[k]; qm[k] = q[k]; }
+      qp[j] += 1e-6; qm[j] -= 1e-6;
+      auto [a, b, c] = fks[f](qp);
+      auto [d, e, g] = fks[f](qm);
+      const double fd[3] = {(a - d) / 2e-6, (b - e) / 2e-6, (c - g) / 2e-6};
+      for (int ax = 0; ax < 3; ++ax) CHECK(std::fabs(fd[ax] - J[ax * 6 + j]) < 1e-8);
+    }
+  }
+  double sol[6];
+  CHECK(inverse_kinematics(sol, -0.4, 0.2, 0.4) == 1);
+  auto [sx, sy, sz] = forward_kinematics(sol);
+  CHECK(std::fabs(sx + 0.4) < 1e-8 && std::fabs(sy - 0.2) < 1e-8 && std::fabs(sz - 0.4) < 1e-8);
+  const double pi = 3.14159265358979323846;
+  for (int obst = 0; obst < 2; ++obst) {
+    std::vector<RobotBall> balls{RobotBall(&forward_kinematics_6_back, &joint_jacobian_6_back, 0.15, false),
+                                 RobotBall(&forward_kinematics, &joint_jacobian, 0.05, true)};
+    std::vector<HorizontalLine> lines;
+    if (obst) lines.push_back(HorizontalLine({0, 1}, {0.3, 0, 0.35}, false));
+    GOMPSolver<6, OracleQPSolver> g(W, 0.1, constraints::inRange<6>(constraints::of<6>(-2 * pi), constraints::of<6>(2 * pi)),
+                                    constraints::inRange<6>(constraints::of<6>(-pi), constraints::of<6>(pi)),
+                                    constraints::inRange<6>(constraints::of<6>(-pi * 800 / 180), constraints::of<6>(pi * 800 / 180)),
+                                    constraints::inRange<3>(Vec<3>{-INF, -0.4, -INF}, Vec<3>{INF, INF, INF}), lines, balls, &inverse_kinematics, false);
+    auto [code, x] = g.run({0, 0, 0, 0, 0, 0}, {pi, 0, 0, 0, 0, 0});
+    double ymin = 1e9;
+    const size_t nw = x.size() / 12;
+    for (size_t w = 0; w < nw; ++w) { double qq[6]; for (int k = 0; k < 6; ++k) qq[k] = x[6 * w + k]; ymin = std::fmin(ymin, std::get<1>(forward_kinematics(qq)) - 0.05); }
+    std::printf("ur5e obstacle=%d %s segments %d solves %d updates %d waypoints %zu min(y - r) of the gripper %.4f\n", obst,
+                ToString(code).c_str(), g.segments_run, g.qp_solves, g.qp_updates, nw, ymin);
+    CHECK(code == ExitCode::kOptimal);
+    CHECK(ymin >= -0.4 - 1e-2);
+    CHECK(std::fabs(x[0]) < 1e-3);
+  }
+  std::printf(fails ? "UR5E FAILED (%d)\n" : "UR5E OK\n", fails);
+  return fails ? 1 : 0;
+}
 int main(int argc, char **argv) {
   if (argc > 1 && !std::strcmp(argv[1], "kats")) return run_kats();
+  if (argc > 1 && !std::strcmp(argv[1], "ur5e")) return run_ur5e(argc > 2 ? std::atoi(argv[2]) : 22);
   if (argc > 1 && !std::strcmp(argv[1], "bench"))
     return run_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "batch")) return run_batch();

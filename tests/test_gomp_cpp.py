@@ -53,3 +53,34 @@ def test_batched_gomp_driver_matches_sequential_drivers(exe):
     of 6 sequential GOMPSolver runs (GPU QPSolver and oracle twin)."""
     r = subprocess.run([exe, "batch"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "BATCH OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_ur5e_kinematics_and_example_scenario_on_oracle(exe):
+    """own UR5e FK / Jacobians (published DH parameters; the reference's kinematics library is
+    absent) -- zero-pose position, Jacobians vs central differences, IK round trip -- and the scenario of
+    examples/gomp_example.cpp (two collision balls, y >= -0.4, optional bar obstacle) on the oracle backend."""
+    r = subprocess.run([exe, "ur5e", "40"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "UR5E OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_gomp_example_writes_reference_trajectory_files(tmp_path):
+    """SURVEY 8(f) rank 4: examples/gomp_example.cpp = [REF] examples/solver-example.cpp on the MI355X QPSolver;
+    output_trajectory_ctrl.data holds D joint values per line, output_trajectory_xyz.data one "(x, y, z)" per line."""
+    import osqp_solver_amd as M
+    M.lib()
+    libdir = os.path.join(ROOT, "osqp-solver_amd")
+    out = tmp_path / "gomp_example"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "gomp_example.cpp"),
+                    "-o", str(out), "-L" + libdir, "-lmi_osqp", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([str(out), "40", "1", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.splitlines()[0] == "kOptimal", r.stdout + r.stderr
+    ctrl = (tmp_path / "output_trajectory_ctrl.data").read_text().strip().splitlines()
+    xyz = (tmp_path / "output_trajectory_xyz.data").read_text().strip().splitlines()
+    assert len(ctrl) == len(xyz) >= 4
+    rows = [[float(v) for v in line.split(" ")] for line in ctrl]
+    assert all(len(rw) == 6 for rw in rows)
+    assert max(abs(v) for v in rows[0]) < 1e-3                     # starts at the zero pose
+    import re
+    assert all(re.fullmatch(r"\(-?[0-9.e+-]+, -?[0-9.e+-]+, -?[0-9.e+-]+\)", line) for line in xyz)
+    assert "re-linearisations" in r.stdout
