@@ -1206,7 +1206,13 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
       hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, __VA_ARGS__);                  \
       return hipGetLastError();                                                                    \
     };                                                                                             \
-    if (threads > 512) return hipErrorInvalidValue;                                                \
+    if (threads > 1024) return hipErrorInvalidValue;                                               \
+    if (threads > 512) {          /* 16 waves per tile: one workgroup per CU */                    \
+      if (a.xs_global) return hipErrorInvalidValue;                                                \
+      if (BT == 1) return go(&KERNEL<1, 1024, false>);                                             \
+      if (BT == 2) return go(&KERNEL<2, 1024, false>);                                             \
+      return hipErrorInvalidValue;                                                                 \
+    }                                                                                              \
     if (a.xs_global) {                                                                             \
       if (BT == 1) return go(&KERNEL<1, 512, true>);                                               \
       if (BT == 2) return go(&KERNEL<2, 512, true>);                                               \

@@ -402,7 +402,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
   {
     const char *eth = getenv("MI_OSQP_THREADS");
-    h->threads = eth ? std::max(64, std::min(512, atoi(eth) / 64 * 64)) : 512;
+    h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 512;
   }
   if (n + m >= 65535 || 2 * n + m >= 65535) {
     g_last_error = "KKT dimension too large for 16-bit gather / row indices (n + m and 2n + m must stay below 65535)";
@@ -826,15 +826,8 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
       (rc = cp(h->rho_vec, h->rho_vec0)) || (rc = cp(h->rho_inv, h->rho_inv0)) || (rc = cp(h->dscal, h->dscal0))) return rc;
   if ((rc = reset_solve_state(h, true))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  // host mirrors of rho follow the snapshot
-  if ((rc = sync_bounds_to_host(h))) return rc;
-  size_t dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
-  HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
-  for (int q = 0; q < h->B; q++) {
-    h->qp[q].rho = h->h_dscal[(size_t)(q / h->BT) * DS_COUNT * h->BT + DS_RHO * h->BT + q % h->BT];
-    set_rho_vec(h->an, h->st, h->qp[q]);
-  }
-  h->host_rho_stale = false;
+  // the host mirrors of rho follow the snapshot lazily (sync_rho_to_host, only the host update paths need them)
+  h->host_rho_stale = true;
   return MI_OSQP_OK;
 }
 

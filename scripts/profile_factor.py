@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import osqp_solver_amd as M
 from osqp_solver_amd import problems as PR
-pr = PR.random_box_qp(1024)
+pr = PR.random_box_qp(int(os.environ.get("B", "1024")))
 s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
 for skip, name in ((0, "full"), (1, "no rank-1"), (2, "no general"), (3, "no updates"), (3 + 4 + 8, "no U/D/T"), (31, "assembly+zero only"), (16, "no scatter")):
     os.environ["MI_OSQP_FACTOR_SKIP"] = str(skip)
