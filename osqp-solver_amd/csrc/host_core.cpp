@@ -1149,16 +1149,14 @@ int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric 
   // inverted diagonal blocks, exactly as factor_kernel stores them: inv(L_JJ)[i,k] (i > k) at (row k, col i) of B(J,J)
   for (uint32_t t = 0; t < bf.dtask.size(); t++) {
     uint32_t off, r0, c0, h, w; B(bf.dtask[t], off, r0, c0, h, w);
-    double V[kChunk];
-    for (uint32_t k = 0; k + 1 < w; k++) {
-      V[k] = 1.0;
-      for (uint32_t i = k + 1; i < w; i++) {
-        double v = 0.0;
-        for (uint32_t p2 = k; p2 < i; p2++) v = std::fma(-S[off + p2 * h + i], V[p2], v);
-        V[i] = v;
+    // same recurrence and order as fct_diag: X[i,j] = -L[i,j] - sum_{p=j+1}^{i-1} X[i,p] L[p,j], j descending
+    // (X[i,p] lives at (row p, col i) of the block, L[p,j] at (row p, col j))
+    for (int j = (int)w - 2; j >= 0; j--)
+      for (uint32_t i = (uint32_t)j + 1; i < w; i++) {
+        double x = -S[off + (uint32_t)j * h + i];
+        for (uint32_t p2 = (uint32_t)j + 1; p2 < i; p2++) x = std::fma(-S[off + i * h + p2], S[off + (uint32_t)j * h + p2], x);
+        S[off + i * h + (uint32_t)j] = x;
       }
-      for (uint32_t i = k + 1; i < w; i++) S[off + i * h + k] = V[i];
-    }
   }
   out.Lx.resize(an.nnzLx()); out.Dl = D; out.Dlinv.resize(N);
   for (int p = 0; p < an.nnzLx(); p++) out.Lx[p] = S[bf.lpos[p]];

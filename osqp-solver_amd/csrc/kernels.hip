@@ -945,27 +945,24 @@ __device__ __forceinline__ void fct_diag(const FactorArgs &a, double *Lb, double
   if (ok) {
     for (uint32_t k = 0; k < (uint32_t)i; k++) Lb[((size_t)off + k * w + i) * BT + b] = Ss[MI_BS(k, b, i)];
   }
-  // inv(L_JJ) for the solve schedules (phase B = product with the inverted diagonal block): lane (k, b) owns
-  // column k of the inverse, V[i] = -sum_{p=k}^{i-1} L[i,p] V[p]; all lanes of a QP read the same L[i,p]
-  // (LDS broadcast).  Stored in the unused upper triangle of the block: inv[i,k] at (row k, col i).
+  // inv(L_JJ) for the solve schedules (phase B = product with the inverted diagonal block), IN PLACE in the
+  // staged copy (L itself is already back in global memory): for j = w-2 .. 0, column j of X = inv(L) follows from
+  // X L = I:  X[i,j] = -L[i,j] - sum_{p=j+1}^{i-1} X[i,p] L[p,j]; lane (i, b) owns row i.  Register-light on purpose
+  // (a column-per-lane variant with 16 live values spilled).  Stored in the unused upper triangle of the block:
+  // inv[i,k] at (row k, col i).
   if (w >= 2) {
-    const uint32_t k = (uint32_t)i;
-    double V[MI_CHUNK];
-#pragma unroll
-    for (int r = 0; r < MI_CHUNK; r++) V[r] = (uint32_t)r == k ? 1.0 : 0.0;
-#pragma unroll
-    for (int r = 1; r < MI_CHUNK; r++) {
-      if ((uint32_t)r < w) {               // uniform
-        double v = 0.0;
-#pragma unroll
-        for (int p2 = 0; p2 < r; p2++) v = fma(-Ss[MI_BS(p2, b, r)], V[p2], v);   // V[p2] = 0 for p2 < k
-        if ((uint32_t)r > k) V[r] = v;
+    for (int j = (int)w - 2; j >= 0; j--) {
+      double x = 0.0;
+      if (ok && i > j) {
+        x = -Ss[MI_BS(j, b, i)];
+        for (int p2 = j + 1; p2 < i; p2++) x = fma(-Ss[MI_BS(p2, b, i)], Ss[MI_BS(j, b, p2)], x);
       }
+      wave_sync();
+      if (ok && i > j) Ss[MI_BS(j, b, i)] = x;
+      wave_sync();
     }
     if (ok) {
-#pragma unroll
-      for (int r = 1; r < MI_CHUNK; r++)
-        if ((uint32_t)r < w && (uint32_t)r > k) Lb[((size_t)off + r * w + k) * BT + b] = V[r];
+      for (uint32_t k = 0; k < (uint32_t)i; k++) Lb[((size_t)off + (size_t)i * w + k) * BT + b] = Ss[MI_BS(k, b, i)];
     }
   }
 }
@@ -1027,21 +1024,39 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
       rho_vec[e] = rv; rho_inv[e] = 1.0 / rv;
     }
   }
-  for (size_t e = tid; e < (size_t)a.storage * BT; e += nthr) Lb[e] = 0.0;
+  {    // zero the block storage (16-byte stores; storage * BT is even or the tail is handled singly)
+    const size_t tot = (size_t)a.storage * BT, pairs = tot / 2;
+    double2 *L2p = reinterpret_cast<double2 *>(Lb);
+    for (size_t e = tid; e < pairs; e += nthr) L2p[e] = make_double2(0.0, 0.0);
+    if (tid == 0 && (tot & 1)) Lb[tot - 1] = 0.0;
+  }
   __syncthreads();
   // ---- assemble the permuted KKT into block storage
   {
     const double *pav = a.pa_val + (size_t)tile * a.pa_len * BT;
-    for (int e = tid; e < a.nnzK * BT; e += nthr) {
-      const int k = e / BT;
-      const uint32_t src = a.asm_src[k], kind = src >> 29, idx = src & 0x1FFFFFFFu;
-      double v;
-      if (kind == 0) v = pav[(size_t)idx * BT + b];
-      else if (kind == 1) v = pav[(size_t)idx * BT + b] + a.sigma;
-      else if (kind == 2) v = a.sigma;
-      else if (kind == 3) v = pav[((size_t)a.nnzP + idx) * BT + b];
-      else v = -rho_inv[(size_t)idx * BT + b];
-      Lb[(size_t)a.asm_dst[k] * BT + b] = v;
+    // 4 entries per thread and trip: the table reads, then the value reads, then the stores (independent loads in flight)
+    constexpr int UA = 2;
+    const int tot = a.nnzK * BT;
+    for (int e0 = tid; e0 < tot; e0 += nthr * UA) {
+      uint32_t src[UA], dst[UA];
+      double v[UA];
+#pragma unroll
+      for (int u = 0; u < UA; u++) {
+        const int e = e0 + u * nthr;
+        const int k = e < tot ? e / BT : 0;
+        src[u] = a.asm_src[k]; dst[u] = a.asm_dst[k];
+      }
+#pragma unroll
+      for (int u = 0; u < UA; u++) {
+        const uint32_t kind = src[u] >> 29, idx = src[u] & 0x1FFFFFFFu;
+        if (kind == 0) v[u] = pav[(size_t)idx * BT + b];
+        else if (kind == 1) v[u] = pav[(size_t)idx * BT + b] + a.sigma;
+        else if (kind == 2) v[u] = a.sigma;
+        else if (kind == 3) v[u] = pav[((size_t)a.nnzP + idx) * BT + b];
+        else v[u] = -rho_inv[(size_t)idx * BT + b];
+      }
+#pragma unroll
+      for (int u = 0; u < UA; u++) if (e0 + u * nthr < tot) Lb[(size_t)dst[u] * BT + b] = v[u];
     }
   }
   __syncthreads();
@@ -1073,14 +1088,22 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag && !(a.debug_skip & 16)) {
     double *fv = a.fwd_val + (size_t)tile * a.fwd.n_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.n_steps * 64 * BT;
-    for (size_t e = tid; e < (size_t)a.fwd.n_slots * BT; e += nthr) {
-      const uint32_t sl = (uint32_t)(e / BT);
-      fv[phys_index(sl, b, BT)] = slot_value(a.fwd_srcblk[sl], Lb, BT, b);
-    }
-    for (size_t e = tid; e < (size_t)a.bwd.n_slots * BT; e += nthr) {
-      const uint32_t sl = (uint32_t)(e / BT);
-      bv[phys_index(sl, b, BT)] = slot_value(a.bwd_srcblk[sl], Lb, BT, b);
-    }
+    auto scatter = [&](double *dst, const int32_t *map, uint32_t n_slots) {
+      constexpr int US = 4;                 // table reads, then value reads, then stores: 4 independent chains per thread
+      const uint32_t tot = n_slots * (uint32_t)BT;
+      for (uint32_t e0 = tid; e0 < tot; e0 += (uint32_t)nthr * US) {
+        int32_t mp[US];
+        double v[US];
+#pragma unroll
+        for (int u = 0; u < US; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); mp[u] = e < tot ? map[e / BT] : MI_SRC_ZERO; }
+#pragma unroll
+        for (int u = 0; u < US; u++) v[u] = slot_value(mp[u], Lb, BT, b);
+#pragma unroll
+        for (int u = 0; u < US; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); if (e < tot) dst[e] = v[u]; }   // phys_index(slot, b) = slot * BT + b = e
+      }
+    };
+    scatter(fv, a.fwd_srcblk, a.fwd.n_slots);
+    scatter(bv, a.bwd_srcblk, a.bwd.n_slots);
     for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
   }
   __syncthreads();
