@@ -453,36 +453,42 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   const int done = p.iscal[IS_DONE * BT + b];
   if (__syncthreads_and(done)) return;
   const double alpha = a.alpha, sigma = a.sigma;
+  // ---- E6 of the first iteration: rhs into the permuted solve vector
+  for (int e = tid; e < N * BT; e += nthr) {
+    const int i = e / BT;
+    double v;
+    if (i < n) v = sigma * p.x[e] - p.q[e];
+    else { const int ez = e - n * BT; v = p.z[ez] - p.rho_inv[ez] * p.y[ez]; }
+    xs[(size_t)a.pinv[i] * BT + b] = v;
+  }
+  __syncthreads();
   for (int iter = a.iter_begin + 1; iter <= a.iter_end; iter++) {
     const bool do_info = a.info_at_end && iter == a.iter_end;     // delta_x / delta_y are only needed by check_kernel
-    // ---- E6: rhs into the permuted LDS vector
-    for (int e = tid; e < N * BT; e += nthr) {
-      const int i = e / BT;
-      double v;
-      if (i < n) v = sigma * p.x[e] - p.q[e];
-      else { const int ez = e - n * BT; v = p.z[ez] - p.rho_inv[ez] * p.y[ez]; }
-      xs[(size_t)a.pinv[i] * BT + b] = v;
-    }
-    __syncthreads();
     // ---- E7
     kkt_solve_lds<BT, MI_PFV, GX>(a, p, xs, tid, nthr, wave, nw, lane);
-    // ---- E8-E10 (run_tri ends with a barrier)
+    // ---- E8-E10 fused with E6 of the next iteration (run_tri ends with a barrier): every thread replaces the
+    // solution entry it has just consumed by the next right-hand side entry - same position, no other reader
     for (int e = tid; e < n * BT; e += nthr) {
       const int i = e / BT;
-      const double xt = xs[(size_t)a.pinv[i] * BT + b], xp = p.x[e];
-      const double xn = alpha * xt + (1.0 - alpha) * xp;
-      if (!done) { p.x[e] = xn; if (do_info) p.dx[e] = xn - xp; }
+      const size_t pos = (size_t)a.pinv[i] * BT + b;
+      const double xt = xs[pos], xp = p.x[e];
+      double xn = alpha * xt + (1.0 - alpha) * xp;
+      if (!done) { p.x[e] = xn; if (do_info) p.dx[e] = xn - xp; } else xn = xp;
+      xs[pos] = sigma * xn - p.q[e];
     }
     for (int e = tid; e < m * BT; e += nthr) {
       const int j = e / BT;
-      const double nu = xs[(size_t)a.pinv[n + j] * BT + b];
+      const size_t pos = (size_t)a.pinv[n + j] * BT + b;
+      const double nu = xs[pos];
       const double zp = p.z[e], yv = p.y[e], ri = p.rho_inv[e], rv = p.rho_vec[e];
       double zt = zp - ri * yv;
       zt += ri * nu;
       const double zr = alpha * zt + (1.0 - alpha) * zp;
-      const double zn = fmin(fmax(zr + ri * yv, p.l[e]), p.u[e]);
+      double zn = fmin(fmax(zr + ri * yv, p.l[e]), p.u[e]);
       const double dyv = rv * (zr - zn);
-      if (!done) { p.z[e] = zn; p.y[e] = yv + dyv; if (do_info) p.dy[e] = dyv; }
+      double yn = yv + dyv;
+      if (!done) { p.z[e] = zn; p.y[e] = yn; if (do_info) p.dy[e] = dyv; } else { zn = zp; yn = yv; }
+      xs[pos] = zn - ri * yn;
     }
     __syncthreads();
   }
