@@ -819,6 +819,13 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   build_tri_schedules(an, nwaves, bt);
   build_chk_schedule(an, nwaves, bt);
   build_block_factor(an);
+  // A wave that passes fewer barriers than the others would hang its workgroup (and the GPU): re-count.
+  for (const Schedule *sc : {&an.fwd, &an.bwd, &an.chk})
+    for (int w = 0; w < sc->nw; w++) {
+      uint64_t bars = sc->tail_bar[w];
+      for (uint32_t q = sc->wave_range[2 * w]; q < sc->wave_range[2 * w + 1]; q++) bars += MI_D_NBAR(sc->step[q]);
+      if (bars != (sc->barriers ? (uint64_t)sc->n_phases : 0u)) return MI_OSQP_ERR_INVALID_DATA;
+    }
   return MI_OSQP_OK;
 }
 

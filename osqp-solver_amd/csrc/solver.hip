@@ -134,7 +134,7 @@ struct mi_osqp_batch {
   DevBuf<uint32_t> bf_blk, bf_lvl, bf_utask, bf_tri, bf_dtask, bf_ttask, bf_asm_dst, bf_asm_src;
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
-  bool host_rho_stale = false, host_refactor = false;
+  bool host_rho_stale = false;
   int *h_npos = nullptr;
   DevBuf<double> stage; DevBuf<int> ids;
   int *h_iscal = nullptr;     // pinned
@@ -466,7 +466,6 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
         (rc = h->Lblk.alloc((size_t)bf.storage * T)) || (rc = h->Dl.alloc((size_t)an.N * T)) || (rc = h->Dl.zero(h->stream)) ||
         (rc = h->dinv_scratch.alloc((size_t)an.N * T)) || (rc = h->npos.alloc(T))) return rc;
     HIPCHK(hipHostMalloc((void **)&h->h_npos, T * sizeof(int)));
-    h->host_refactor = getenv("MI_OSQP_HOST_REFACTOR") != nullptr;
   }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
