@@ -422,9 +422,13 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
     }
   }
-  if (getenv("MI_OSQP_DEBUG_ORDER"))
+  if (getenv("MI_OSQP_DEBUG_ORDER")) {
     fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu steps %u outA %zu\n", levels.size(), phases.size(), sch.n_steps,
             sch.outA.size());
+    uint32_t cnt[7][2] = {};
+    for (uint32_t st = 0; st < sch.n_steps; st++) cnt[MI_D_LT(sch.step[st])][(sch.step[st] & MI_D_FLUSH) ? 1 : 0]++;
+    for (int lt = 0; lt < 7; lt++) fprintf(stderr, "[mi_osqp]   lane groups of %2d: %u flush steps, %u other steps\n", 1 << lt, cnt[lt][1], cnt[lt][0]);
+  }
 }
 }  // namespace
 

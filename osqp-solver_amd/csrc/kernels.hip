@@ -107,8 +107,6 @@ __device__ __forceinline__ mi_cptr as_const(const uint32_t *p) { return (mi_cptr
 // (a __syncthreads() would drain vmcnt to 0).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// physical position (doubles inside one tile) of QP b's value of a slot
-__device__ __forceinline__ size_t phys_index(uint32_t slot, int b, int BT) { return (size_t)slot * BT + b; }
 // value of a slot from its source code (host_core.hpp Schedule::src composed with a position map)
 __device__ __forceinline__ double slot_value(int32_t mp, const double *src, size_t stride, int b) {
   return mp >= 0 ? src[(size_t)mp * stride + b] : (mp == MI_SRC_ONE ? 1.0 : 0.0);
@@ -229,15 +227,24 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 #endif
 template <int BT, int PF>
 struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t desc; };
-struct ValSrc { mi_rsrc vals, idx, step; };     // one tile's value stream + the shared index words / descriptors
+// The value streams of a tile: ONE stream per QP ([slot][step][64] doubles, 8 B per lane and load) plus the shared
+// index words / descriptors.  A QP that has finished (or a padding slot) gets a null descriptor: its loads
+// return 0 without touching memory, so a half-done tile streams half the bytes.
+template <int BT>
+struct ValSrc { mi_rsrc vals[BT], idx, step; };
 
 template <int BT>
-__device__ __forceinline__ void load_step(const ValSrc &vs, uint32_t stepno, int lane, double (&v)[BT], uint32_t &gi) {
+__device__ __forceinline__ void load_step(const ValSrc<BT> &vs, uint32_t stepno, int lane, double (&v)[BT], uint32_t &gi) {
   gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, (uint32_t)lane * 4u, stepno * 256u, 0);
-  buf_load_bt<BT>(vs.vals, (uint32_t)lane * (uint32_t)(BT * 8), stepno * (uint32_t)(64 * BT * 8), v);
+#pragma unroll
+  for (int b = 0; b < BT; b++) {
+    const mi_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(vs.vals[b], (uint32_t)lane * 8u, stepno * 512u, 0);
+    v[b] = __hiloint2double((int)t.y, (int)t.x);
+  }
 }
 // lane st gets the descriptor of step pos + st, a no-op at and past `end`
-__device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t pos, uint32_t end, int lane) {
+template <int BT>
+__device__ __forceinline__ uint32_t load_desc(const ValSrc<BT> &vs, uint32_t pos, uint32_t end, int lane) {
   const uint32_t d = __builtin_amdgcn_raw_buffer_load_b32(vs.step, (uint32_t)lane * 4u, pos * 4u, 0);
   return pos + (uint32_t)lane < end ? d : MI_D_NOOP;
 }
@@ -248,7 +255,7 @@ __device__ __forceinline__ uint32_t load_desc(const ValSrc &vs, uint32_t pos, ui
 //   TR   = debug instantiations: 1: lane 0 logs the shader clock before / after every barrier into
 //          tr[(ordinal of the barrier * nw + wave) * 2 + {0, 1}]; 2: also the time spent waiting for ring slots
 template <int BT, int PF, bool SUB, bool BAR, bool GX, int TR = 0>
-__device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs,
+__device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs,
                                            double *out, int lane, uint32_t *tr = nullptr, int wave = 0, int nw = 0,
                                            uint32_t *tw = nullptr) {
   double *base = SUB ? xs : out;
@@ -328,7 +335,7 @@ __device__ __forceinline__ void run_stream(const ValSrc &vs, uint32_t begin, uin
 
 // One triangular solve: this wave's whole stream of the schedule.
 template <int BT, int PF, bool GX, int TR = 0>
-__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, double *xs, int wave, int lane,
+__device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc<BT> &vals, double *xs, int wave, int lane,
                                         uint32_t *tr = nullptr, uint32_t *tw = nullptr) {
   mi_cptr lp = as_const(s.lvl_pos);
   const uint32_t begin = lp[wave], end = lp[(size_t)s.n_levels * s.nw + wave], tail = as_const(s.tail_bar)[wave];
@@ -337,7 +344,7 @@ __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc &vals, d
 
 // SpMV with the same streams: levels [l0, l1) of the check schedule (independent rows, no barriers)
 template <int BT, int PF>
-__device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc &vals, double *xs, double *out, int wave,
+__device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc<BT> &vals, double *xs, double *out, int wave,
                                          int lane, int l0, int l1) {
   mi_cptr lp = as_const(s.lvl_pos);
   const uint32_t begin = lp[(size_t)l0 * s.nw + wave], end = lp[(size_t)l1 * s.nw + wave];
@@ -382,21 +389,18 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double *red, int ti
 
 template <int BT>
 struct TilePtrs {
-  const double *fwd_val, *bwd_val, *chk_val, *dinv;
+  const double *dinv;
   double *x, *z, *y;
   const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
   double *dx, *dy, *out1, *out2, *dscal;
   int *iscal;
-  ValSrc vfwd, vbwd, vchk;
+  ValSrc<BT> vfwd, vbwd, vchk;
 };
 
 template <int BT>
-__device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile) {
+__device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile, bool skip_done = false) {
   TilePtrs<BT> p;
   const size_t n = a.n, m = a.m, N = a.N, t = tile;
-  p.fwd_val = a.fwd_val + t * a.fwd.n_steps * 64 * BT;
-  p.bwd_val = a.bwd_val + t * a.bwd.n_steps * 64 * BT;
-  p.chk_val = a.chk_val + t * a.chk.n_steps * 64 * BT;
   p.dinv = a.dinv + t * N * BT;
   p.x = a.x + t * n * BT; p.z = a.z + t * m * BT; p.y = a.y + t * m * BT;
   p.q = a.q + t * n * BT; p.l = a.l + t * m * BT; p.u = a.u + t * m * BT;
@@ -407,12 +411,17 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile)
   p.out1 = a.out1 + t * (2 * n + m) * BT; p.out2 = a.out2 + t * (2 * n + m) * BT;
   p.dscal = a.dscal + t * DS_COUNT * BT;
   p.iscal = a.iscal + t * IS_COUNT * BT;
-  p.vfwd.vals = make_rsrc(p.fwd_val, a.fwd.n_steps * (uint32_t)(64 * BT * 8)); p.vfwd.idx = make_rsrc(a.fwd.idxw, a.fwd.n_steps * 256u);
-  p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
-  p.vbwd.vals = make_rsrc(p.bwd_val, a.bwd.n_steps * (uint32_t)(64 * BT * 8)); p.vbwd.idx = make_rsrc(a.bwd.idxw, a.bwd.n_steps * 256u);
-  p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
-  p.vchk.vals = make_rsrc(p.chk_val, a.chk.n_steps * (uint32_t)(64 * BT * 8)); p.vchk.idx = make_rsrc(a.chk.idxw, a.chk.n_steps * 256u);
-  p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
+  p.vfwd.idx = make_rsrc(a.fwd.idxw, a.fwd.n_steps * 256u); p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
+  p.vbwd.idx = make_rsrc(a.bwd.idxw, a.bwd.n_steps * 256u); p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
+  p.vchk.idx = make_rsrc(a.chk.idxw, a.chk.n_steps * 256u); p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
+#pragma unroll
+  for (int bb = 0; bb < BT; bb++) {
+    const size_t slot = t * BT + bb;
+    const bool off = skip_done && p.iscal[IS_DONE * BT + bb] != 0;     // wave-uniform: inside a solve, finished QPs (and padding slots) stream nothing
+    p.vfwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.fwd_val + slot * a.fwd.n_steps * 64, a.fwd.n_steps * 512u);
+    p.vbwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.bwd_val + slot * a.bwd.n_steps * 64, a.bwd.n_steps * 512u);
+    p.vchk.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.chk_val + slot * a.chk.n_steps * 64, a.chk.n_steps * 512u);
+  }
   return p;
 }
 
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   const int n = a.n, m = a.m, N = a.N;
   double *unused_scratch;
   double *xs = solve_vector<BT, GX>(a, smem, tile, unused_scratch);
-  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile, true);
   const int done = p.iscal[IS_DONE * BT + b];
   if (__syncthreads_and(done)) return;
   const double alpha = a.alpha, sigma = a.sigma;
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   const int n = a.n, m = a.m, N = a.N;
   double *red;
   double *xs = solve_vector<BT, GX>(a, smem, tile, red);
-  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  const TilePtrs<BT> p = tile_ptrs<BT>(a, tile, true);
   // global QP id of this thread's class: during a solve the QPs still iterating are
   // compacted into the leading tiles (solver.hip), so the id comes from a table
   const int qp = a.qp_of_slot[tile * BT + b];
@@ -1093,7 +1102,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag && !(a.debug_skip & 16)) {
-    double *fv = a.fwd_val + (size_t)tile * a.fwd.n_steps * 64 * BT, *bv = a.bwd_val + (size_t)tile * a.bwd.n_steps * 64 * BT;
+    double *fv = a.fwd_val + ((size_t)tile * BT + b) * a.fwd.n_steps * 64, *bv = a.bwd_val + ((size_t)tile * BT + b) * a.bwd.n_steps * 64;   // this thread's QP stream
     auto scatter = [&](double *dst, const int32_t *map, uint32_t n_slots) {
       constexpr int US = 4;                 // table reads, then value reads, then stores: 4 independent chains per thread
       const uint32_t tot = n_slots * (uint32_t)BT;
@@ -1105,7 +1114,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
 #pragma unroll
         for (int u = 0; u < US; u++) v[u] = slot_value(mp[u], Lb, BT, b);
 #pragma unroll
-        for (int u = 0; u < US; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); if (e < tot) dst[e] = v[u]; }   // phys_index(slot, b) = slot * BT + b = e
+        for (int u = 0; u < US; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); if (e < tot) dst[e / BT] = v[u]; }   // dst = the stream of QP b = e % BT
       }
     };
     scatter(fv, a.fwd_srcblk, a.fwd.n_slots);
@@ -1154,8 +1163,8 @@ __global__ void scatter_kernel(const double *__restrict__ src, double *dst, cons
   const int j = (int)(g / slots);
   const uint32_t s = (uint32_t)(g % slots);
   const int q = ids ? ids[j] : j;
-  const size_t tile_doubles = (size_t)sd.n_steps * 64 * BT;
-  dst[(size_t)(q / BT) * tile_doubles + phys_index(s, q % BT, BT)] = slot_value(map[s], src + (size_t)j * srclen, 1, 0);
+  dst[(size_t)q * slots + s] = slot_value(map[s], src + (size_t)j * srclen, 1, 0);      // one stream per QP: [q][slot]
+  (void)BT;
 }
 // Compaction support: exchange the complete per-QP contents of slot pairs (slot =
 // tile*BT + b).  Every array is [tile][len][BT].
@@ -1183,9 +1192,10 @@ __global__ void swap_sched_kernel(double *base, const int2 *pairs, int npairs, S
   if (g >= (size_t)npairs * per) return;
   const int2 pr = pairs[g / per];
   const size_t u = g % per;
-  double *pa = base + ((size_t)(pr.x / BT) * per + u) * BT + pr.x % BT;
-  double *pb = base + ((size_t)(pr.y / BT) * per + u) * BT + pr.y % BT;
+  double *pa = base + (size_t)pr.x * per + u;        // one stream per slot
+  double *pb = base + (size_t)pr.y * per + u;
   const double t = *pa; *pa = *pb; *pb = t;
+  (void)BT;
 }
 
 // dst[q][i] = src[tile][i][b]
