@@ -49,7 +49,7 @@ struct FactorArgs {
   int debug_skip;     // timing experiments only (MI_OSQP_FACTOR_SKIP): 1 rank-1 updates, 2 general updates, 4 diag, 8 trsm, 16 scatter
   uint32_t storage;
   SchedDev fwd, bwd;
-  const uint32_t *blk, *lvl, *utask, *tri, *dtask, *ttask, *asm_dst, *asm_src;
+  const uint32_t *blk, *lvl, *utask, *tri4, *dtask, *ttask, *asm_dst, *asm_src;
   const int32_t *fwd_srcblk, *bwd_srcblk;
   const double *pa_val, *l, *u, *dscal;
   double *rho_vec, *rho_inv, *Lblk, *Dl, *dinv_scratch, *fwd_val, *bwd_val, *dinv;

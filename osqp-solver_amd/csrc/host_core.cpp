@@ -655,6 +655,13 @@ static void build_block_factor(Analysis &an) {
       }
     bf.lvl.insert(bf.lvl.end(), {u0, (uint32_t)(bf.utask.size() / 4), d0, (uint32_t)bf.dtask.size(), t0, (uint32_t)(bf.ttask.size() / 2)});
   }
+  bf.tri4.resize(2 * bf.tri.size());
+  for (size_t q = 0; q < bf.tri.size() / 2; q++) {
+    const uint32_t ia = bf.tri[2 * q], ib = bf.tri[2 * q + 1];
+    const uint32_t ahw = bf.blk[4 * ia + 3], bh = bf.blk[4 * ib + 3] >> 8;
+    bf.tri4[4 * q] = bf.blk[4 * ia]; bf.tri4[4 * q + 1] = bf.blk[4 * ib]; bf.tri4[4 * q + 2] = bf.blk[4 * ia + 2];
+    bf.tri4[4 * q + 3] = ((ahw >> 8) << 16) | ((ahw & 255u) << 8) | bh;
+  }
   // assembly map: natural KKT entry -> (storage position, value source)
   const int n = an.n, m = an.m, nnzK = an.nnzK();
   bf.asm_dst.assign(nnzK, 0); bf.asm_src.assign(nnzK, 0);

@@ -83,6 +83,8 @@ struct BlockFactor {
   std::vector<uint32_t> lvl;          // 6/level: u_begin,u_end, d_begin,d_end, t_begin,t_end
   std::vector<uint32_t> utask;        // 4/task : block id, tri_begin, tri_mid, tri_end  ([begin,mid): rank-1 sources, i.e. 1-column chunks)
   std::vector<uint32_t> tri;          // 2/triple: block (I,K), block (J,K)
+  std::vector<uint32_t> tri4;         // 4/triple, resolved for the device (one 16-byte load instead of a chain of three):
+                                      // offset of (I,K), offset of (J,K), first column of K, (h_I << 16) | (w_K << 8) | h_J
   std::vector<uint32_t> dtask;        // diagonal block ids
   std::vector<uint32_t> ttask;        // 2/task : block id, diagonal block id
   std::vector<uint32_t> asm_dst;      // per natural KKT entry: position in block storage

@@ -843,7 +843,7 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
   constexpr int H = 64 / (MI_CHUNK * BT);
   mi_cptr ut = as_const(a.utask) + 4 * (size_t)t;
   mi_cptr blk = as_const(a.blk);
-  mi_cptr tri = as_const(a.tri);
+  mi_cptr tri4 = as_const(a.tri4);        // resolved triples: {offset A, offset B, first column of K, (h_A << 16) | (w_K << 8) | h_B}
   const uint32_t tid_blk = ut[0], q0 = ut[1], qm = ut[2], q1 = ut[3];
   const uint32_t off = blk[4 * tid_blk], hw = blk[4 * tid_blk + 3], h = hw >> 8, w = hw & 255u;
   const int hh = lane / (MI_CHUNK * BT), i = (lane / BT) % MI_CHUNK, b = lane % BT;
@@ -861,9 +861,8 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
       const int g = gg * H + hh;
       av[gg] = 0.0; bv[gg] = 0.0;
       if (q + g < qm) {
-        const uint32_t ia = tri[2 * (q + g)], ib = tri[2 * (q + g) + 1];
-        const uint32_t ao = blk[4 * ia], ah = blk[4 * ia + 3] >> 8, kc0 = blk[4 * ia + 2];
-        const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
+        const uint4 t4 = reinterpret_cast<const uint4 *>(a.tri4)[q + g];      // one 16-byte load per member, no dependent chain
+        const uint32_t ao = t4.x, bo = t4.y, kc0 = t4.z, ah = t4.w >> 16, bh = t4.w & 255u;
         if ((uint32_t)i < ah) av[gg] = Lb[((size_t)ao + i) * BT + b];
         if ((uint32_t)i < bh) bv[gg] = Lb[((size_t)bo + i) * BT + b] * Dl[(size_t)kc0 * BT + b];
       }
@@ -885,9 +884,8 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
   }
   // ---- general sources (width > 1): group hh handles the columns k = hh mod H
   for (uint32_t q = qm; q < ((a.debug_skip & 2) ? qm : q1); q++) {
-    const uint32_t ia = tri[2 * q], ib = tri[2 * q + 1];
-    const uint32_t ao = blk[4 * ia], ahw = blk[4 * ia + 3], ah = ahw >> 8, aw = ahw & 255u, kc0 = blk[4 * ia + 2];
-    const uint32_t bo = blk[4 * ib], bh = blk[4 * ib + 3] >> 8;
+    const uint32_t ao = tri4[4 * q], bo = tri4[4 * q + 1], kc0 = tri4[4 * q + 2], pk = tri4[4 * q + 3];
+    const uint32_t ah = pk >> 16, aw = (pk >> 8) & 255u, bh = pk & 255u;
     // all operand loads of the triple are issued up front (fixed unroll, predicated):
     // lane (hh, i, b) needs A[i, k] and provides (B .* d)[i, k] for its columns k
     const bool brow = (uint32_t)i < bh, arow = (uint32_t)i < ah;

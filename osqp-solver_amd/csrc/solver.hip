@@ -209,7 +209,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.n = an.n; a.m = an.m; a.N = an.N; a.B = h->B; a.nnzP = an.Pp[an.n]; a.nnzK = an.nnzK();
   a.pa_len = an.Pp[an.n] + an.Ap[an.n]; a.n_levels = an.bf.n_levels; a.force_all = force_all;
   a.storage = an.bf.storage; a.fwd = h->fwd.view(an.fwd); a.bwd = h->bwd.view(an.bwd);
-  a.blk = h->bf_blk.p; a.lvl = h->bf_lvl.p; a.utask = h->bf_utask.p; a.tri = h->bf_tri.p; a.dtask = h->bf_dtask.p;
+  a.blk = h->bf_blk.p; a.lvl = h->bf_lvl.p; a.utask = h->bf_utask.p; a.tri4 = h->bf_tri.p; a.dtask = h->bf_dtask.p;
   a.ttask = h->bf_ttask.p; a.asm_dst = h->bf_asm_dst.p; a.asm_src = h->bf_asm_src.p;
   a.fwd_srcblk = h->fwd_srcblk.p; a.bwd_srcblk = h->bwd_srcblk.p;
   a.pa_val = h->pa_val.p; a.l = h->l.p; a.u = h->u.p; a.dscal = h->dscal.p;
@@ -459,7 +459,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   {
     const BlockFactor &bf = an.bf;
     if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_utask.upload(bf.utask)) ||
-        (rc = h->bf_tri.upload(bf.tri)) || (rc = h->bf_dtask.upload(bf.dtask)) || (rc = h->bf_ttask.upload(bf.ttask)) ||
+        (rc = h->bf_tri.upload(bf.tri4)) || (rc = h->bf_dtask.upload(bf.dtask)) || (rc = h->bf_ttask.upload(bf.ttask)) ||
         (rc = h->bf_asm_dst.upload(bf.asm_dst)) || (rc = h->bf_asm_src.upload(bf.asm_src)) ||
         (rc = h->fwd_srcblk.upload(an.fwd_srcblk)) || (rc = h->bwd_srcblk.upload(an.bwd_srcblk))) return rc;
     if ((rc = h->pa_val.alloc((size_t)(an.Pp[n] + an.Ap[n]) * T)) || (rc = h->pa_val.zero(h->stream)) ||
