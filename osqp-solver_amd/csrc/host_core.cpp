@@ -293,7 +293,8 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     for (const RowWork &rw : rows) {
       int len = std::max<int>(1, (int)rw.ent.size());
       if (len > 64) { longs.push_back(&rw); continue; }
-      if (kind == 1) { byTS[ilog2(kChunk) * 4].push_back(&rw); continue; }   // phase B: <=16 entries, one step, 4 rows per step
+      if (kind == 1) { byTS[(len <= kChunk / 2 ? ilog2(kChunk) - 1 : ilog2(kChunk)) * 4].push_back(&rw); continue; }   // phase B: one step per
+                                                                               // row; rows of <= 8 entries share an 8-lane group (3 instead of 4 steps per 16-row chunk)
       int bestlt = 6, bestS = 1, bestcost = 1 << 30;
       for (int lt = 0; lt <= 6; lt++) {
         int T = 1 << lt, S = (len + T - 1) / T;
