@@ -386,3 +386,43 @@ def test_reference_example_horizon_802_waypoints():
     code, x = s.solve(); sto, xo = o.solve()
     assert code == ST2EXIT[sto] and s.info().iter == o.info().iter
     assert np.max(np.abs(x - xo)) <= TOL_X
+
+
+def test_sixteen_waves_per_tile_variant(monkeypatch):
+    """MI_OSQP_THREADS=1024: the 16-wave instantiations of the solve kernels (one workgroup per CU) walk
+    schedules built for 16 waves; results equal the default 8-wave run up to round-off, iteration counts exactly."""
+    pr = PR.random_box_qp(10, n=96, mg=64, nnz_per_row=6)
+    def run():
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+        info = s.solve()
+        return s.stats()["threads_per_block"], [i.iter for i in info], s.primal().copy()
+    t8, it8, x8 = run()
+    monkeypatch.setenv("MI_OSQP_THREADS", "1024")
+    t16, it16, x16 = run()
+    assert (t8, t16) == (512, 1024)
+    assert it8 == it16 and np.max(np.abs(x8 - x16)) <= 1e-9
+    _compare_simple = _oracle_batch(pr, range(3))
+    for b, (_, xo, _, _) in enumerate(_compare_simple):
+        assert np.max(np.abs(x16[b] - xo)) <= TOL_X
+
+
+def test_phase_trace_diagnostics_reproduce_the_op():
+    """The traced twin of the kkt_solve op (mi_osqp_debug_trace_kkt_solve, scripts/trace_phases.py) computes the
+    same solution bit for bit and returns one (before, after) clock stamp pair per phase barrier and wave."""
+    import torch
+    pr = PR.random_box_qp(8, n=96, mg=64, nnz_per_row=6)
+    os.environ["MI_OSQP_TILE"] = "2"
+    try:
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    finally:
+        del os.environ["MI_OSQP_TILE"]
+    B, N = 8, pr["n"] + pr["m"]
+    rhs = torch.randn(B, N, dtype=torch.float64, device="cuda")
+    sol_t = torch.empty_like(rhs); sol_o = torch.empty_like(rhs)
+    tr, ftab, btab, (fp, bp, nw, words) = s.debug_trace_kkt_solve(rhs, sol_t)
+    s.kkt_solve_device(rhs, sol_o)
+    assert torch.equal(sol_t, sol_o)
+    assert ftab.shape == (fp, 4 * nw + 1) and btab.shape == (bp, 4 * nw + 1) and tr.shape == (2, words)
+    stamps = tr[0][4 + 4 * nw: 4 + 4 * nw + fp * nw * 2].reshape(fp, nw, 2).astype(np.int64)
+    assert np.all((stamps[:, :, 1] - stamps[:, :, 0]) % (1 << 32) < (1 << 28))     # every barrier was passed by every wave
+    assert np.all(stamps[:, :, 1] != 0)
