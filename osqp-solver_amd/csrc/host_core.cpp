@@ -267,7 +267,6 @@ namespace {
 struct RowWork { uint32_t row; std::vector<std::pair<uint32_t, int32_t>> ent; };   // ent: (gather index, value source)
 struct LevelWork { std::vector<RowWork> rowsA, rowsB; };                           // B rows: store instead of subtract
 
-int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
 // Builds one schedule.  Work is first laid out as phases (per level: one phase for rowsA, one for rowsB, each

@@ -64,22 +64,6 @@ typedef __amdgpu_buffer_rsrc_t mi_rsrc;
 __device__ __forceinline__ mi_rsrc make_rsrc(const void *p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
-template <int BT>
-__device__ __forceinline__ void buf_load_bt(mi_rsrc r, uint32_t voff, uint32_t soff, double (&o)[BT]) {
-  if constexpr (BT == 1) {
-    const mi_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    o[0] = __hiloint2double((int)t.y, (int)t.x);
-  } else if constexpr (BT == 2) {
-    const mi_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    o[0] = __hiloint2double((int)t.y, (int)t.x); o[1] = __hiloint2double((int)t.w, (int)t.z);
-  } else {
-    const mi_u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    const mi_u32x4 t1 = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16u, soff, 0);
-    o[0] = __hiloint2double((int)t0.y, (int)t0.x); o[1] = __hiloint2double((int)t0.w, (int)t0.z);
-    o[2] = __hiloint2double((int)t1.y, (int)t1.x); o[3] = __hiloint2double((int)t1.w, (int)t1.z);
-  }
-}
-
 __device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
@@ -511,7 +495,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
-  const int n = a.n, m = a.m, N = a.N;
+  const int n = a.n, m = a.m;
   double *red;
   double *xs = solve_vector<BT, GX>(a, smem, tile, red);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile, true);
@@ -800,7 +784,7 @@ template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), b = tid % BT;
   const int n = a.n, m = a.m;
   const int qp = tile * BT + b;
   double *lds_rest;
