@@ -54,6 +54,8 @@ struct FactorArgs {
   const double *pa_val, *l, *u, *dscal;
   double *rho_vec, *rho_inv, *Lblk, *Dl, *dinv_scratch, *fwd_val, *bwd_val, *dinv;
   int *iscal, *npos;
+  const int *work;    // non-null: work list of the slots (tile * BT + b) to refactor, packed BT per work tile, -1 = none;
+                      // null: every slot of the batch (force_all) / the slots whose IS_NEED_REFACTOR flag is set
   double sigma;
 };
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);

@@ -1000,25 +1000,29 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   const int m = a.m, N = a.N;
-  int *iscal = a.iscal + (size_t)tile * IS_COUNT * BT;
-  const int flag = a.force_all ? (tile * BT + b < a.B) : iscal[IS_NEED_REFACTOR * BT + b];
+  // The QP of lane class b: with a work list the flagged QPs of the whole batch are packed BT per workgroup (a
+  // refactorisation is latency-bound per tile, so fewer, fuller tiles = fewer rounds over the CUs); per-QP arrays
+  // are addressed through their home slot, the block storage / D scratch through the work tile.
+  const int slot = a.work ? a.work[tile * BT + b] : tile * BT + b;
+  const size_t home = slot >= 0 ? (size_t)(slot / BT) : 0, hb = slot >= 0 ? (size_t)(slot % BT) : 0;
+  auto H = [&](size_t len, size_t i) { return (home * len + i) * BT + hb; };      // element i of a [tile][len][BT] array of this QP
+  int flag = 0;
+  if (slot >= 0) flag = a.work ? 1 : (a.force_all ? (slot < a.B) : a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)]);
   if (!__syncthreads_or(flag)) return;
   double *Ss = smem + (size_t)wave * MI_CHUNK * MI_CHUNK * BT;
   double *Lb = a.Lblk + (size_t)tile * a.storage * BT;
   double *Dl = a.Dl + (size_t)tile * N * BT;
-  double *dinv = a.dinv + (size_t)tile * N * BT;
-  double *rho_vec = a.rho_vec + (size_t)tile * m * BT, *rho_inv = a.rho_inv + (size_t)tile * m * BT;
-  const double *lo = a.l + (size_t)tile * m * BT, *up = a.u + (size_t)tile * m * BT;
-  const double rho = a.dscal[((size_t)tile * DS_COUNT + DS_RHO) * BT + b];
+  const double rho = a.dscal[H(DS_COUNT, DS_RHO)];
   // ---- rho vector of the QPs being refactored ([EXT] osqp_update_rho)
   if (flag && !a.force_all) {
     for (int e = tid; e < m * BT; e += nthr) {
-      const double l = lo[e], u = up[e];
+      const size_t k = H(m, e / BT);
+      const double l = a.l[k], u = a.u[k];
       double rv;
       if (l < -MI_INFTY * MI_MIN_SCALING && u > MI_INFTY * MI_MIN_SCALING) rv = MI_RHO_MIN;
       else if (u - l < 1e-4) rv = 1e3 * rho;
       else rv = rho;
-      rho_vec[e] = rv; rho_inv[e] = 1.0 / rv;
+      a.rho_vec[k] = rv; a.rho_inv[k] = 1.0 / rv;
     }
   }
   {    // zero the block storage (16-byte stores; storage * BT is even or the tail is handled singly)
@@ -1030,7 +1034,6 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   __syncthreads();
   // ---- assemble the permuted KKT into block storage
   {
-    const double *pav = a.pa_val + (size_t)tile * a.pa_len * BT;
     // 4 entries per thread and trip: the table reads, then the value reads, then the stores (independent loads in flight)
     constexpr int UA = 2;
     const int tot = a.nnzK * BT;
@@ -1046,11 +1049,11 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
 #pragma unroll
       for (int u = 0; u < UA; u++) {
         const uint32_t kind = src[u] >> 29, idx = src[u] & 0x1FFFFFFFu;
-        if (kind == 0) v[u] = pav[(size_t)idx * BT + b];
-        else if (kind == 1) v[u] = pav[(size_t)idx * BT + b] + a.sigma;
+        if (kind == 0) v[u] = a.pa_val[H(a.pa_len, idx)];
+        else if (kind == 1) v[u] = a.pa_val[H(a.pa_len, idx)] + a.sigma;
         else if (kind == 2) v[u] = a.sigma;
-        else if (kind == 3) v[u] = pav[((size_t)a.nnzP + idx) * BT + b];
-        else v[u] = -rho_inv[(size_t)idx * BT + b];
+        else if (kind == 3) v[u] = a.pa_val[H(a.pa_len, (size_t)a.nnzP + idx)];
+        else v[u] = -a.rho_inv[H(m, idx)];
       }
 #pragma unroll
       for (int u = 0; u < UA; u++) if (e0 + u * nthr < tot) Lb[(size_t)dst[u] * BT + b] = v[u];
@@ -1079,12 +1082,12 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     __syncthreads();
     if (npos) atomicAdd(&s_npos[b], npos);
     __syncthreads();
-    if (tid < BT) a.npos[(size_t)tile * BT + b] = s_npos[b];
+    if (tid < BT && slot >= 0) a.npos[slot] = s_npos[b];
     if (tid < BT && flag && s_npos[b] != a.n && !a.debug_skip) bad_inertia = 1;
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag && !(a.debug_skip & 16)) {
-    double *fv = a.fwd_val + ((size_t)tile * BT + b) * a.fwd.n_steps * 64, *bv = a.bwd_val + ((size_t)tile * BT + b) * a.bwd.n_steps * 64;   // this thread's QP stream
+    double *fv = a.fwd_val + (size_t)slot * a.fwd.n_steps * 64, *bv = a.bwd_val + (size_t)slot * a.bwd.n_steps * 64;   // this thread's QP stream
     auto scatter = [&](double *dst, const int32_t *map, uint32_t n_slots) {
       constexpr int US = 4;                 // table reads, then value reads, then stores: 4 independent chains per thread
       const uint32_t tot = n_slots * (uint32_t)BT;
@@ -1101,10 +1104,10 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     };
     scatter(fv, a.fwd_srcblk, a.fwd.n_slots);
     scatter(bv, a.bwd_srcblk, a.bwd.n_slots);
-    for (int e = tid; e < N * BT; e += nthr) dinv[e] = dnew[e];
+    for (int e = tid; e < N * BT; e += nthr) a.dinv[H(N, e / BT)] = dnew[e];
   }
   __syncthreads();
-  if (tid < BT) iscal[IS_NEED_REFACTOR * BT + b] = bad_inertia ? -1 : 0;   // -1: the new factor has the wrong inertia
+  if (tid < BT && slot >= 0) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = bad_inertia ? -1 : 0;   // -1: the new factor has the wrong inertia
 }
 
 template <int BT>

@@ -136,7 +136,7 @@ struct mi_osqp_batch {
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
   bool host_rho_stale = false;
   int *h_npos = nullptr;
-  DevBuf<double> stage; DevBuf<int> ids;
+  DevBuf<double> stage; DevBuf<int> ids, work;
   int *h_iscal = nullptr;     // pinned
   double *h_dscal = nullptr;  // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -634,7 +634,9 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     if (active.empty()) break;
     // ---- compaction
     int target = ((int)active.size() + BT - 1) / BT;
+    bool compacted_now = false;
     if (!no_compact && target < ntl) {
+      compacted_now = true;
       double tc = now_s();
       std::vector<char> is_active(ntl * BT, 0);
       for (int s : active) is_active[s] = 1;
@@ -656,7 +658,20 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     if (n_ref) {
       double tr = now_s();
       FactorArgs fa = make_factor_args(h, 0);
-      HIPCHK(launch_factor(fa, BT, ntl, factor_threads(), h->stream));
+      // work list: the flagged slots packed BT per workgroup (fewer, fuller tiles = fewer rounds over the CUs)
+      // (after a compaction of this segment the host copy of the flags is stale: flag-driven mode over all tiles)
+      std::vector<int> work;
+      int wtiles = ntl;
+      if (!compacted_now) {
+        for (int s : active)
+          if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
+        wtiles = ((int)work.size() + BT - 1) / BT;
+        work.resize((size_t)wtiles * BT, -1);
+        if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT))) return rc;
+        HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        fa.work = h->work.p;
+      }
+      HIPCHK(launch_factor(fa, BT, wtiles, factor_threads(), h->stream));
       HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       for (int s = 0; s < ntl * BT; s++)
