@@ -54,6 +54,7 @@ struct FactorArgs {
   const double *pa_val, *l, *u, *dscal;
   double *rho_vec, *rho_inv, *Lblk, *Dl, *dinv_scratch, *fwd_val, *bwd_val, *dinv;
   int *iscal, *npos;
+  int home_bt;        // QPs per tile of the per-QP arrays ([tile][len][home_bt]); the kernel's own BT (QPs per workgroup) may differ
   const int *work;    // non-null: work list of the slots (tile * BT + b) to refactor, packed BT per work tile, -1 = none;
                       // null: every slot of the batch (force_all) / the slots whose IS_NEED_REFACTOR flag is set
   double sigma;

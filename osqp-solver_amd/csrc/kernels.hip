@@ -837,7 +837,7 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
   for (int j = 0; j < MI_CHUNK; j++) acc[j] = (hh == 0 && row_ok && (uint32_t)j < w) ? Lb[((size_t)off + j * h + i) * BT + b] : 0.0;
   // ---- rank-1 sources (one-column chunks), 8 per batch: all operand loads of a batch are in flight
   // together, the 8 scaled B columns go through wave-private LDS; group hh applies members g = hh mod H
-  constexpr int G = 8;
+  constexpr int G = 8;                     // rank-1 sources per batch (16 at BT = 1 fits the registers but is not faster)
   for (uint32_t q = q0; q < ((a.debug_skip & 1) ? q0 : qm); q += G) {
     double av[G / H], bv[G / H];
 #pragma unroll
@@ -1004,8 +1004,9 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   // refactorisation is latency-bound per tile, so fewer, fuller tiles = fewer rounds over the CUs); per-QP arrays
   // are addressed through their home slot, the block storage / D scratch through the work tile.
   const int slot = a.work ? a.work[tile * BT + b] : tile * BT + b;
-  const size_t home = slot >= 0 ? (size_t)(slot / BT) : 0, hb = slot >= 0 ? (size_t)(slot % BT) : 0;
-  auto H = [&](size_t len, size_t i) { return (home * len + i) * BT + hb; };      // element i of a [tile][len][BT] array of this QP
+  const size_t hbt = (size_t)a.home_bt;
+  const size_t home = slot >= 0 ? (size_t)slot / hbt : 0, hb = slot >= 0 ? (size_t)slot % hbt : 0;
+  auto H = [&](size_t len, size_t i) { return (home * len + i) * hbt + hb; };      // element i of a [tile][len][home_bt] array of this QP
   int flag = 0;
   if (slot >= 0) flag = a.work ? 1 : (a.force_all ? (slot < a.B) : a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)]);
   if (!__syncthreads_or(flag)) return;

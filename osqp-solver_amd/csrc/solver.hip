@@ -117,7 +117,7 @@ struct SchedBufs {
 struct mi_osqp_batch {
   Settings st;
   Analysis an;
-  int B = 0, BT = 1, ntiles = 0, threads = 512, device = 0;
+  int B = 0, BT = 1, ntiles = 0, threads = 512, device = 0, n_cus = 256;
   size_t lds = 0;
   std::vector<QPNumeric> qp;
   bool host_bounds_stale = false;
@@ -215,7 +215,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.pa_val = h->pa_val.p; a.l = h->l.p; a.u = h->u.p; a.dscal = h->dscal.p;
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
-  a.sigma = h->st.sigma;
+  a.sigma = h->st.sigma; a.home_bt = h->BT;
   { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }
   return a;
 }
@@ -438,6 +438,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if (device >= 0) { HIPCHK(hipSetDevice((int)device)); h->device = (int)device; } else HIPCHK(hipGetDevice(&h->device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
+  h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_last_error = std::string("device is not gfx950: ") + prop.gcnArchName; return MI_OSQP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
@@ -463,8 +464,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
         (rc = h->bf_asm_dst.upload(bf.asm_dst)) || (rc = h->bf_asm_src.upload(bf.asm_src)) ||
         (rc = h->fwd_srcblk.upload(an.fwd_srcblk)) || (rc = h->bwd_srcblk.upload(an.bwd_srcblk))) return rc;
     if ((rc = h->pa_val.alloc((size_t)(an.Pp[n] + an.Ap[n]) * T)) || (rc = h->pa_val.zero(h->stream)) ||
-        (rc = h->Lblk.alloc((size_t)bf.storage * T)) || (rc = h->Dl.alloc((size_t)an.N * T)) || (rc = h->Dl.zero(h->stream)) ||
-        (rc = h->dinv_scratch.alloc((size_t)an.N * T)) || (rc = h->npos.alloc(T))) return rc;
+        // (+4 QPs: a refactorisation may pack its work list with up to 4 QPs per workgroup, rounded up)
+        (rc = h->Lblk.alloc((size_t)bf.storage * (T + 4))) || (rc = h->Dl.alloc((size_t)an.N * (T + 4))) || (rc = h->Dl.zero(h->stream)) ||
+        (rc = h->dinv_scratch.alloc((size_t)an.N * (T + 4))) || (rc = h->npos.alloc(T))) return rc;
     HIPCHK(hipHostMalloc((void **)&h->h_npos, T * sizeof(int)));
   }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
@@ -661,17 +663,23 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
       // work list: the flagged slots packed BT per workgroup (fewer, fuller tiles = fewer rounds over the CUs)
       // (after a compaction of this segment the host copy of the flags is stale: flag-driven mode over all tiles)
       std::vector<int> work;
-      int wtiles = ntl;
+      int wtiles = ntl, kbt = BT;
       if (!compacted_now) {
         for (int s : active)
           if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
-        wtiles = ((int)work.size() + BT - 1) / BT;
-        work.resize((size_t)wtiles * BT, -1);
-        if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT))) return rc;
+        // QPs per workgroup of this refactorisation: one while every QP can have a CU of its own (a lone tile is
+        // latency-bound: 3.3 ms with one QP, 4.6 ms with two), the solve tiling otherwise (measured: 605 QPs take
+        // 10.9 ms whether packed 1, 2 or 4 per workgroup - the memory system, not the tiling, is the limit there)
+        const int nq = (int)work.size();
+        kbt = nq <= h->n_cus ? 1 : BT;
+        { const char *e = getenv("MI_OSQP_FACTOR_BT"); if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) kbt = atoi(e); }
+        wtiles = (nq + kbt - 1) / kbt;
+        work.resize((size_t)wtiles * kbt, -1);
+        if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT + 4))) return rc;
         HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
         fa.work = h->work.p;
       }
-      HIPCHK(launch_factor(fa, BT, wtiles, factor_threads(), h->stream));
+      HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
       HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       for (int s = 0; s < ntl * BT; s++)

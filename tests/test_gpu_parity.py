@@ -302,7 +302,10 @@ def test_compaction_path_gives_identical_results(monkeypatch):
     monkeypatch.delenv("MI_OSQP_COMPACT")
     c = run()
     assert b[0] == c[0] and b[3] == c[3]
-    np.testing.assert_array_equal(b[1], c[1]); np.testing.assert_array_equal(b[2], c[2]); np.testing.assert_array_equal(b[4], c[4])
+    # round-off only: the two paths may refactor with different numbers of QPs per workgroup (the packed work list
+    # vs. the flag-driven sweep over the compacted tiles), which changes the order of the partial sums
+    for k in (1, 2, 4):
+        assert np.max(np.abs(b[k] - c[k])) <= 1e-12
     assert a[0] == b[0] and np.max(np.abs(a[1] - b[1])) <= 1e-9      # tile 2 vs tile 4: same algorithm, round-off only
 
 
