@@ -545,21 +545,31 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
 
 // ------------------------------------------------------------------- solve
 
-static int refactor_flagged(mi_osqp_batch *h, const std::vector<int> &ids) {
-  if (ids.empty()) return 0;
-  const Analysis &an = h->an;
+// Row E13 on the device for a list of slots (tile * BT + b): rho vector from the current bounds and rho, KKT
+// assembly, block LDL', scatter into the solve streams.  The work list packs the slots kbt per workgroup.
+static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
+  if (work.empty()) return 0;
+  const int BT = h->BT;
   int rc;
-  if ((rc = sync_bounds_to_host(h))) return rc;
-  std::vector<std::vector<double>> works(host_threads());
-  std::atomic<int> fail{0};
-  parallel_for((int)ids.size(), [&](int k, int tid) {
-    QPNumeric &Q = h->qp[ids[k]];
-    int r = factor_qp(an, h->st, Q, works[tid]);
-    if (r) fail.store(r);
-  });
-  if (fail.load()) return fail.load();
-  if ((rc = upload_factors(h, ids)) || (rc = upload_rho(h, ids))) return rc;
-  for (int q : ids) std::vector<double>().swap(h->qp[q].Lx);
+  FactorArgs fa = make_factor_args(h, 0);
+  // QPs per workgroup of this refactorisation: one while every QP can have a CU of its own (a lone tile is
+  // latency-bound: 3.3 ms with one QP, 4.6 ms with two), the solve tiling otherwise (measured: 605 QPs take
+  // 10.9 ms whether packed 1, 2 or 4 per workgroup - the memory system, not the tiling, is the limit there)
+  const int nq = (int)work.size();
+  int kbt = nq <= h->n_cus ? 1 : BT;
+  { const char *e = getenv("MI_OSQP_FACTOR_BT"); if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) kbt = atoi(e); }
+  const int wtiles = (nq + kbt - 1) / kbt;
+  work.resize((size_t)wtiles * kbt, -1);
+  if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT + 4))) return rc;
+  HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  fa.work = h->work.p;
+  HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
+  HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < h->ntiles * BT; s++)
+    if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
+      g_last_error = "the KKT factor lost its inertia"; return MI_OSQP_ERR_NONCONVEX;
+    }
   return 0;
 }
 
@@ -659,33 +669,23 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     // ---- row E13 on the device: rho vector, KKT assembly, block LDL', scatter into the schedules
     if (n_ref) {
       double tr = now_s();
-      FactorArgs fa = make_factor_args(h, 0);
-      // work list: the flagged slots packed BT per workgroup (fewer, fuller tiles = fewer rounds over the CUs)
-      // (after a compaction of this segment the host copy of the flags is stale: flag-driven mode over all tiles)
-      std::vector<int> work;
-      int wtiles = ntl, kbt = BT;
       if (!compacted_now) {
+        // work list: the flagged slots of the whole batch (fewer, fuller tiles = fewer rounds over the CUs)
+        std::vector<int> work;
         for (int s : active)
           if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
-        // QPs per workgroup of this refactorisation: one while every QP can have a CU of its own (a lone tile is
-        // latency-bound: 3.3 ms with one QP, 4.6 ms with two), the solve tiling otherwise (measured: 605 QPs take
-        // 10.9 ms whether packed 1, 2 or 4 per workgroup - the memory system, not the tiling, is the limit there)
-        const int nq = (int)work.size();
-        kbt = nq <= h->n_cus ? 1 : BT;
-        { const char *e = getenv("MI_OSQP_FACTOR_BT"); if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) kbt = atoi(e); }
-        wtiles = (nq + kbt - 1) / kbt;
-        work.resize((size_t)wtiles * kbt, -1);
-        if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT + 4))) return rc;
-        HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-        fa.work = h->work.p;
+        if ((rc = device_refactor_slots(h, std::move(work)))) return rc;
+      } else {
+        // after a compaction of this segment the host copy of the flags is stale: flag-driven sweep over all tiles
+        FactorArgs fa = make_factor_args(h, 0);
+        HIPCHK(launch_factor(fa, BT, ntl, factor_threads(), h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int s = 0; s < ntl * BT; s++)
+          if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
+            g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX;
+          }
       }
-      HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
-      HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      for (int s = 0; s < ntl * BT; s++)
-        if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
-          g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX;
-        }
       h->host_rho_stale = true;
       h->last_refactors += n_ref;
       h->last_refactor_s += now_s() - tr;
@@ -885,7 +885,7 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
   std::vector<int> all(B);
   for (int i = 0; i < B; i++) all[i] = i;
   if ((rc = upload_problem(h, all, false))) return rc;
-  if ((rc = refactor_flagged(h, changed))) return rc;
+  if ((rc = device_refactor_slots(h, changed))) return rc;      // constraint types changed: new rho vector + factor on the device
   if (!changed.empty() && (rc = snapshot(h))) return rc;
   return MI_OSQP_OK;
 }
@@ -923,26 +923,23 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
   for (int j = 0; j <= n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
   for (int k = 0; k < nnzA; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
   if ((rc = sync_bounds_to_host(h)) || (rc = sync_rho_to_host(h))) return rc;
-  std::vector<std::vector<double>> works(host_threads());
-  std::atomic<int> fail{0};
+  // host: unscale, new values, Ruiz rescale (O(nnz) per QP); device: the numeric refactorisation of every QP
+  // (factor_kernel on the new scaled values and the current rho vectors) - the same code path a rho update takes
   const int CH = 128;
   for (int c0 = 0; c0 < B; c0 += CH) {
     int c1 = std::min(B, c0 + CH);
-    parallel_for(c1 - c0, [&](int k, int tid) {
+    parallel_for(c1 - c0, [&](int k, int) {
       int qi = c0 + k;
       QPNumeric &Q = h->qp[qi];
       if (h->st.scaling) unscale_qp(an, Q);
       std::copy(Av + (size_t)qi * nnzA, Av + (size_t)(qi + 1) * nnzA, Q.Av.begin());
       if (h->st.scaling) scale_qp(an, h->st, Q);
-      int r = factor_qp(an, h->st, Q, works[tid]);
-      if (r) fail.store(r);
     });
-    if (fail.load()) return fail.load();
     std::vector<int> ids(c1 - c0);
     for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
-    if ((rc = upload_factors(h, ids)) || (rc = upload_problem(h, ids, true)) || (rc = sync_scalars_to_device(h, ids, true))) return rc;
-    for (int qi = c0; qi < c1; qi++) std::vector<double>().swap(h->qp[qi].Lx);
+    if ((rc = upload_problem(h, ids, true)) || (rc = sync_scalars_to_device(h, ids, true))) return rc;
   }
+  if ((rc = mi_osqp_batch_refactor_device(h))) return rc;
   return snapshot(h);
 }
 
