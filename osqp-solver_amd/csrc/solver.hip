@@ -247,25 +247,6 @@ static std::vector<double> gather_rows(const std::vector<int> &ids, int len, G &
   return rows;
 }
 
-// upload factors (canonical Lx + Dlinv on the host) of the listed QPs
-static int upload_factors(mi_osqp_batch *h, const std::vector<int> &ids) {
-  const Analysis &an = h->an;
-  int nq = (int)ids.size(), nnzL = an.nnzLx(), N = an.N;
-  if (!nq) return 0;
-  std::vector<double> rows = gather_rows(ids, nnzL, [&](int q) -> const std::vector<double> & { return h->qp[q].Lx; });
-  int rc = ensure_stage(h, std::max<size_t>(rows.size(), 1), ids.size());
-  if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  if (nnzL) {
-    HIPCHK(hipMemcpyAsync(h->stage.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(launch_scatter(h->stage.p, h->fwd_val.p, h->fwd.src.p, h->ids.p, nq, nnzL, h->fwd.view(an.fwd), h->BT, h->stream));
-    HIPCHK(launch_scatter(h->stage.p, h->bwd_val.p, h->bwd.src.p, h->ids.p, nq, nnzL, h->bwd.view(an.bwd), h->BT, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-  }
-  std::vector<double> drows = gather_rows(ids, N, [&](int q) -> const std::vector<double> & { return h->qp[q].Dlinv; });
-  return upload_rows(h, drows, &ids, nq, N, h->dinv.p);
-}
-
 static int upload_rho(mi_osqp_batch *h, const std::vector<int> &ids) {
   int m = h->an.m, nq = (int)ids.size(), rc;
   if (!nq || !m) return 0;
@@ -478,15 +459,13 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   // ---- per-QP numeric (host threads), uploaded in chunks to bound host memory
   h->qp.resize(B);
   int nnzPin = (int)Pp[n], nnzA = (int)Ap[n];
-  std::atomic<int> fail{0};
   const int CH = 128;
-  std::vector<std::vector<double>> works(host_threads());
   double t_factor = 0.0, t_upload = 0.0;
   for (int c0 = 0; c0 < B; c0 += CH) {
     int c1 = (int)std::min<int64_t>(B, c0 + CH);
     double ta = now_s();
     // QPs whose P, A, q equal those of the chunk's first QP (GOMP: all of them, only bounds differ) reuse its
-    // equilibration and, when their rho vector matches too, its factor
+    // equilibration.  The numeric factorisation itself happens on the device, below.
     std::vector<char> dup(c1 - c0, 0);
     for (int k = 1; k < c1 - c0; k++) {
       const int qi = c0 + k;
@@ -494,28 +473,22 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
                !memcmp(Av + (size_t)qi * nnzA, Av + (size_t)c0 * nnzA, sizeof(double) * nnzA) &&
                (!q || !memcmp(q + (size_t)qi * n, q + (size_t)c0 * n, sizeof(double) * n));
     }
-    auto numeric = [&](int k, int tid, bool second_pass) {
+    auto numeric = [&](int k, bool second_pass) {
       if ((bool)dup[k] != second_pass) return;
       int qi = c0 + k;
       QPNumeric &Q = h->qp[qi];
       load_qp(an, h->st, Pv + (size_t)qi * nnzPin, q ? q + (size_t)qi * n : nullptr, Av + (size_t)qi * nnzA,
               l + (size_t)qi * m, u + (size_t)qi * m, Q);
-      const QPNumeric &R = h->qp[c0];
-      if (h->st.scaling) { if (second_pass) scale_like(an, R, Q); else scale_qp(an, h->st, Q); }
+      if (h->st.scaling) { if (second_pass) scale_like(an, h->qp[c0], Q); else scale_qp(an, h->st, Q); }
       set_rho_vec(an, h->st, Q);
-      if (second_pass && Q.rho_vec == R.rho_vec) { Q.Lx = R.Lx; Q.Dl = R.Dl; Q.Dlinv = R.Dlinv; return; }
-      int r = factor_qp(an, h->st, Q, works[tid]);
-      if (r) fail.store(r);
     };
-    parallel_for(c1 - c0, [&](int k, int tid) { numeric(k, tid, false); });
-    if (!fail.load()) parallel_for(c1 - c0, [&](int k, int tid) { numeric(k, tid, true); });
+    parallel_for(c1 - c0, [&](int k, int) { numeric(k, false); });
+    parallel_for(c1 - c0, [&](int k, int) { numeric(k, true); });
     double tb = now_s();
     t_factor += tb - ta;
-    if (fail.load()) return fail.load();
     std::vector<int> ids(c1 - c0);
     for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
-    if ((rc = upload_factors(h, ids)) || (rc = upload_rho(h, ids)) || (rc = upload_problem(h, ids, true))) return rc;
-    for (int qi = c0; qi < c1; qi++) { std::vector<double>().swap(h->qp[qi].Lx); }
+    if ((rc = upload_rho(h, ids)) || (rc = upload_problem(h, ids, true))) return rc;
     t_upload += now_s() - tb;
   }
   {
@@ -525,6 +498,13 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     for (size_t k = 0; k < cnt; k++) h->h_dscal[k] = 0.0;
     HIPCHK(hipMemcpy(h->dscal.p, h->h_dscal, cnt * sizeof(double), hipMemcpyHostToDevice));
     if ((rc = sync_scalars_to_device(h, all, true))) return rc;
+  }
+  // E5 numeric on the device: KKT assembly + block LDL' + inverted diagonal blocks + scatter into the solve
+  // streams of every QP (the kernel every later rho / A update uses); a wrong inertia comes back as an error
+  {
+    double tb = now_s();
+    if ((rc = mi_osqp_batch_refactor_device(h))) return rc;
+    t_factor += now_s() - tb;
   }
   if ((rc = reset_solve_state(h, true))) return rc;
   if ((rc = snapshot(h))) return rc;
