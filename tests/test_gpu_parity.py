@@ -259,9 +259,10 @@ def test_cpp_facade_example_runs(tmp_path):
 
 @pytest.mark.parametrize("tile", [1, 4])
 def test_device_refactor_matches_host_factor(tile, monkeypatch):
-    """Row E13 on the device: the batched block LDL' must reproduce the factor the
-    host built at setup (same KKT, same rho) -- checked through the KKT-solve op
-    against the oracle's independent factor."""
+    """Rows E5 / E13 on the device: the batched block LDL' (used at setup and for every rho / A update) is checked
+    through the KKT-solve op against the oracle's independent factor, after setup and again after an explicit
+    refactorisation (same KKT, same rho).  The host left-looking factor it replaced lives on as the reference of
+    the CPU tests (tests/test_host_schedule.py)."""
     import torch
     monkeypatch.setenv("MI_OSQP_TILE", str(tile))
     for pr in (PR.random_box_qp(6, n=96, mg=64, nnz_per_row=6), PR.gomp_batch(3, 4, 12), PR.random_box_qp(2)):
