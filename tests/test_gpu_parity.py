@@ -430,3 +430,25 @@ def test_phase_trace_diagnostics_reproduce_the_op():
     stamps = tr[0][4 + 4 * nw: 4 + 4 * nw + fp * nw * 2].reshape(fp, nw, 2).astype(np.int64)
     assert np.all((stamps[:, :, 1] - stamps[:, :, 0]) % (1 << 32) < (1 << 28))     # every barrier was passed by every wave
     assert np.all(stamps[:, :, 1] != 0)
+
+
+def test_degenerate_shapes_no_constraints_and_one_variable():
+    """Edge shapes of the boundary: m = 0 (unconstrained QP: the KKT system is just P + sigma I) and n = m = 1."""
+    n = 5
+    P = sp.csc_matrix(np.diag([1.0, 2, 3, 4, 5]) + 0.1 * np.ones((5, 5)))
+    q = np.array([1.0, -2, 0.5, 0, 3])
+    A = sp.csc_matrix((0, n))
+    s = M.BatchSolver(P, np.tile(P.data, (2, 1)), np.tile(q, (2, 1)), A, np.zeros((2, 0)), np.zeros((2, 0)), np.zeros((2, 0)))
+    info = s.solve()
+    o = O.OracleQPSolver(P, q, A, np.zeros(0), np.zeros(0))
+    st, xo = o.solve()
+    for b in range(2):
+        assert info[b].exit_code == ST2EXIT[st] and info[b].iter == o.info().iter
+        assert np.max(np.abs(s.primal()[b] - xo)) <= TOL_X
+    assert np.max(np.abs(xo + np.linalg.solve(P.toarray(), q))) < 1e-4          # and that is the unconstrained minimiser
+    P1 = sp.csc_matrix([[2.0]]); A1 = sp.csc_matrix([[1.0]])
+    s = M.BatchSolver(P1, np.array([[2.0]]), np.array([[1.0]]), A1, np.array([[1.0]]), np.array([[0.3]]), np.array([[1.0]]))
+    info = s.solve()
+    o = O.OracleQPSolver(P1, np.array([1.0]), A1, np.array([0.3]), np.array([1.0]))
+    st, xo = o.solve()
+    assert info[0].exit_code == ST2EXIT[st] and info[0].iter == o.info().iter and abs(s.primal()[0][0] - xo[0]) <= TOL_X
