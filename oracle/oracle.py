@@ -184,6 +184,11 @@ class OracleQPSolver:
         if self._L.oq_update_bounds(self._h, _dp(lv), _dp(uv)) != 0:
             raise ValueError("lower bound must be <= upper bound")
 
+    def update_bounds_only(self, l, u):
+        lv, uv = _f64(l), _f64(u)
+        if self._L.oq_update_bounds(self._h, _dp(lv), _dp(uv)) != 0:
+            raise ValueError("lower bound must be <= upper bound")
+
     def set_warm_start(self, x):
         xv = _f64(x); self._L.oq_warm_start_x(self._h, _dp(xv))
 

@@ -135,6 +135,7 @@ struct mi_osqp_batch {
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
   bool host_rho_stale = false;
+  bool clear_rho_updates = true;          // the next solve starts counting rho updates from 0 (setup / update_* / reset happened)
   int *h_npos = nullptr;
   DevBuf<double> stage; DevBuf<int> ids, work;
   int *h_iscal = nullptr;     // pinned
@@ -357,14 +358,19 @@ static int sync_rho_to_host(mi_osqp_batch *h) {
 static int reset_solve_state(mi_osqp_batch *h, bool cold) {
   int rc;
   // statuses: UNSOLVED, not done (padding lanes of the last tile stay done)
+  // (the count of rho updates survives a plain re-solve, as upstream's info->rho_updates does: only setup and the
+  //  update_* calls reset it)
   size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT;
-  for (size_t k = 0; k < icnt; k++) h->h_iscal[k] = 0;
   for (int t = 0; t < h->ntiles; t++)
     for (int b = 0; b < h->BT; b++) {
       int *p = h->h_iscal + (size_t)t * IS_COUNT * h->BT;
+      const int keep = h->clear_rho_updates ? 0 : p[IS_RHO_UPDATES * h->BT + b];
+      for (int k = 0; k < IS_COUNT; k++) p[k * h->BT + b] = 0;
       p[IS_STATUS * h->BT + b] = -10;
       p[IS_DONE * h->BT + b] = (t * h->BT + b >= h->B) ? 1 : 0;
+      p[IS_RHO_UPDATES * h->BT + b] = keep;
     }
+  h->clear_rho_updates = false;
   HIPCHK(hipMemcpyAsync(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (cold) { if ((rc = h->x.zero(h->stream)) || (rc = h->z.zero(h->stream)) || (rc = h->y.zero(h->stream))) return rc; }
   return 0;
@@ -616,18 +622,23 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
     h->kernel_qp_iters += 0;
     iter = seg_end;
-    // slots still iterating / asking for a refactorisation
-    std::vector<int> active;
-    int n_ref = 0;
+    // slots still iterating / asking for a refactorisation.  A QP that runs into max_iter at a rho-update iteration
+    // has finished AND asks for its refactorisation: upstream adapts rho (and refactors) before it leaves the loop,
+    // and the next Solve() of a warm-started solver continues from that factor.
+    std::vector<int> active, work;
     for (int s = 0; s < ntl * BT; s++) {
       const int *t = h->h_iscal + (size_t)(s / BT) * IS_COUNT * BT;
-      if (qp_of_slot[s] >= 0 && !t[IS_DONE * BT + s % BT]) { active.push_back(s); if (t[IS_NEED_REFACTOR * BT + s % BT]) n_ref++; }
+      if (qp_of_slot[s] < 0) continue;
+      if (!t[IS_DONE * BT + s % BT]) active.push_back(s);
+      if (t[IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
     }
-    if (active.empty()) break;
+    const int n_ref = (int)work.size();
+    if (active.empty() && !n_ref) break;
     // ---- compaction
     int target = ((int)active.size() + BT - 1) / BT;
     bool compacted_now = false;
-    if (!no_compact && target < ntl) {
+    const int ntl_before = ntl;
+    if (!no_compact && target < ntl && !active.empty()) {
       compacted_now = true;
       double tc = now_s();
       std::vector<char> is_active(ntl * BT, 0);
@@ -651,17 +662,14 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
       double tr = now_s();
       if (!compacted_now) {
         // work list: the flagged slots of the whole batch (fewer, fuller tiles = fewer rounds over the CUs)
-        std::vector<int> work;
-        for (int s : active)
-          if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
         if ((rc = device_refactor_slots(h, std::move(work)))) return rc;
       } else {
-        // after a compaction of this segment the host copy of the flags is stale: flag-driven sweep over all tiles
+        // after a compaction of this segment the host copy of the flags is stale: flag-driven sweep over the tiles
         FactorArgs fa = make_factor_args(h, 0);
-        HIPCHK(launch_factor(fa, BT, ntl, factor_threads(), h->stream));
-        HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(launch_factor(fa, BT, ntl_before, factor_threads(), h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl_before * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        for (int s = 0; s < ntl * BT; s++)
+        for (int s = 0; s < ntl_before * BT; s++)
           if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
             g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX;
           }
@@ -670,6 +678,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
       h->last_refactors += n_ref;
       h->last_refactor_s += now_s() - tr;
     }
+    if (active.empty()) break;
   }
   // ---- undo the compaction (reverse order; swaps are involutions)
   {
@@ -819,6 +828,7 @@ int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launche
 
 int mi_osqp_batch_reset(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
+  h->clear_rho_updates = true;
   auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
     if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return 0;
@@ -848,6 +858,7 @@ int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
 
 int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u) {
   if (!h || !l || !u) return MI_OSQP_ERR_NULL;
+  h->clear_rho_updates = true;
   const Analysis &an = h->an;
   int m = an.m, B = h->B, rc;
   for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
@@ -872,6 +883,7 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
 
 int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream) {
   if (!h || !d_l || !d_u) return MI_OSQP_ERR_NULL;
+  h->clear_rho_updates = true;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   int m = h->an.m, B = h->B;
   if (!m) return MI_OSQP_OK;
@@ -898,6 +910,7 @@ int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, cons
 
 int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
+  h->clear_rho_updates = true;
   const Analysis &an = h->an;
   int n = an.n, B = h->B, nnzA = an.Ap[n], rc;
   for (int j = 0; j <= n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;

@@ -1,0 +1,52 @@
+"""developer script: randomized parity sweep (GPU vs oracle) over shapes, densities, tilings and thread counts."""
+import os, sys, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import osqp_solver_amd as M
+from osqp_solver_amd import problems as PR
+from oracle import oracle as O
+
+ST2EXIT = {1: 0, 2: 3, -3: 1, 3: 4, -4: 2, 4: 5, -2: 6, -7: 9, -10: 10}
+rng = np.random.default_rng(7)
+bad = 0
+cases = 0
+for trial in range(int(os.environ.get("TRIALS", "24"))):
+    n = int(rng.integers(3, 220)); mg = int(rng.integers(1, 260)); nnz = int(rng.integers(1, min(n, 12) + 1))
+    B = int(rng.integers(1, 7))
+    tile = int(rng.choice([1, 2, 4])); thr = int(rng.choice([128, 256, 512, 1024]))
+    if thr == 1024 and tile == 4: thr = 512
+    os.environ["MI_OSQP_TILE"] = str(tile); os.environ["MI_OSQP_THREADS"] = str(thr)
+    if rng.random() < 0.25: os.environ["MI_OSQP_GLOBAL_XS"] = "1"
+    else: os.environ.pop("MI_OSQP_GLOBAL_XS", None)
+    if os.environ.get("MI_OSQP_GLOBAL_XS") and thr == 1024: thr = 512; os.environ["MI_OSQP_THREADS"] = "512"
+    pr = PR.random_box_qp(B, n=n, mg=mg, nnz_per_row=nnz, pattern_seed=int(rng.integers(1 << 30)))
+    eps = float(rng.choice([1e-3, 1e-6]))
+    kw = dict(eps_abs=eps, eps_rel=eps)
+    try:
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
+        info = s.solve(); x = s.primal()
+        # second solve after a bounds change (update path) for half of the trials
+        if trial % 2:
+            if trial % 4 == 1: s.update_A(pr["Ax"])          # same values: the full QPSolver::update sequence on both sides
+            s.update_bounds(pr["l"] * 0.8, pr["u"] * 0.8); info = s.solve(); x = s.primal()
+    except Exception as e:
+        print("trial", trial, "EXCEPTION", repr(e), dict(n=n, mg=mg, nnz=nnz, B=B, tile=tile, thr=thr)); bad += 1; continue
+    for b in range(B):
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, pr["q"][b], A, pr["l"][b], pr["u"][b], **kw)
+        st, xo = o.solve()
+        if trial % 2:
+            if trial % 4 == 1: o.update(pr["l"][b] * 0.8, A, pr["u"][b] * 0.8)
+            else: o.update_bounds_only(pr["l"][b] * 0.8, pr["u"][b] * 0.8)
+            st, xo = o.solve()
+        io = o.info()
+        tol = 1e-3 if st == -2 else 1e-6          # max_iter: thousands of non-converging iterations amplify round-off
+        okk = info[b].exit_code == ST2EXIT[st] and info[b].iter == io.iter and (np.all(np.isnan(xo)) or np.max(np.abs(x[b] - xo)) <= tol)
+        cases += 1
+        if not okk:
+            bad += 1
+            print("trial", trial, "MISMATCH qp", b, dict(n=n, mg=mg, nnz=nnz, B=B, tile=tile, thr=thr, eps=eps, gx=os.environ.get("MI_OSQP_GLOBAL_XS")),
+                  "gpu", info[b].exit_code, info[b].iter, "oracle", ST2EXIT[st], io.iter, "dx", float(np.nanmax(np.abs(x[b] - xo))))
+    s.close()
+print(f"{cases} QPs compared, {bad} problems")
+sys.exit(1 if bad else 0)

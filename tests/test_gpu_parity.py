@@ -452,3 +452,25 @@ def test_degenerate_shapes_no_constraints_and_one_variable():
     o = O.OracleQPSolver(P1, np.array([1.0]), A1, np.array([0.3]), np.array([1.0]))
     st, xo = o.solve()
     assert info[0].exit_code == ST2EXIT[st] and info[0].iter == o.info().iter and abs(s.primal()[0][0] - xo[0]) <= TOL_X
+
+
+def test_max_iter_at_a_rho_update_iteration_then_resolve():
+    """Found by scripts/stress_random.py: a QP that runs into max_iter (4000 = a multiple of the rho interval) adapts rho
+    and refactors in its very last iteration (upstream's loop order), and the next Solve() of the warm-started solver
+    continues from THAT factor.  The second solve must therefore follow the oracle's (here: again 4000 iterations),
+    and the count of rho updates accumulates over a plain re-solve as upstream's info does."""
+    pr = PR.random_box_qp(3, n=80, mg=63, nnz_per_row=1, pattern_seed=1021630442)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    i1 = s.solve()
+    i2 = s.solve()
+    for b in range(3):
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, pr["q"][b], A, pr["l"][b], pr["u"][b])
+        st1, _ = o.solve(); io1 = o.info()
+        it1, ru1 = io1.iter, io1.rho_updates
+        st2, x2 = o.solve(); io2 = o.info()
+        assert (i1[b].exit_code, i1[b].iter, i1[b].rho_updates) == (ST2EXIT[st1], it1, ru1)
+        assert (i2[b].exit_code, i2[b].iter, i2[b].rho_updates) == (ST2EXIT[st2], io2.iter, io2.rho_updates)
+        tol = 1e-3 if st2 == -2 else TOL_X
+        assert np.max(np.abs(s.primal()[b] - x2)) <= tol
+    assert any(i.exit_code == ST2EXIT[-2] for i in i1)          # the case really contains a max_iter QP
