@@ -432,7 +432,7 @@ __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtr
 
 // E6-E10 for iterations (iter_begin, iter_end] of one tile.  Lean on purpose: the
 // residual / termination / rho logic lives in check_kernel, so this kernel needs
-// little beyond the rotating prefetch buffer.
+// little beyond the register ring of the step streams.
 template <int BT, int NT, bool GX>
 __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   extern __shared__ double smem[];

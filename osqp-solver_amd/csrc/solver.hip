@@ -601,8 +601,8 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
   for (int s = 0; s < nslots; s++) qp_of_slot[s] = s < h->B ? s : -1;
   HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, qp_of_slot.data(), nslots * sizeof(int), hipMemcpyHostToDevice, h->stream));
   std::vector<std::vector<int2>> rounds;
-  // compaction is implemented and tested but OFF by default: a CU ingests ~18 GB/s whatever the number of
-  // active tiles, so packing the survivors into fewer tiles does not shorten a segment (profiles/r01/README.md)
+  // compaction (re-pairing the QPs still iterating into fewer tiles) is implemented and tested but OFF by default:
+  // since the value streams are per QP, a finished QP costs no bytes anyway, and moving data only breaks even
   const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr;
   int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
   while (true) {
