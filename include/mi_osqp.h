@@ -96,6 +96,7 @@ typedef struct {
   int64_t n_supernodes, n_blocks;
   int64_t fwd_levels, bwd_levels, fwd_slots, bwd_slots, chk_slots;
   int64_t lds_bytes, threads_per_block;
+  int64_t dense_tail_rows, dense_tail_slots;   /* trailing rows served by the inverted Schur complement (0 = none), its stream slots */
   double  setup_seconds_host, setup_seconds_factor, setup_seconds_upload;
 } mi_osqp_stats;
 

@@ -50,7 +50,7 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_int64) for k in
                 ("n", "m", "N", "batch", "tile", "n_tiles", "nnz_P_triu", "nnz_A", "nnz_KKT", "nnz_L",
                  "n_supernodes", "n_blocks", "fwd_levels", "bwd_levels", "fwd_slots", "bwd_slots",
-                 "chk_slots", "lds_bytes", "threads_per_block")] + \
+                 "chk_slots", "lds_bytes", "threads_per_block", "dense_tail_rows", "dense_tail_slots")] + \
                [(k, C.c_double) for k in ("setup_seconds_host", "setup_seconds_factor", "setup_seconds_upload")]
 
     def as_dict(self):

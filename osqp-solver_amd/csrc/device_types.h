@@ -15,6 +15,14 @@ struct SchedDev {
   uint32_t n_steps, n_slots;
 };
 
+// device view of host_core.hpp DenseTail (k == 0: none)
+struct DenseTailDev {
+  int s, k, n_phases;
+  uint32_t n_steps;
+  const uint32_t *task;                             // 4 words per task
+  const uint32_t *wave_task, *wave_step, *tail_bar;
+};
+
 // per-QP double scalars, laid out [tile][DS_COUNT][BT]
 enum { DS_C = 0, DS_CINV, DS_RHO, DS_RHO_EST, DS_PRI_RES, DS_DUA_RES, DS_OBJ, DS_COUNT };
 // per-QP int scalars, laid out [tile][IS_COUNT][BT]
@@ -27,6 +35,8 @@ struct KernelArgs {
   const uint32_t *xloc;                 // permuted row -> position of its forward result / backward input (host_core.hpp Analysis::xloc)
   // tile-interleaved value arrays: [tile][len][BT]
   const double *fwd_val, *bwd_val, *chk_val, *dinv;
+  DenseTailDev dt;
+  const double *dt_val;                 // per QP: the stream of the inverted Schur complement ([slot][dt.n_steps * 64])
   double *x, *z, *y;
   const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
   double *dx, *dy, *out1, *out2, *dscal;
@@ -58,7 +68,21 @@ struct FactorArgs {
   const int *work;    // non-null: work list of the slots (tile * BT + b) to refactor, packed BT per work tile, -1 = none;
                       // null: every slot of the batch (force_all) / the slots whose IS_NEED_REFACTOR flag is set
   double sigma;
+  int dt_k;           // rows of the dense tail: their pivots are counted by dense_inverse_kernel, which then checks the inertia
 };
+
+// inversion of the dense tail's Schur complement (one workgroup per refactored QP, after factor_kernel)
+struct DenseInvArgs {
+  int n, N, s, k, kbt, home_bt;
+  uint32_t storage, n_slots;
+  const int *work;              // slot of every (work tile, lane class), -1 = none
+  const uint32_t *sblk;         // k x k column-major (lower): block-storage position of S[i, j]
+  const int32_t *src;           // per stream slot: position in the dense k x k array, MI_SRC_ZERO = 0
+  const double *Lblk;
+  double *Sd, *dt_val, *dinv;
+  int *npos, *iscal;
+};
+hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, hipStream_t st);
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
 

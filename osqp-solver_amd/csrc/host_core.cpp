@@ -438,12 +438,17 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
   std::vector<int> chunk_of(N);
   for (int c = 0; c < nch; c++) for (int j = an.chunk_start[c]; j < an.chunk_start[c + 1]; j++) chunk_of[j] = c;
   // inverted diagonal blocks and the second vector position of the rows of multi-row chunks
+  // Dense tail (host_core.hpp DenseTail): the rows from ts on keep their couplings to the columns before ts
+  // (phase A of the forward sweep, gathers of the backward sweep) and nothing else - no in-chunk triangle, no second
+  // vector position, no couplings among themselves: x_tail = S^-1 t_tail happens between the two sweeps.
+  const int ts = an.dt.k ? an.dt.s : N;
   an.inv_off.assign(nch, -1); an.n_inv = 0;
   an.xloc.resize(N); an.Next = N;
   for (int c = 0; c < nch; c++) {
     int c0 = an.chunk_start[c], r = an.chunk_start[c + 1] - c0;
-    if (r >= 2) { an.inv_off[c] = an.n_inv; an.n_inv += r * (r - 1) / 2; }
-    for (int i = 0; i < r; i++) an.xloc[c0 + i] = r >= 2 ? an.Next++ : c0 + i;
+    const bool multi = r >= 2 && c0 < ts;
+    if (multi) { an.inv_off[c] = an.n_inv; an.n_inv += r * (r - 1) / 2; }
+    for (int i = 0; i < r; i++) an.xloc[c0 + i] = multi ? an.Next++ : c0 + i;
   }
   // ---- forward: rows ascending, sources are columns j < row.  Row i of a chunk: phase A subtracts the
   // couplings to earlier chunks in place (position i); phase B stores inv(L_cc) t at position xloc[i],
@@ -454,7 +459,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
     for (int c = 0; c < nch; c++) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], L = 0;
       for (int i = c0; i < c1; i++)
-        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0) L = std::max(L, lev[chunk_of[j]] + 1); }
+        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0 && j < ts) L = std::max(L, lev[chunk_of[j]] + 1); }
       lev[c] = L; maxlev = std::max(maxlev, L);
     }
     an.chunk_lev = lev;
@@ -465,10 +470,10 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
         RowWork rw; rw.row = (uint32_t)i;
         for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) {
           int j = an.Rj[t];
-          if (j < c0) rw.ent.push_back({(uint32_t)an.xloc[j], an.Rpos[t]});
+          if (j < c0 && j < ts) rw.ent.push_back({(uint32_t)an.xloc[j], an.Rpos[t]});
         }
         if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
-        if (r >= 2) {
+        if (r >= 2 && c0 < ts) {
           RowWork rb; rb.row = (uint32_t)an.xloc[i];
           for (int k = c0; k < i; k++) rb.ent.push_back({(uint32_t)k, an.inv_index(c, i - c0, k - c0)});
           rb.ent.push_back({(uint32_t)i, MI_SRC_ONE});
@@ -485,6 +490,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
     int maxlev = 0;
     for (int c = nch - 1; c >= 0; c--) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], L = 0;
+      if (c0 >= ts) { lev[c] = -1; continue; }             // tail rows are final before the sweep starts
       for (int col = c0; col < c1; col++)
         for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) { int j = an.Li[p]; if (j >= c1) L = std::max(L, lev[chunk_of[j]] + 1); }
       lev[c] = L; maxlev = std::max(maxlev, L);
@@ -492,6 +498,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
     std::vector<LevelWork> lw(maxlev + 1);
     for (int c = nch - 1; c >= 0; c--) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
+      if (c0 >= ts) continue;
       for (int col = c1 - 1; col >= c0; col--) {
         RowWork rw; rw.row = (uint32_t)an.xloc[col];
         for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
@@ -535,6 +542,104 @@ static void build_chk_schedule(Analysis &an, int nw, int bt) {
   pack_schedule(lw, an.chk, nw, bt, false);
 }
 
+
+// ------------------------------------------------ dense tail (host_core.hpp DenseTail)
+
+static void build_dense_tail(Analysis &an, int nw) {
+  DenseTail &dt = an.dt;
+  if (!dt.k) return;
+  const int k = dt.k, nb = k / 64;
+  dt.nb = nb; dt.nw = nw;
+  struct T { int I, J; uint32_t flags; };
+  std::vector<std::vector<T>> phases;
+  {
+    std::vector<T> p0;
+    for (int J = 0; J < nb; J++) p0.push_back({J, J, DT_DIAG});
+    phases.push_back(std::move(p0));
+  }
+  // shift p pairs with shift nb - p: the first group adds its row sums to y_r and its column sums to y_c, the second
+  // the other way round, which keeps the (vector, 64-row part) targets of one phase disjoint
+  for (int p = 1; 2 * p <= nb; p++) {
+    std::vector<T> ph;
+    for (int J = 0; J + p < nb; J++) ph.push_back({J + p, J, 0u});
+    if (2 * p != nb) for (int J = 0; J < p; J++) ph.push_back({J + nb - p, J, DT_SWAP});
+    if (!ph.empty()) phases.push_back(std::move(ph));
+  }
+  dt.n_phases = (int)phases.size();
+  dt.task.clear(); dt.src.clear();
+  dt.wave_task.assign(nw + 1, 0u); dt.wave_step.assign(nw + 1, 0u); dt.tail_bar.assign(nw, 0u);
+  dt.n_steps = 0;
+  for (int w = 0; w < nw; w++) {
+    dt.wave_task[w] = (uint32_t)(dt.task.size() / 4); dt.wave_step[w] = dt.n_steps;
+    int last_phase = 0;
+    for (int ph = 0; ph < dt.n_phases; ph++) {
+      const std::vector<T> &v = phases[ph];
+      bool first = true;
+      for (size_t t = 0; t < v.size(); t++) {
+        if ((int)((t + (size_t)ph) % (size_t)nw) != w) continue;       // round robin, rotated per phase
+        const bool diag = v[t].flags & DT_DIAG;
+        const uint32_t nsteps = diag ? 32u : 64u, s0 = diag ? 1u : 0u;
+        uint32_t nbar = 0;
+        if (first) { nbar = (uint32_t)(ph - last_phase); last_phase = ph; first = false; }
+        dt.task.insert(dt.task.end(), {(uint32_t)v[t].I * 64u, (uint32_t)v[t].J * 64u, v[t].flags | (nbar << 8), nsteps});
+        for (uint32_t q = 0; q < nsteps; q++)
+          for (uint32_t ln = 0; ln < 64; ln++) {
+            const uint32_t sh = s0 + q;
+            int i = v[t].I * 64 + (int)((ln + sh) % 64u), j = v[t].J * 64 + (int)ln;
+            int32_t src;
+            if (diag && sh == 32u && ln >= 32u) src = MI_SRC_ZERO;      // the pairs at distance 32 appear twice
+            else { if (i < j) std::swap(i, j); src = j * k + i; }
+            dt.src.push_back(src);
+          }
+        dt.n_steps += nsteps;
+      }
+    }
+    dt.tail_bar[w] = (uint32_t)(dt.n_phases - last_phase);
+  }
+  dt.wave_task[nw] = (uint32_t)(dt.task.size() / 4); dt.wave_step[nw] = dt.n_steps;
+}
+
+// The product exactly as the device evaluates it: per task 64 column sums that stay in their lane, 64 row sums that
+// rotate; M: k x k column-major (lower triangle read), mdiag: diagonal, xt: t in, x out.
+bool replay_dense_tail(const DenseTail &dt, const double *M, const double *mdiag, double *xt) {
+  const int k = dt.k, nb = dt.nb;
+  std::vector<double> yr(k), yc(k, 0.0);
+  for (int i = 0; i < k; i++) yr[i] = mdiag[i] * xt[i];
+  bool ok = true;
+  std::vector<int> touched_r(nb), touched_c(nb);
+  std::vector<uint32_t> pos(dt.nw), epoch(dt.nw, 0u), slot(dt.nw);
+  for (int w = 0; w < dt.nw; w++) { pos[w] = dt.wave_task[w]; slot[w] = dt.wave_step[w] * 64u; }
+  for (int cur = 0; cur < dt.n_phases; cur++) {
+    std::fill(touched_r.begin(), touched_r.end(), 0); std::fill(touched_c.begin(), touched_c.end(), 0);
+    for (int w = 0; w < dt.nw; w++)
+      while (pos[w] < dt.wave_task[w + 1]) {
+        const uint32_t *t = &dt.task[4 * (size_t)pos[w]];
+        const uint32_t nbar = t[2] >> 8, flags = t[2] & 255u, nsteps = t[3];
+        if ((int)(epoch[w] + nbar) > cur) break;
+        epoch[w] += nbar;
+        const uint32_t I0 = t[0], J0 = t[1], s0 = (flags & DT_DIAG) ? 1u : 0u;
+        double accr[64] = {0.0}, accc[64] = {0.0};      // accr indexed by the row inside the block
+        for (uint32_t q = 0; q < nsteps; q++)
+          for (uint32_t ln = 0; ln < 64; ln++) {
+            const int32_t sc = dt.src[slot[w] + q * 64u + ln];
+            const double v = sc == MI_SRC_ZERO ? 0.0 : M[sc];
+            const uint32_t il = (ln + s0 + q) % 64u;
+            accc[ln] = std::fma(v, xt[I0 + il], accc[ln]);
+            accr[il] = std::fma(v, xt[J0 + ln], accr[il]);
+          }
+        slot[w] += nsteps * 64u;
+        std::vector<double> &rv = (flags & DT_SWAP) ? yc : yr, &cv = (flags & DT_SWAP) ? yr : yc;
+        std::vector<int> &rt = (flags & DT_SWAP) ? touched_c : touched_r, &ct = (flags & DT_SWAP) ? touched_r : touched_c;
+        if (rt[I0 / 64]++ || ct[J0 / 64]++) ok = false;
+        for (uint32_t ln = 0; ln < 64; ln++) { rv[I0 + ln] += accr[ln]; cv[J0 + ln] += accc[ln]; }
+        pos[w]++;
+      }
+  }
+  for (int w = 0; w < dt.nw; w++) if (pos[w] != dt.wave_task[w + 1] || epoch[w] + dt.tail_bar[w] != (uint32_t)dt.n_phases) ok = false;
+  for (int i = 0; i < k; i++) xt[i] = yr[i] + yc[i];
+  return ok;
+}
+
 // ------------------------------------------------ block factor (device refactor)
 
 static void build_block_factor(Analysis &an) {
@@ -548,9 +653,15 @@ static void build_block_factor(Analysis &an) {
   std::vector<std::vector<std::pair<int, uint32_t>>> colblk(nch);   // (I, block id)
   std::vector<std::vector<std::pair<int, uint32_t>>> rowlist(nch);  // per row chunk: (K, block id) with K < I
   std::vector<int> mark(nch, -1);
+  // dense tail: its chunk columns (16 wide each) hold the Schur complement S instead of L - every block (I >= J) of
+  // the tail exists, receives the updates of the columns before the tail and is neither factorised nor a source
+  const int ts = an.dt.k ? an.dt.s : N;
+  const int ct0 = an.dt.k ? chunk_of[ts] : nch;            // first tail chunk
   for (int J = 0; J < nch; J++) {
     std::vector<int> rows{J};
     mark[J] = J;
+    if (J >= ct0) { for (int I = J + 1; I < nch; I++) rows.push_back(I); }
+    else
     for (int col = an.chunk_start[J]; col < an.chunk_start[J + 1]; col++)
       for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
         int I = chunk_of[an.Li[p]];
@@ -599,14 +710,14 @@ static void build_block_factor(Analysis &an) {
       for (const auto &[I, id] : colblk[J]) {
         std::vector<std::pair<uint32_t, uint32_t>> tl;
         if (I == J) {
-          for (const auto &[K, bid] : rj) tl.push_back({bid, bid});
+          for (const auto &[K, bid] : rj) if (K < ct0) tl.push_back({bid, bid});
         } else {
           const auto &ri = rowlist[I];
           size_t a = 0, b = 0;
           while (a < ri.size() && b < rj.size()) {
             if (ri[a].first < rj[b].first) a++;
             else if (ri[a].first > rj[b].first) b++;
-            else { tl.push_back({ri[a].second, rj[b].second}); a++; b++; }
+            else { if (ri[a].first < ct0) tl.push_back({ri[a].second, rj[b].second}); a++; b++; }
           }
         }
         std::stable_partition(tl.begin(), tl.end(), [&](const std::pair<uint32_t, uint32_t> &t) { return width_of(t.first) == 1; });
@@ -650,6 +761,7 @@ static void build_block_factor(Analysis &an) {
     }
     for (int J : cols_of_level[L])
       for (const auto &[I, id] : colblk[J]) {
+        if (J >= ct0) continue;
         if (I == J) bf.dtask.push_back(id);
         else bf.ttask.insert(bf.ttask.end(), {id, colblk[J][0].second});
       }
@@ -680,7 +792,7 @@ static void build_block_factor(Analysis &an) {
   for (int j = 0; j < N; j++) for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) bf.lpos[p] = (int32_t)pos_of(an.Li[p], j);
   for (int c = 0; c < nch; c++) {
     const int c0 = an.chunk_start[c], r = cw(c);
-    if (r < 2) continue;
+    if (an.inv_off[c] < 0) continue;
     const uint32_t id = find_blk(c, c), off = bf.blk[4 * id];
     for (int k = 0; k < r; k++) for (int i = k + 1; i < r; i++) bf.lpos[an.inv_index(c, i, k)] = (int32_t)(off + (uint32_t)i * r + (uint32_t)k);
     (void)c0;
@@ -691,12 +803,17 @@ static void build_block_factor(Analysis &an) {
   };
   compose(an.fwd, an.fwd_srcblk);
   compose(an.bwd, an.bwd_srcblk);
+  if (an.dt.k) {
+    const int k = an.dt.k;
+    an.dt.sblk.assign((size_t)k * k, 0u);
+    for (int j = 0; j < k; j++) for (int i = j; i < k; i++) an.dt.sblk[(size_t)j * k + i] = pos_of(ts + i, ts + j);
+  }
 }
 
 // --------------------------------------------------------------------- analyze
 
 int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows) {
+            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows, int dense_tail_max) {
   if (nwaves < 1 || nwaves > 16 || (bt != 1 && bt != 2 && bt != 4)) return MI_OSQP_ERR_INVALID_SETTINGS;
   if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
   int n = (int)n64, m = (int)m64, N = n + m;
@@ -776,6 +893,27 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
       for (int j = 0; j < N; j++)
         for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int q = fill[an.Li[p]]++; an.Rj[q] = j; an.Rpos[q] = p; }
     }
+    // ---- dense tail (host_core.hpp DenseTail): the last k rows (k a multiple of 64) whose triangle of L would cost
+    // more bytes per solve (read twice) than the k^2/2 values of the inverted Schur complement (read once); taken
+    // when it saves at least a tenth of the factor stream.  MI_OSQP_DENSE_TAIL = 0: never, = k: exactly k rows.
+    an.dt = DenseTail();
+    int64_t tail_nnz_used = 0;
+    {
+      const char *e = getenv("MI_OSQP_DENSE_TAIL");
+      const int forced = e ? atoi(e) : -1;
+      const int kmax = std::min({forced == 0 ? 0 : dense_tail_max, N - 1, max_extra_rows / 2});
+      int64_t tail_nnz = 0, best_gain = 0;
+      int best_k = 0;
+      for (int k = 1; k <= kmax; k++) {
+        tail_nnz += (int64_t)cols[N - k].size();
+        if (k % 64) continue;
+        const int64_t gain = 2 * tail_nnz - (int64_t)k * k / 2 - k;
+        if (forced > 0 ? k == forced / 64 * 64 : gain > best_gain) { best_gain = gain; best_k = k; tail_nnz_used = tail_nnz; }
+      }
+      if (best_k && (forced > 0 || best_gain * 10 >= 2 * (int64_t)an.Lp[N])) { an.dt.k = best_k; an.dt.s = N - best_k; }
+      else tail_nnz_used = 0;
+    }
+    const int ts = an.dt.k ? an.dt.s : N;
     // fundamental supernodes: j+1 joins j when parent(j)=j+1 and |col j| = |col j+1| + 1
     an.sn_start.clear(); an.sn_start.push_back(0);
     for (int j = 0; j + 1 < N; j++) {
@@ -787,14 +925,17 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     // vector (phase B reads t and writes x); when the budget of extra positions (LDS capacity / 16-bit
     // indices) is used up, the remaining supernodes are cut into one-row chunks (more levels, no phase B).
     an.chunk_start.clear();
-    int extra_left = max_extra_rows;
-    for (size_t s = 0; s + 1 < an.sn_start.size(); s++)
-      for (int c = an.sn_start[s]; c < an.sn_start[s + 1]; c += kChunk) {
-        const int r = std::min(kChunk, an.sn_start[s + 1] - c);
+    int extra_left = max_extra_rows - 2 * an.dt.k;           // the dense tail keeps two accumulation vectors next to the solve vector
+    for (size_t s = 0; s + 1 < an.sn_start.size() && an.sn_start[s] < ts; s++) {
+      const int send = std::min(an.sn_start[s + 1], ts);     // chunks never straddle the start of the dense tail
+      for (int c = an.sn_start[s]; c < send; c += kChunk) {
+        const int r = std::min(kChunk, send - c);
         if (r >= 2 && r > extra_left) { for (int j = c; j < c + r; j++) an.chunk_start.push_back(j); continue; }
         if (r >= 2) extra_left -= r;
         an.chunk_start.push_back(c);
       }
+    }
+    for (int c = ts; c < N; c += kChunk) an.chunk_start.push_back(c);     // the tail: 16 x 16 tiles of the Schur complement
     an.chunk_start.push_back(N);
     // forward chunk levels (the backward sweep has the same depth)
     int nch = (int)an.chunk_start.size() - 1, depth = 0;
@@ -803,15 +944,16 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     for (int c = 0; c < nch; c++) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], L = 0;
       for (int i = c0; i < c1; i++)
-        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0) L = std::max(L, lev[chunk_of[j]] + 1); }
+        for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) { int j = an.Rj[t]; if (j < c0 && j < ts) L = std::max(L, lev[chunk_of[j]] + 1); }
       lev[c] = L; depth = std::max(depth, L + 1);
     }
     // phases of one sweep: one A phase per level + one B phase where the level has multi-row chunks
     std::vector<int> blocks_at(depth, 0);
-    for (int c = 0; c < nch; c++) if (an.chunk_start[c + 1] - an.chunk_start[c] >= 2) blocks_at[lev[c]]++;
+    for (int c = 0; c < nch; c++) if (an.chunk_start[c + 1] - an.chunk_start[c] >= 2 && an.chunk_start[c] < ts) blocks_at[lev[c]]++;
     int phases = depth;
     for (int L = 0; L < depth; L++) phases += blocks_at[L] ? 1 : 0;
-    cost = 2.0 * phases * 0.4e-6 + 2.0 * 8.0 * bt * 1.15 * (double)an.Lp[N] / 40e9;
+    const double stream = 2.0 * (double)(an.Lp[N] - tail_nnz_used) + 0.5 * (double)an.dt.k * an.dt.k;   // values read per solve
+    cost = (2.0 * phases + (an.dt.k ? an.dt.k / 128 + 3 : 0)) * 0.4e-6 + 8.0 * bt * 1.15 * stream / 40e9;
   };
   {
     std::vector<int> p_md, p_nd;
@@ -829,6 +971,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   }
   build_tri_schedules(an, nwaves, bt);
   build_chk_schedule(an, nwaves, bt);
+  build_dense_tail(an, nwaves);
   build_block_factor(an);
   // A wave that passes fewer barriers than the others would hang its workgroup (and the GPU): re-count.
   for (const Schedule *sc : {&an.fwd, &an.bwd, &an.chk})
@@ -984,7 +1127,7 @@ static void invert_diag_blocks(const Analysis &an, double *Lx) {
   double Lc[kChunk][kChunk], V[kChunk];
   for (int c = 0; c < nch; c++) {
     const int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
-    if (r < 2) continue;
+    if (an.inv_off[c] < 0) continue;
     for (int i = 0; i < r; i++) for (int k = 0; k < r; k++) Lc[i][k] = 0.0;
     for (int j = c0; j < c1; j++)
       for (int p = an.Lp[j]; p < an.Lp[j + 1] && an.Li[p] < c1; p++) Lc[an.Li[p] - c0][j - c0] = Lx[p];
@@ -1029,6 +1172,28 @@ int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector
     for (int p = an.Lp[j]; p < an.Lp[j + 1]; p++) { int i = an.Li[p]; qp.Lx[p] = w[i] * dinv; w[i] = 0.0; }
   }
   invert_diag_blocks(an, qp.Lx.data());
+  // dense tail reference: M = S^-1 = L22^-T D2^-1 L22^-1 from the complete factor (W = L22^-1 by forward substitution)
+  qp.Minv.clear();
+  if (an.dt.k) {
+    const int k = an.dt.k, ts = an.dt.s;
+    std::vector<double> W((size_t)k * k, 0.0);           // column-major, unit lower triangular
+    for (int c = 0; c < k; c++) {
+      double *wc = &W[(size_t)c * k];
+      wc[c] = 1.0;
+      for (int j = c; j < k; j++) {                      // column-oriented forward substitution on e_c
+        const double v = wc[j];
+        if (v == 0.0) continue;
+        for (int p = an.Lp[ts + j]; p < an.Lp[ts + j + 1]; p++) wc[an.Li[p] - ts] -= qp.Lx[p] * v;
+      }
+    }
+    qp.Minv.assign((size_t)k * k, 0.0);
+    for (int a = 0; a < k; a++)
+      for (int b = a; b < k; b++) {
+        double sum = 0.0;
+        for (int r = b; r < k; r++) sum += W[(size_t)a * k + r] * qp.Dlinv[ts + r] * W[(size_t)b * k + r];
+        qp.Minv[(size_t)a * k + b] = qp.Minv[(size_t)b * k + a] = sum;
+      }
+  }
   return positive == n ? MI_OSQP_OK : MI_OSQP_ERR_NONCONVEX;
 }
 
@@ -1102,7 +1267,13 @@ bool replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs
   std::vector<double> xs(an.Next, 0.0);
   for (int k = 0; k < N; k++) xs[k] = rhs[an.perm[k]];
   bool ok = replay(an.fwd, qp.Lx.data(), xs.data(), xs.size(), true, nullptr);
-  for (int k = 0; k < N; k++) xs[an.xloc[k]] *= qp.Dlinv[k];
+  const int ts = an.dt.k ? an.dt.s : N;
+  for (int k = 0; k < ts; k++) xs[an.xloc[k]] *= qp.Dlinv[k];
+  if (an.dt.k) {
+    std::vector<double> md(an.dt.k);
+    for (int i = 0; i < an.dt.k; i++) md[i] = qp.Minv[(size_t)i * an.dt.k + i];
+    ok = replay_dense_tail(an.dt, qp.Minv.data(), md.data(), xs.data() + ts) && ok;
+  }
   ok = replay(an.bwd, qp.Lx.data(), xs.data(), xs.size(), true, nullptr) && ok;
   for (int k = 0; k < N; k++) sol[an.perm[k]] = xs[k];
   return ok;
@@ -1179,6 +1350,51 @@ int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric 
   out.Lx.resize(an.nnzLx()); out.Dl = D; out.Dlinv.resize(N);
   for (int p = 0; p < an.nnzLx(); p++) out.Lx[p] = S[bf.lpos[p]];
   for (int j = 0; j < N; j++) out.Dlinv[j] = 1.0 / D[j];
+  out.Minv.clear();
+  if (an.dt.k) {
+    // the tail blocks now hold the Schur complement; invert it the way dense_inverse_kernel does: symmetric sweep with
+    // 16 x 16 pivot tiles  (P = inv(A_pp); G = A_:p P; A -= G A_p:; A_:p = G; A_pp = -P;  result = -inv(S))
+    const int k = an.dt.k;
+    std::vector<double> A((size_t)k * k);
+    for (int j = 0; j < k; j++) for (int i = j; i < k; i++) A[(size_t)j * k + i] = A[(size_t)i * k + j] = S[an.dt.sblk[(size_t)j * k + i]];
+    std::vector<double> G((size_t)k * 16), C((size_t)k * 16);
+    for (int p0 = 0; p0 < k; p0 += 16) {
+      double T[16][16];
+      for (int a = 0; a < 16; a++) for (int b = 0; b < 16; b++) T[a][b] = A[(size_t)(p0 + b) * k + p0 + a];
+      for (int kk = 0; kk < 16; kk++) {                 // scalar sweep of the pivot tile: T <- -inv(T); its pivots are those of LDL'
+        const double d = T[kk][kk];
+        if (d == 0.0) return MI_OSQP_ERR_NONCONVEX;
+        if (d > 0.0) positive++;
+        const double di = 1.0 / d;
+        for (int a = 0; a < 16; a++) for (int b = 0; b < 16; b++) if (a != kk && b != kk) T[a][b] -= T[a][kk] * di * T[kk][b];
+        for (int a = 0; a < 16; a++) if (a != kk) { T[a][kk] *= di; T[kk][a] = T[a][kk]; }
+        T[kk][kk] = -di;
+      }
+      for (int r = 0; r < k; r++)
+        for (int c = 0; c < 16; c++) {
+          const bool piv = r >= p0 && r < p0 + 16;
+          C[(size_t)c * k + r] = piv ? 0.0 : A[(size_t)(p0 + c) * k + r];
+        }
+      for (int r = 0; r < k; r++)
+        for (int c = 0; c < 16; c++) {
+          double g = 0.0;
+          for (int q = 0; q < 16; q++) g = std::fma(C[(size_t)q * k + r], -T[q][c], g);      // P = -T
+          G[(size_t)c * k + r] = g;
+        }
+      for (int j = 0; j < k; j++) for (int i = 0; i < k; i++) {
+        double acc = A[(size_t)j * k + i];
+        for (int q = 0; q < 16; q++) acc = std::fma(-G[(size_t)q * k + i], C[(size_t)q * k + j], acc);
+        A[(size_t)j * k + i] = acc;
+      }
+      for (int r = 0; r < k; r++) {
+        if (r >= p0 && r < p0 + 16) continue;
+        for (int c = 0; c < 16; c++) A[(size_t)(p0 + c) * k + r] = A[(size_t)r * k + p0 + c] = G[(size_t)c * k + r];
+      }
+      for (int a = 0; a < 16; a++) for (int b = 0; b < 16; b++) A[(size_t)(p0 + b) * k + p0 + a] = T[a][b];
+    }
+    out.Minv.resize((size_t)k * k);
+    for (size_t e = 0; e < A.size(); e++) out.Minv[e] = -A[e];
+  }
   return positive == n ? MI_OSQP_OK : MI_OSQP_ERR_NONCONVEX;
 }
 

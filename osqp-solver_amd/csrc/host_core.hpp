@@ -96,6 +96,34 @@ struct BlockFactor {
 };
 enum { ASM_P = 0, ASM_P_SIGMA = 1, ASM_SIGMA = 2, ASM_A = 3, ASM_NEG_RHOINV = 4 };
 
+// Dense tail.  With a fill-reducing ordering of a KKT matrix whose graph is expander-like (random A) almost all
+// of nnz(L) sits in one dense trailing triangle.  For the last k rows (k a multiple of 64, chosen by analyze())
+// the factorisation then stops at the Schur complement S (k x k, dense, symmetric) and the solve applies
+// M = S^-1 as ONE symmetric product between the forward and the backward sweep:
+//     x_tail = M t_tail        instead of     L22 D2 L22' x_tail = t_tail   (two dependent triangular sweeps)
+// M is streamed once per solve (k^2/2 values, every value used for row i AND for row j) where L22 was streamed
+// twice (k^2 values), and the ~k/16 dependent levels of the trailing triangle become a handful of phases.
+//
+// Layout of the product: M is cut into 64 x 64 blocks (I >= J).  A wave owns a block for 64 steps; at step q lane l
+// holds M[I0 + (l + q) % 64, J0 + l] ("circulant" order): the column partial sums stay in the lane, the row
+// partial sums and the t values of the rows travel one lane per step (DPP wave rotate), so a block costs no LDS
+// traffic until its two 64-vectors of partial sums are added to y.  Diagonal blocks use steps 1..32 only (each
+// unordered pair once; the diagonal itself is a separate vector).  Blocks of one phase touch disjoint parts of
+// the two accumulation vectors y_r / y_c (block (I, J): rows of I in y_r, rows of J in y_c, or swapped), phases
+// are separated by workgroup barriers, x_tail = y_r + y_c.
+struct DenseTail {
+  int s = 0, k = 0, nb = 0;          // first permuted row, rows (multiple of 64; 0 = no dense tail), 64-row panels
+  int nw = 0, n_phases = 0;
+  uint32_t n_steps = 0;              // wave-steps of the value stream (64 slots each), wave-major
+  std::vector<uint32_t> task;        // 4/task: I0, J0 (tail-local), flags (bit 0 diagonal block, bit 1 swap y_r / y_c) | barriers before << 8, steps
+  std::vector<uint32_t> wave_task;   // nw + 1: task range of every wave
+  std::vector<uint32_t> wave_step;   // nw + 1: stream range of every wave
+  std::vector<uint32_t> tail_bar;    // nw: barriers owed after the last task (every wave passes n_phases)
+  std::vector<int32_t> src;          // per slot: j * k + i (tail-local, i > j: column-major position in the dense k x k array) or MI_SRC_ZERO
+  std::vector<uint32_t> sblk;        // k x k column-major, lower triangle incl. diagonal: block-storage position of S[i, j]
+};
+enum { DT_DIAG = 1, DT_SWAP = 2 };
+
 struct Analysis {
   int n = 0, m = 0, N = 0;
   // triu(P) and A patterns (CSC, 32-bit on our side)
@@ -124,6 +152,7 @@ struct Analysis {
   int Next = 0;
   Schedule fwd, bwd, chk;
   BlockFactor bf;
+  DenseTail dt;                    // dt.k == 0: none
   std::vector<int32_t> fwd_srcblk, bwd_srcblk;   // fwd/bwd slot -> block-storage position (-1 = zero)
   int nnzL() const { return Lp.empty() ? 0 : Lp.back(); }
   int nnzLx() const { return nnzL() + n_inv; }     // length of the canonical factor array QPNumeric::Lx
@@ -140,8 +169,10 @@ struct Analysis {
 // tile (the step streams are laid out per wave; bt only sizes the physical layout).
 // `max_extra_rows` = how many rows may get a second position in the solve vector (Analysis::xloc): the caller's
 // LDS capacity / the 16-bit index range minus n + m; negative = as many as the 16-bit range allows.
+// `dense_tail_max` = largest dense tail (rows) the caller can serve, 0 = never use one.
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1);
+            const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1,
+            int dense_tail_max = 512);
 // physical position (in doubles, inside one tile) of QP b's value of a logical slot
 size_t phys_index(const Schedule &s, uint32_t slot, int b);
 
@@ -154,6 +185,7 @@ struct QPNumeric {
   std::vector<double> rho_vec, rho_inv;
   std::vector<int8_t> ctype;
   std::vector<double> Lx, Dl, Dlinv;              // factor: L in canonical CSC order, then the inverted diagonal blocks (Analysis::nnzLx)
+  std::vector<double> Minv;                       // dense tail: S^-1, k x k column-major (both triangles)
 };
 
 void load_qp(const Analysis &an, const Settings &st, const double *Pval, const double *q,
@@ -169,6 +201,8 @@ void apply_rho(const Analysis &an, QPNumeric &qp, double rho_new);
 int factor_qp(const Analysis &an, const Settings &st, QPNumeric &qp, std::vector<double> &work);
 // reference solve with the canonical factor (natural order in/out)
 void direct_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);
+// x_tail = M t_tail exactly as the device evaluates it (task order, fma order); false: two tasks of a phase collide
+bool replay_dense_tail(const DenseTail &dt, const double *M, const double *mdiag, double *xt);
 // sequential interpreter of the device schedules (tests only; see mi_osqp.h)
 bool replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol);   // false: the streams are not race- / deadlock-free
 // host interpreter of the device block factorisation (tests only): fills Lx/Dlinv

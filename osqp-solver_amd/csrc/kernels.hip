@@ -379,6 +379,7 @@ struct TilePtrs {
   double *dx, *dy, *out1, *out2, *dscal;
   int *iscal;
   ValSrc<BT> vfwd, vbwd, vchk;
+  mi_rsrc vdt[BT];                 // dense tail: the stream of the inverted Schur complement, one per QP
 };
 
 template <int BT>
@@ -405,6 +406,7 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile,
     p.vfwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.fwd_val + slot * a.fwd.n_steps * 64, a.fwd.n_steps * 512u);
     p.vbwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.bwd_val + slot * a.bwd.n_steps * 64, a.bwd.n_steps * 512u);
     p.vchk.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.chk_val + slot * a.chk.n_steps * 64, a.chk.n_steps * 512u);
+    p.vdt[bb] = (off || !a.dt.k) ? make_rsrc(nullptr, 0u) : make_rsrc(a.dt_val + slot * a.dt.n_steps * 64, a.dt.n_steps * 512u);
   }
   return p;
 }
@@ -420,13 +422,108 @@ __device__ __forceinline__ double *solve_vector(const KernelArgs &a, double *sme
   else { scratch = smem + (size_t)a.xs_len * BT; return smem; }
 }
 
+
+// ---- dense tail: x_tail = S^-1 t_tail as one symmetric product (host_core.hpp DenseTail) ------------------
+// lane i reads lane (i + 1) % 64
+__device__ __forceinline__ double rol1_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+#define MI_DT_PF 16
+// Every wave walks its tasks (64 x 64 blocks of M, 64 or 32 steps each) through a 16-step register ring of the
+// value stream; per step and QP: two fmas (column sum stays in the lane, row sum travels) and two rotations.
+// xt = the tail of the solve vector (t, read only), yr / yc = the two accumulation vectors (LDS, [k][BT]).
+template <int BT>
+__device__ __forceinline__ void dense_tail_apply(const DenseTailDev &dt, const mi_rsrc (&vals)[BT], const double *xt,
+                                                 double *yr, double *yc, int wave, int lane) {
+  constexpr int PF = MI_DT_PF;
+  mi_cptr tk = as_const(dt.task);
+  uint32_t t = as_const(dt.wave_task)[wave];
+  const uint32_t begin = as_const(dt.wave_step)[wave], end = as_const(dt.wave_step)[wave + 1];
+  double rv[PF][BT], tj[BT], ti[BT], accr[BT], accc[BT];
+#pragma unroll
+  for (int b = 0; b < BT; b++) {
+    tj[b] = 0.0; ti[b] = 0.0; accr[b] = 0.0; accc[b] = 0.0;
+#pragma unroll
+    for (int st = 0; st < PF; st++) rv[st][b] = 0.0;
+  }
+  uint32_t left = 0, I0 = 0, J0 = 0, flags = 0, nst = 0;
+  for (uint32_t pos = begin; pos < end + PF; pos += PF) {       // this revolution consumes steps [pos - PF, pos) and loads [pos, pos + PF)
+    if (pos > begin && left == 0) {                             // the next task starts (task lengths are multiples of PF)
+      I0 = tk[4 * t]; J0 = tk[4 * t + 1]; nst = tk[4 * t + 3];
+      const uint32_t fl = tk[4 * t + 2];
+      for (uint32_t nb = fl >> 8; nb; nb--) lds_barrier();
+      flags = fl & 255u; left = nst;
+      const uint32_t s0 = flags & 1u;
+      load_bt<BT>(xt + (size_t)(J0 + (uint32_t)lane) * BT, tj);
+      load_bt<BT>(xt + (size_t)(I0 + (((uint32_t)lane + s0) & 63u)) * BT, ti);
+#pragma unroll
+      for (int b = 0; b < BT; b++) { accr[b] = 0.0; accc[b] = 0.0; }
+    }
+#pragma unroll
+    for (int st = 0; st < PF; st++) {
+#pragma unroll
+      for (int b = 0; b < BT; b++) {
+        accc[b] = fma(rv[st][b], ti[b], accc[b]);
+        accr[b] = fma(rv[st][b], tj[b], accr[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < BT; b++) { ti[b] = rol1_d(ti[b]); accr[b] = rol1_d(accr[b]); }
+#pragma unroll
+      for (int b = 0; b < BT; b++) {
+        const mi_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(vals[b], (uint32_t)lane * 8u, (pos + (uint32_t)st) * 512u, 0);
+        rv[st][b] = __hiloint2double((int)w.y, (int)w.x);
+      }
+    }
+    if (pos > begin) {
+      left -= PF;
+      if (left == 0) {                                          // the task is complete: add its two 64-vectors of sums
+        const uint32_t il = ((uint32_t)lane + (flags & 1u) + nst) & 63u;      // the row this lane's travelling sum belongs to
+        double *rvec = (flags & 2u) ? yc : yr, *cvec = (flags & 2u) ? yr : yc;
+#pragma unroll
+        for (int b = 0; b < BT; b++) {
+          rvec[(size_t)(I0 + il) * BT + b] += accr[b];
+          cvec[(size_t)(J0 + (uint32_t)lane) * BT + b] += accc[b];
+        }
+        t++;
+      }
+    }
+  }
+  for (uint32_t nb = as_const(dt.tail_bar)[wave]; nb; nb--) lds_barrier();
+}
+
+// what happens between the forward and the backward sweep: D^-1 on the rows before the dense tail, S^-1 on the tail
+template <int BT, bool GX>
+__device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *dinv, const mi_rsrc (&vdt)[BT], double *xs,
+                                           int tid, int nthr, int wave, int lane) {
+  if (!a.dt.k) {
+    for (int e = tid; e < a.N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= dinv[e];
+    __syncthreads();
+    return;
+  }
+  if constexpr (!GX) {
+    const int s = a.dt.s, k = a.dt.k;
+    double *yr = xs + (size_t)a.xs_len * BT, *yc = yr + (size_t)k * BT;      // overlays the reduction scratch of check_kernel
+    for (int e = tid; e < a.N * BT; e += nthr) {
+      const int i = e / BT;
+      if (i < s) xs[(size_t)a.xloc[i] * BT + e % BT] *= dinv[e];
+      else { yr[e - s * BT] = dinv[e] * xs[e]; yc[e - s * BT] = 0.0; }          // dinv of a tail row = diagonal of S^-1
+    }
+    __syncthreads();
+    dense_tail_apply<BT>(a.dt, vdt, xs + (size_t)s * BT, yr, yc, wave, lane);
+    for (int e = tid; e < k * BT; e += nthr) xs[(size_t)s * BT + e] = yr[e] + yc[e];
+    __syncthreads();
+  }
+}
+
 // K solve on the LDS vector: fwd levels, D^-1, bwd levels (row E7)
 template <int BT, int PF, bool GX>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
                                               int tid, int nthr, int wave, int nw, int lane) {
   run_tri<BT, PF, GX>(a.fwd, p.vfwd, xs, wave, lane);
-  for (int e = tid; e < a.N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= p.dinv[e];
-  __syncthreads();
+  kkt_middle<BT, GX>(a, p.dinv, p.vdt, xs, tid, nthr, wave, lane);
   run_tri<BT, PF, GX>(a.bwd, p.vbwd, xs, wave, lane);
 }
 
@@ -754,7 +851,7 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
   const int N = a.N;
   double *lds_rest;
   double *xs = solve_vector<BT, false>(a, smem, tile, lds_rest);
-  uint32_t *tr = reinterpret_cast<uint32_t *>(xs + (size_t)a.xs_len * BT);
+  uint32_t *tr = reinterpret_cast<uint32_t *>(xs + ((size_t)a.xs_len + 2 * (size_t)a.dt.k) * BT);    // behind the dense tail's accumulation vectors
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   for (uint32_t i = tid; i < words; i += nthr) tr[i] = 0;
   for (int bb = 0; bb < BT; bb++) {
@@ -766,8 +863,7 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
   uint32_t *twf = tr + 4, *twb = twf + 2 * nw;          // per wave: cycles waited for ring slots, real steps
   uint32_t *trf = twb + 2 * nw, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
   run_tri<BT, MI_PFV, false, TRL>(a.fwd, p.vfwd, xs, wave, lane, trf, twf);
-  for (int e = tid; e < N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= p.dinv[e];
-  __syncthreads();
+  kkt_middle<BT, false>(a, p.dinv, p.vdt, xs, tid, nthr, wave, lane);
   run_tri<BT, MI_PFV, false, TRL>(a.bwd, p.vbwd, xs, wave, lane, trb, twb);
   if (tid == 0) { tr[2] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
   for (int bb = 0; bb < BT; bb++) {
@@ -1084,7 +1180,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     if (npos) atomicAdd(&s_npos[b], npos);
     __syncthreads();
     if (tid < BT && slot >= 0) a.npos[slot] = s_npos[b];
-    if (tid < BT && flag && s_npos[b] != a.n && !a.debug_skip) bad_inertia = 1;
+    if (tid < BT && flag && s_npos[b] != a.n && !a.debug_skip && !a.dt_k) bad_inertia = 1;   // (dense tail: dense_inverse_kernel adds its pivots and checks)
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
   if (flag && !(a.debug_skip & 16)) {
@@ -1127,6 +1223,147 @@ hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hi
     case 2: return launch_factor_t<2>(a, tiles, threads, st);
     default: return launch_factor_t<4>(a, tiles, threads, st);
   }
+}
+
+
+// ---- dense tail: M = S^-1 (host_core.hpp DenseTail) ------------------------------------------------------------
+// factor_kernel leaves the Schur complement S of the trailing k rows in the tail blocks of the work tile's block
+// storage.  One workgroup per QP gathers it into a dense column-major array (lower triangle) and inverts it in place
+// with the symmetric sweep operator on 16 x 16 pivot tiles:
+//     P = inv(A_pp);  G = A_:p P;  A_ij -= G_i A_pj (i, j outside p);  A_:p = G;  A_pp = -P        ->  A = -inv(S)
+// (no pivoting, like the LDL' it replaces: the scalar pivots met inside the pivot tiles ARE the pivots of LDL', which
+// is how the inertia check still works).  The panel C = A_:p and G live in LDS ([16][k] each); the trailing update
+// is register-tiled 4 x 4 per thread and runs over the lower triangle in global memory (L2).  The result goes
+// straight into the QP's value stream of the symmetric product (dense_tail_apply) and its diagonal into dinv.
+__global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
+  extern __shared__ double smem[];
+  const int g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = a.work[g];
+  if (slot < 0) return;
+  const int k = a.k, kbt = a.kbt, wt = g / kbt, wb = g % kbt;
+  const size_t hbt = (size_t)a.home_bt, home = (size_t)slot / hbt, hb = (size_t)slot % hbt;
+  auto H = [&](size_t len, size_t i) { return (home * len + i) * hbt + hb; };
+  double *A = a.Sd + (size_t)g * k * k;
+  const double *Lb = a.Lblk + (size_t)wt * a.storage * kbt;
+  double *Ts = smem;                       // [16][17] pivot tile
+  double *Cs = smem + 16 * 17;             // [16][k]: Cs[q * k + r] = A[r, p0 + q]
+  double *Gs = Cs + (size_t)16 * k;        // [16][k]
+  for (int e = tid; e < k * k; e += nthr) {
+    const int j = e / k, i = e % k;
+    A[e] = i >= j ? Lb[(size_t)a.sblk[e] * kbt + wb] : 0.0;       // (the strict upper triangle is only touched inside diagonal 4 x 4 tiles)
+  }
+  __syncthreads();
+  int npos = 0;
+  const int k4 = k / 4;
+  for (int p0 = 0; p0 < k; p0 += 16) {
+    // ---- pivot tile (full symmetric copy) -> LDS, swept by wave 0: Ts <- -inv(Ts)
+    if (tid < 256) {
+      const int r = tid & 15, c = tid >> 4;
+      Ts[r * 17 + c] = r >= c ? A[(size_t)(p0 + c) * k + p0 + r] : A[(size_t)(p0 + r) * k + p0 + c];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int r = lane & 15, c0 = (lane >> 4) * 4;
+      for (int kk = 0; kk < 16; kk++) {
+        const double d = Ts[kk * 17 + kk], di = 1.0 / d, ta = Ts[r * 17 + kk];
+        if (lane == 0 && d > 0.0) npos++;
+        double nv[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) {
+          const int c = c0 + cc;
+          const double tb = Ts[kk * 17 + c];
+          double v = Ts[r * 17 + c];
+          if (r != kk && c != kk) v -= ta * di * tb;
+          else if (r == kk && c == kk) v = -di;
+          else if (c == kk) v = ta * di;
+          else v = tb * di;
+          nv[cc] = v;
+        }
+        wave_sync();
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) Ts[r * 17 + c0 + cc] = nv[cc];
+        wave_sync();
+      }
+    }
+    __syncthreads();
+    // ---- panel: row r of C = A[:, p0 .. p0+15] (zero inside the pivot rows) and of G = C P, P = -Ts
+    double gr[16];
+    const int r = tid;                      // k <= blockDim.x: one row per thread
+    const bool has_row = r < k, piv = r >= p0 && r < p0 + 16;
+    if (has_row) {
+      double cr[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) cr[q] = piv ? 0.0 : (r > p0 ? A[(size_t)(p0 + q) * k + r] : A[(size_t)r * k + p0 + q]);
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        double gsum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) gsum = fma(cr[q], -Ts[q * 17 + c], gsum);
+        gr[c] = gsum;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) { Cs[(size_t)q * k + r] = cr[q]; Gs[(size_t)q * k + r] = gr[q]; }
+    }
+    __syncthreads();
+    // ---- trailing update of the lower triangle outside the pivot rows / columns, 4 x 4 per thread
+    const int pm = p0 / 4;
+    for (int idx = tid; idx < k4 * k4; idx += nthr) {
+      const int mi = idx % k4, mj = idx / k4;
+      if (mi < mj || (mi >= pm && mi < pm + 4) || (mj >= pm && mj < pm + 4)) continue;
+      double acc[4][4];
+      double *dst = A + (size_t)(4 * mj) * k + 4 * mi;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const double2 v0 = *reinterpret_cast<const double2 *>(dst + (size_t)c * k), v1 = *reinterpret_cast<const double2 *>(dst + (size_t)c * k + 2);
+        acc[0][c] = v0.x; acc[1][c] = v0.y; acc[2][c] = v1.x; acc[3][c] = v1.y;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const double2 g0 = *reinterpret_cast<const double2 *>(&Gs[(size_t)q * k + 4 * mi]), g1 = *reinterpret_cast<const double2 *>(&Gs[(size_t)q * k + 4 * mi + 2]);
+        const double2 c0v = *reinterpret_cast<const double2 *>(&Cs[(size_t)q * k + 4 * mj]), c1v = *reinterpret_cast<const double2 *>(&Cs[(size_t)q * k + 4 * mj + 2]);
+        const double gg[4] = {g0.x, g0.y, g1.x, g1.y}, cc[4] = {c0v.x, c0v.y, c1v.x, c1v.y};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int c = 0; c < 4; c++) acc[i][c] = fma(-gg[i], cc[c], acc[i][c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        *reinterpret_cast<double2 *>(dst + (size_t)c * k) = make_double2(acc[0][c], acc[1][c]);
+        *reinterpret_cast<double2 *>(dst + (size_t)c * k + 2) = make_double2(acc[2][c], acc[3][c]);
+      }
+    }
+    // ---- the pivot column takes G, the pivot tile -P
+    if (has_row && !piv) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) { if (r > p0) A[(size_t)(p0 + c) * k + r] = gr[c]; else A[(size_t)r * k + p0 + c] = gr[c]; }
+    }
+    if (tid < 256) {
+      const int rr = tid & 15, c = tid >> 4;
+      if (rr >= c) A[(size_t)(p0 + c) * k + p0 + rr] = Ts[rr * 17 + c];
+    }
+    __syncthreads();
+  }
+  // ---- M = -A into the QP's stream of the symmetric product, its diagonal into dinv
+  {
+    double *dv = a.dt_val + (size_t)slot * a.n_slots;
+    for (uint32_t e = tid; e < a.n_slots; e += nthr) { const int32_t sc = a.src[e]; dv[e] = sc >= 0 ? -A[sc] : 0.0; }
+    for (int i = tid; i < k; i += nthr) a.dinv[H(a.N, (size_t)a.s + i)] = -A[(size_t)i * k + i];
+  }
+  if (tid == 0) {
+    const int total = a.npos[slot] + npos;
+    a.npos[slot] = total;
+    if (total != a.n) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = -1;
+  }
+}
+hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, hipStream_t st) {
+  if (a.k > 512 || (a.k & 63)) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)16 * 17 + (size_t)32 * a.k) * sizeof(double);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(dense_inverse_kernel, dim3(nwork), dim3(512), lds, st, a);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------- layout / upload kernels
@@ -1265,7 +1502,7 @@ hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads,
 hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                             const double *rhs, double *sol, uint32_t *trace, uint32_t words) {
   if (BT != 2 || a.xs_global || threads != 512) return hipErrorInvalidValue;
-  const size_t total = (size_t)a.xs_len * BT * sizeof(double) + (size_t)words * 4;
+  const size_t total = ((size_t)a.xs_len + 2 * (size_t)a.dt.k) * BT * sizeof(double) + (size_t)words * 4;
   if (total > 160 * 1024) return hipErrorInvalidValue;
   (void)lds;
   const bool waits = getenv("MI_OSQP_TRACE_WAITS") != nullptr;     // per-step ring-wait timing (slows every step down)

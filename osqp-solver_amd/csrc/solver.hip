@@ -134,6 +134,10 @@ struct mi_osqp_batch {
   DevBuf<uint32_t> bf_blk, bf_lvl, bf_utask, bf_tri, bf_dtask, bf_ttask, bf_asm_dst, bf_asm_src;
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
+  // dense tail (host_core.hpp DenseTail): task tables, the per-QP stream of S^-1 (+ setup snapshot), dense scratch
+  DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar, dt_sblk;
+  DevBuf<int32_t> dt_src;
+  DevBuf<double> dt_val, dt_val0, dt_Sd;
   bool host_rho_stale = false;
   bool clear_rho_updates = true;          // the next solve starts counting rho updates from 0 (setup / update_* / reset happened)
   int *h_npos = nullptr;
@@ -195,6 +199,12 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
   a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.Next;
+  {
+    const DenseTail &dt = h->an.dt;
+    a.dt.s = dt.s; a.dt.k = dt.k; a.dt.n_phases = dt.n_phases; a.dt.n_steps = dt.n_steps;
+    a.dt.task = h->dt_task.p; a.dt.wave_task = h->dt_wave_task.p; a.dt.wave_step = h->dt_wave_step.p; a.dt.tail_bar = h->dt_tail_bar.p;
+    a.dt_val = h->dt_val.p;
+  }
   const Settings &s = h->st;
   a.sigma = s.sigma; a.alpha = s.alpha; a.eps_abs = s.eps_abs; a.eps_rel = s.eps_rel;
   a.eps_prim_inf = s.eps_prim_inf; a.eps_dual_inf = s.eps_dual_inf; a.rho_tolerance = s.adaptive_rho_tolerance;
@@ -216,7 +226,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.pa_val = h->pa_val.p; a.l = h->l.p; a.u = h->u.p; a.dscal = h->dscal.p;
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
-  a.sigma = h->st.sigma; a.home_bt = h->BT;
+  a.sigma = h->st.sigma; a.home_bt = h->BT; a.dt_k = an.dt.k;
   { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }
   return a;
 }
@@ -316,7 +326,8 @@ static int snapshot(mi_osqp_batch *h) {
   };
   int rc;
   if ((rc = cp(h->fwd_val0, h->fwd_val)) || (rc = cp(h->bwd_val0, h->bwd_val)) || (rc = cp(h->dinv0, h->dinv)) ||
-      (rc = cp(h->rho_vec0, h->rho_vec)) || (rc = cp(h->rho_inv0, h->rho_inv)) || (rc = cp(h->dscal0, h->dscal))) return rc;
+      (rc = cp(h->rho_vec0, h->rho_vec)) || (rc = cp(h->rho_inv0, h->rho_inv)) || (rc = cp(h->dscal0, h->dscal)) ||
+      (rc = cp(h->dt_val0, h->dt_val))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -414,7 +425,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     max_extra = (int)std::min<size_t>((size_t)max_extra, cap_rows - (size_t)(n + m));
   }
   const double ta0 = now_s();
-  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT, max_extra);
+  // dense tail (inverted Schur complement of the trailing rows): needs the LDS vector and <= 512 rows (one row per
+  // thread of dense_inverse_kernel; k^3 flops per refactorisation)
+  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512);
   const double t_analysis = now_s() - ta0;
   if (rc) return rc;
   const Analysis &an = h->an;
@@ -430,7 +443,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
   h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT);
-  h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.Next, BT, h->threads);
+  h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.Next + 2 * an.dt.k, BT, h->threads);
+  if (h->lds > lds_cap) { g_last_error = "internal: LDS budget exceeded"; return MI_OSQP_ERR_ALLOC; }
   // ---- device arrays
   size_t T = (size_t)h->ntiles * BT;
   if ((rc = h->fwd.upload(an.fwd)) || (rc = h->bwd.upload(an.bwd)) || (rc = h->chk.upload(an.chk))) return rc;
@@ -442,6 +456,13 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
   if (h->global_xs) { ALLOC(xs_global, an.Next); }
+  if (an.dt.k) {
+    const DenseTail &dt = an.dt;
+    ALLOC(dt_val, (size_t)dt.n_steps * 64);
+    if ((rc = h->dt_task.upload(dt.task)) || (rc = h->dt_wave_task.upload(dt.wave_task)) || (rc = h->dt_wave_step.upload(dt.wave_step)) ||
+        (rc = h->dt_tail_bar.upload(dt.tail_bar)) || (rc = h->dt_sblk.upload(dt.sblk)) || (rc = h->dt_src.upload(dt.src)) ||
+        (rc = h->dt_Sd.alloc((size_t)dt.k * dt.k * (T + 4)))) return rc;
+  }
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
   {
@@ -522,6 +543,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   s.fwd_levels = an.fwd.n_phases; s.bwd_levels = an.bwd.n_phases;
   s.fwd_slots = (int64_t)an.fwd.phys_steps() * 64; s.bwd_slots = (int64_t)an.bwd.phys_steps() * 64; s.chk_slots = (int64_t)an.chk.phys_steps() * 64;
   s.lds_bytes = (int64_t)h->lds; s.threads_per_block = h->threads;
+  s.dense_tail_rows = an.dt.k; s.dense_tail_slots = (int64_t)an.dt.n_steps * 64;
   s.setup_seconds_host = t1 - t0; s.setup_seconds_factor = t_factor; s.setup_seconds_upload = t_upload;
   if (getenv("MI_OSQP_DEBUG_TIMING"))
     fprintf(stderr, "[mi_osqp] setup B=%d N=%d: analysis+alloc %.1f ms (analysis %.1f), numeric %.1f ms, upload %.1f ms, rest %.1f ms\n", (int)B, an.N,
@@ -550,6 +572,14 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
   HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   fa.work = h->work.p;
   HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
+  if (h->an.dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
+    const DenseTail &dt = h->an.dt;
+    DenseInvArgs da{};
+    da.n = h->an.n; da.N = h->an.N; da.s = dt.s; da.k = dt.k; da.kbt = kbt; da.home_bt = BT;
+    da.storage = h->an.bf.storage; da.n_slots = dt.n_steps * 64u; da.work = h->work.p; da.sblk = h->dt_sblk.p; da.src = h->dt_src.p;
+    da.Lblk = h->Lblk.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
+    HIPCHK(launch_dense_inverse(da, wtiles * kbt, h->stream));
+  }
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int s = 0; s < h->ntiles * BT; s++)
@@ -603,7 +633,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
   std::vector<std::vector<int2>> rounds;
   // compaction (re-pairing the QPs still iterating into fewer tiles) is implemented and tested but OFF by default:
   // since the value streams are per QP, a finished QP costs no bytes anyway, and moving data only breaks even
-  const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr;
+  const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr || h->an.dt.k != 0;      // (and not combined with the dense tail)
   int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
   while (true) {
     int seg_end = (int)S.max_iter;
@@ -835,7 +865,8 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
   };
   int rc;
   if ((rc = cp(h->fwd_val, h->fwd_val0)) || (rc = cp(h->bwd_val, h->bwd_val0)) || (rc = cp(h->dinv, h->dinv0)) ||
-      (rc = cp(h->rho_vec, h->rho_vec0)) || (rc = cp(h->rho_inv, h->rho_inv0)) || (rc = cp(h->dscal, h->dscal0))) return rc;
+      (rc = cp(h->rho_vec, h->rho_vec0)) || (rc = cp(h->rho_inv, h->rho_inv0)) || (rc = cp(h->dscal, h->dscal0)) ||
+      (rc = cp(h->dt_val, h->dt_val0))) return rc;
   if ((rc = reset_solve_state(h, true))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   // the host mirrors of rho follow the snapshot lazily (sync_rho_to_host, only the host update paths need them)
@@ -938,6 +969,11 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
 
 int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
+  if (h->an.dt.k) {        // with a dense tail every refactorisation goes through the work list (factor + dense inverse per QP)
+    std::vector<int> all(h->B);
+    for (int i = 0; i < h->B; i++) all[i] = i;
+    return device_refactor_slots(h, std::move(all));
+  }
   FactorArgs fa = make_factor_args(h, 1);
   HIPCHK(launch_factor(fa, h->BT, h->ntiles, factor_threads(), h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1058,6 +1094,7 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const 
     st->n_supernodes = (int64_t)an.sn_start.size() - 1; st->n_blocks = (int64_t)an.chunk_start.size() - 1;
     st->fwd_levels = an.fwd.n_phases; st->bwd_levels = an.bwd.n_phases;
     st->fwd_slots = (int64_t)an.fwd.phys_steps() * 64; st->bwd_slots = (int64_t)an.bwd.phys_steps() * 64; st->chk_slots = (int64_t)an.chk.phys_steps() * 64;
+    st->dense_tail_rows = an.dt.k; st->dense_tail_slots = (int64_t)an.dt.n_steps * 64;
   }
   return MI_OSQP_OK;
 }
@@ -1079,8 +1116,16 @@ int mi_osqp_debug_host_block_factor(int64_t n, int64_t m, const int64_t *Pp, con
   if ((rc = factor_qp(an, s, Q, w))) return rc;
   if ((rc = replay_block_factor(an, s, Q, R))) return rc;
   double mL = 0.0, sL = 1e-300, mD = 0.0;
-  for (size_t k = 0; k < Q.Lx.size(); k++) { mL = std::max(mL, std::fabs(Q.Lx[k] - R.Lx[k])); sL = std::max(sL, std::fabs(Q.Lx[k])); }
-  for (size_t k = 0; k < Q.Dlinv.size(); k++) mD = std::max(mD, std::fabs(Q.Dlinv[k] - R.Dlinv[k]) / std::fabs(Q.Dlinv[k]));
+  // with a dense tail the device factor holds L only for the columns before it (and S^-1 instead of the rest)
+  const int ts = an.dt.k ? an.dt.s : an.N;
+  for (int k = 0; k < an.Lp[ts]; k++) { mL = std::max(mL, std::fabs(Q.Lx[k] - R.Lx[k])); sL = std::max(sL, std::fabs(Q.Lx[k])); }
+  for (size_t k = (size_t)an.nnzL(); k < Q.Lx.size(); k++) { mL = std::max(mL, std::fabs(Q.Lx[k] - R.Lx[k])); sL = std::max(sL, std::fabs(Q.Lx[k])); }
+  for (int k = 0; k < ts; k++) mD = std::max(mD, std::fabs(Q.Dlinv[k] - R.Dlinv[k]) / std::fabs(Q.Dlinv[k]));
+  if (an.dt.k) {
+    double mM = 0.0, sM = 1e-300;
+    for (size_t k = 0; k < Q.Minv.size(); k++) { mM = std::max(mM, std::fabs(Q.Minv[k] - R.Minv[k])); sM = std::max(sM, std::fabs(Q.Minv[k])); }
+    mL = std::max(mL, mM / sM * sL);
+  }
   if (dL) *dL = mL / sL;
   if (dD) *dD = mD;
   if (counts) {
