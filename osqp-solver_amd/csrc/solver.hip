@@ -582,8 +582,13 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
   }
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (int s = 0; s < h->ntiles * BT; s++)
-    if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
+  for (int s : work)            // (only the listed slots: at setup the flags of padding slots are not initialised yet)
+    if (s >= 0 && h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
+      if (getenv("MI_OSQP_DEBUG_TIMING")) {
+        (void)hipMemcpy(h->h_npos, h->npos.p, (size_t)h->ntiles * BT * sizeof(int), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[mi_osqp] slot %d: %d positive pivots, expected %d\n", s, h->h_npos[s], h->an.n);
+      }
+      if (getenv("MI_OSQP_DEBUG_IGNORE_INERTIA")) continue;
       g_last_error = "the KKT factor lost its inertia"; return MI_OSQP_ERR_NONCONVEX;
     }
   return 0;
