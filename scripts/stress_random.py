@@ -7,11 +7,12 @@ from osqp_solver_amd import problems as PR
 from oracle import oracle as O
 
 ST2EXIT = {1: 0, 2: 3, -3: 1, 3: 4, -4: 2, 4: 5, -2: 6, -7: 9, -10: 10}
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(os.environ.get("SEED", "7")))
 bad = 0
 cases = 0
 for trial in range(int(os.environ.get("TRIALS", "24"))):
-    n = int(rng.integers(3, 220)); mg = int(rng.integers(1, 260)); nnz = int(rng.integers(1, min(n, 12) + 1))
+    NMAX = int(os.environ.get("NMAX", "220"))
+    n = int(rng.integers(3, NMAX)); mg = int(rng.integers(1, NMAX + 40)); nnz = int(rng.integers(1, min(n, 12) + 1))
     B = int(rng.integers(1, 7))
     tile = int(rng.choice([1, 2, 4])); thr = int(rng.choice([128, 256, 512, 1024]))
     if thr == 1024 and tile == 4: thr = 512
@@ -25,6 +26,7 @@ for trial in range(int(os.environ.get("TRIALS", "24"))):
     try:
         s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
         info = s.solve(); x = s.primal()
+        dt_cases = globals().get("dt_cases", 0) + (1 if s.stats()["dense_tail_rows"] else 0)
         # second solve after a bounds change (update path) for half of the trials
         if trial % 2:
             if trial % 4 == 1: s.update_A(pr["Ax"])          # same values: the full QPSolver::update sequence on both sides
@@ -48,5 +50,5 @@ for trial in range(int(os.environ.get("TRIALS", "24"))):
             print("trial", trial, "MISMATCH qp", b, dict(n=n, mg=mg, nnz=nnz, B=B, tile=tile, thr=thr, eps=eps, gx=os.environ.get("MI_OSQP_GLOBAL_XS")),
                   "gpu", info[b].exit_code, info[b].iter, "oracle", ST2EXIT[st], io.iter, "dx", float(np.nanmax(np.abs(x[b] - xo))))
     s.close()
-print(f"{cases} QPs compared, {bad} problems")
+print(f"{cases} QPs compared, {bad} problems, {globals().get('dt_cases', 0)} batches with a dense tail")
 sys.exit(1 if bad else 0)

@@ -9,8 +9,8 @@ python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-34:]) for r in csv.DictReader(open(f)))
-big = [e for e in ev if ("iterate" in e[2] or "factor" in e[2] or "check" in e[2])]
-last = big[-20:]
+big = [e for e in ev if ("iterate" in e[2] or "factor" in e[2] or "check" in e[2] or "dense" in e[2])]
+last = big[-24:]
 for s, e, n in last:
     print(f"{n:36s} {(e - s) / 1e3:9.1f} us")
 PY
