@@ -78,11 +78,13 @@ struct DenseInvArgs {
   const int *work;              // slot of every (work tile, lane class), -1 = none
   const uint32_t *sblk;         // k x k column-major (lower): block-storage position of S[i, j]
   const int32_t *src;           // per stream slot: position in the dense k x k array, MI_SRC_ZERO = 0
+  const uint32_t *micro;        // the 4 x 4 tiles of the lower triangle (row tile | column tile << 16), rows fastest
+  int n_micro;
   const double *Lblk;
   double *Sd, *dt_val, *dinv;
   int *npos, *iscal;
 };
-hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, hipStream_t st);
+hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, int threads, hipStream_t st);
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
 

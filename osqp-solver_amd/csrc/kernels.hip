@@ -1235,7 +1235,8 @@ hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hi
 // is how the inertia check still works).  The panel C = A_:p and G live in LDS ([16][k] each); the trailing update
 // is register-tiled 4 x 4 per thread and runs over the lower triangle in global memory (L2).  The result goes
 // straight into the QP's value stream of the symmetric product (dense_tail_apply) and its diagonal into dinv.
-__global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void dense_inverse_kernel(DenseInvArgs a) {
   extern __shared__ double smem[];
   const int g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1255,7 +1256,6 @@ __global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
   }
   __syncthreads();
   int npos = 0;
-  const int k4 = k / 4;
   for (int p0 = 0; p0 < k; p0 += 16) {
     // ---- pivot tile (full symmetric copy) -> LDS, swept by wave 0: Ts <- -inv(Ts)
     if (tid < 256) {
@@ -1288,11 +1288,10 @@ __global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
     }
     __syncthreads();
     // ---- panel: row r of C = A[:, p0 .. p0+15] (zero inside the pivot rows) and of G = C P, P = -Ts
-    double gr[16];
     const int r = tid;                      // k <= blockDim.x: one row per thread
     const bool has_row = r < k, piv = r >= p0 && r < p0 + 16;
     if (has_row) {
-      double cr[16];
+      double cr[16], gr[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) cr[q] = piv ? 0.0 : (r > p0 ? A[(size_t)(p0 + q) * k + r] : A[(size_t)r * k + p0 + q]);
 #pragma unroll
@@ -1304,20 +1303,31 @@ __global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < 16; q++) { Cs[(size_t)q * k + r] = cr[q]; Gs[(size_t)q * k + r] = gr[q]; }
+      // the pivot column takes G right away: row r of it is read and written by this thread only, and the trailing
+      // update below stays outside the pivot rows / columns
+      if (!piv) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) { if (r > p0) A[(size_t)(p0 + c) * k + r] = gr[c]; else A[(size_t)r * k + p0 + c] = gr[c]; }
+      }
     }
     __syncthreads();
-    // ---- trailing update of the lower triangle outside the pivot rows / columns, 4 x 4 per thread
-    const int pm = p0 / 4;
-    for (int idx = tid; idx < k4 * k4; idx += nthr) {
-      const int mi = idx % k4, mj = idx / k4;
-      if (mi < mj || (mi >= pm && mi < pm + 4) || (mj >= pm && mj < pm + 4)) continue;
-      double acc[4][4];
-      double *dst = A + (size_t)(4 * mj) * k + 4 * mi;
+    // ---- trailing update of the lower triangle outside the pivot rows / columns: 4 x 4 per thread, two tiles in
+    // flight per thread (the loads of both are issued before the fmas of the first)
+    const uint32_t pm = (uint32_t)p0 / 4u;
+    auto tile_of = [&](int t, uint32_t &mi, uint32_t &mj) -> bool {
+      if (t >= a.n_micro) return false;
+      const uint32_t w = a.micro[t];
+      mi = w & 0xFFFFu; mj = w >> 16;
+      return !((mi >= pm && mi < pm + 4u) || (mj >= pm && mj < pm + 4u));
+    };
+    auto load_tile = [&](double *dst, double (&acc)[4][4]) {
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const double2 v0 = *reinterpret_cast<const double2 *>(dst + (size_t)c * k), v1 = *reinterpret_cast<const double2 *>(dst + (size_t)c * k + 2);
         acc[0][c] = v0.x; acc[1][c] = v0.y; acc[2][c] = v1.x; acc[3][c] = v1.y;
       }
+    };
+    auto update_tile = [&](double *dst, uint32_t mi, uint32_t mj, double (&acc)[4][4]) {
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         const double2 g0 = *reinterpret_cast<const double2 *>(&Gs[(size_t)q * k + 4 * mi]), g1 = *reinterpret_cast<const double2 *>(&Gs[(size_t)q * k + 4 * mi + 2]);
@@ -1333,12 +1343,29 @@ __global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
         *reinterpret_cast<double2 *>(dst + (size_t)c * k) = make_double2(acc[0][c], acc[1][c]);
         *reinterpret_cast<double2 *>(dst + (size_t)c * k + 2) = make_double2(acc[2][c], acc[3][c]);
       }
+    };
+    if constexpr (NT > 512) {               // 128 VGPRs: one tile at a time
+      for (int t0 = tid; t0 < a.n_micro; t0 += nthr) {
+        uint32_t mi0 = 0, mj0 = 0;
+        if (!tile_of(t0, mi0, mj0)) continue;
+        double acc0[4][4];
+        double *d0 = A + (size_t)(4 * mj0) * k + 4 * mi0;
+        load_tile(d0, acc0);
+        update_tile(d0, mi0, mj0, acc0);
+      }
+    } else {
+      for (int t0 = tid; t0 < a.n_micro; t0 += 2 * nthr) {
+        uint32_t mi0 = 0, mj0 = 0, mi1 = 0, mj1 = 0;
+        const bool ok0 = tile_of(t0, mi0, mj0), ok1 = tile_of(t0 + nthr, mi1, mj1);
+        double acc0[4][4], acc1[4][4];
+        double *d0 = A + (size_t)(4 * mj0) * k + 4 * mi0, *d1 = A + (size_t)(4 * mj1) * k + 4 * mi1;
+        if (ok0) load_tile(d0, acc0);
+        if (ok1) load_tile(d1, acc1);
+        if (ok0) update_tile(d0, mi0, mj0, acc0);
+        if (ok1) update_tile(d1, mi1, mj1, acc1);
+      }
     }
-    // ---- the pivot column takes G, the pivot tile -P
-    if (has_row && !piv) {
-#pragma unroll
-      for (int c = 0; c < 16; c++) { if (r > p0) A[(size_t)(p0 + c) * k + r] = gr[c]; else A[(size_t)r * k + p0 + c] = gr[c]; }
-    }
+    // ---- the pivot tile takes -P
     if (tid < 256) {
       const int rr = tid & 15, c = tid >> 4;
       if (rr >= c) A[(size_t)(p0 + c) * k + p0 + rr] = Ts[rr * 17 + c];
@@ -1357,12 +1384,13 @@ __global__ __launch_bounds__(512) void dense_inverse_kernel(DenseInvArgs a) {
     if (total != a.n) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = -1;
   }
 }
-hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, hipStream_t st) {
-  if (a.k > 512 || (a.k & 63)) return hipErrorInvalidValue;
+hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, int threads, hipStream_t st) {
+  if (a.k > 512 || (a.k & 63) || threads < a.k || threads > 1024 || (threads & 63)) return hipErrorInvalidValue;
   const size_t lds = ((size_t)16 * 17 + (size_t)32 * a.k) * sizeof(double);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dense_inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto kern = threads > 512 ? &dense_inverse_kernel<1024> : &dense_inverse_kernel<512>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(dense_inverse_kernel, dim3(nwork), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(nwork), dim3(threads), lds, st, a);
   return hipGetLastError();
 }
 

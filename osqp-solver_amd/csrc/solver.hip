@@ -135,7 +135,7 @@ struct mi_osqp_batch {
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
   // dense tail (host_core.hpp DenseTail): task tables, the per-QP stream of S^-1 (+ setup snapshot), dense scratch
-  DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar, dt_sblk;
+  DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar, dt_sblk, dt_micro;
   DevBuf<int32_t> dt_src;
   DevBuf<double> dt_val, dt_val0, dt_Sd;
   bool host_rho_stale = false;
@@ -462,6 +462,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     if ((rc = h->dt_task.upload(dt.task)) || (rc = h->dt_wave_task.upload(dt.wave_task)) || (rc = h->dt_wave_step.upload(dt.wave_step)) ||
         (rc = h->dt_tail_bar.upload(dt.tail_bar)) || (rc = h->dt_sblk.upload(dt.sblk)) || (rc = h->dt_src.upload(dt.src)) ||
         (rc = h->dt_Sd.alloc((size_t)dt.k * dt.k * (T + 4)))) return rc;
+    std::vector<uint32_t> micro;             // 4 x 4 tiles of the lower triangle for dense_inverse_kernel's trailing update
+    for (uint32_t mj = 0; mj < (uint32_t)dt.k / 4; mj++) for (uint32_t mi = mj; mi < (uint32_t)dt.k / 4; mi++) micro.push_back(mi | (mj << 16));
+    if ((rc = h->dt_micro.upload(micro))) return rc;
   }
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
@@ -577,8 +580,13 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
     DenseInvArgs da{};
     da.n = h->an.n; da.N = h->an.N; da.s = dt.s; da.k = dt.k; da.kbt = kbt; da.home_bt = BT;
     da.storage = h->an.bf.storage; da.n_slots = dt.n_steps * 64u; da.work = h->work.p; da.sblk = h->dt_sblk.p; da.src = h->dt_src.p;
+    da.micro = h->dt_micro.p; da.n_micro = (int)h->dt_micro.n;
     da.Lblk = h->Lblk.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
-    HIPCHK(launch_dense_inverse(da, wtiles * kbt, h->stream));
+    // a lone workgroup is latency-bound (more threads = fewer trips of the trailing update: 1.3 ms instead of 1.7);
+    // with every CU busy the kernel is bound by the read-modify-write traffic of the trailing updates and 512 threads do better
+    int dthreads = wtiles * kbt <= h->n_cus ? 1024 : 512;
+    { const char *e = getenv("MI_OSQP_DENSE_THREADS"); if (e) dthreads = std::max(512, std::min(1024, atoi(e) / 64 * 64)); }
+    HIPCHK(launch_dense_inverse(da, wtiles * kbt, dthreads, h->stream));
   }
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
