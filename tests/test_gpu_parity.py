@@ -474,3 +474,38 @@ def test_max_iter_at_a_rho_update_iteration_then_resolve():
         tol = 1e-3 if st2 == -2 else TOL_X
         assert np.max(np.abs(s.primal()[b] - x2)) <= tol
     assert any(i.exit_code == ST2EXIT[-2] for i in i1)          # the case really contains a max_iter QP
+
+
+# ---- dense tail (inverted Schur complement of the trailing rows)
+
+def test_dense_tail_on_and_off_agree_and_match_oracle(monkeypatch):
+    pr = PR.random_box_qp(8)
+    res = {}
+    for mode in ("auto", "0"):
+        if mode == "0":
+            monkeypatch.setenv("MI_OSQP_DENSE_TAIL", "0")
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+        assert (s.stats()["dense_tail_rows"] > 0) == (mode == "auto")
+        info = s.solve()
+        x1 = s.primal().copy()
+        s.update_bounds(pr["l"] * 0.7, pr["u"] * 0.7)          # re-solve from the refactored state (rho updates happened)
+        info2 = s.solve()
+        res[mode] = ([i.iter for i in info], x1, [i.iter for i in info2], s.primal().copy(), [i.rho_updates for i in info2])
+        if mode == "auto":
+            _compare(info, x1, _oracle_batch(pr, range(8)), range(8))
+        s.close()
+    assert res["auto"][0] == res["0"][0] and res["auto"][2] == res["0"][2] and res["auto"][4] == res["0"][4]
+    assert np.max(np.abs(res["auto"][1] - res["0"][1])) <= 1e-9 and np.max(np.abs(res["auto"][3] - res["0"][3])) <= 1e-9
+
+
+@pytest.mark.parametrize("k", [64, 192])
+def test_forced_dense_tail_on_gomp_matches_oracle(k, monkeypatch):
+    monkeypatch.setenv("MI_OSQP_DENSE_TAIL", str(k))
+    P, (l, A, u), _ = PR.gomp_qp(6, 50, np.zeros(6), np.ones(6))
+    s = M.QPSolver((l, A, u), P)
+    assert s.stats()["dense_tail_rows"] == k
+    code, x = s.solve()
+    o = O.OracleQPSolver(P, None, A, l, u)
+    st, xo = o.solve()
+    assert code == 0 and st == 1 and s.info().iter == o.info().iter
+    assert np.max(np.abs(x - xo)) <= TOL_X

@@ -67,3 +67,41 @@ def test_block_factor_replay_matches_left_looking(case):
     dL, dD, cnt = M.debug_host_block_factor(P, A, l, u)
     assert dL <= 1e-10 and dD <= 1e-9, (name, dL, dD)
     assert cnt["blocks"] >= 1 and cnt["storage"] >= 1
+
+
+# ---- dense tail (host_core.hpp DenseTail): the trailing rows served by the inverted Schur complement
+
+def _kkt_check(P, A, l, u, scaling=10):
+    n, m = A.shape[1], A.shape[0]
+    rhs = np.random.default_rng(9).standard_normal(n + m)
+    s_sched, s_direct, st = M.debug_host_kkt_solve(P, A, l, u, rhs, scaling=scaling)
+    assert np.max(np.abs(s_sched - s_direct)) <= 1e-8 * np.max(np.abs(s_direct))
+    return st
+
+
+def test_dense_tail_is_chosen_for_config3_and_can_be_switched_off(monkeypatch):
+    pr = PR.random_box_qp(1)
+    P, A = PR.qp_matrices(pr, 0)
+    st = _kkt_check(P, A, pr["l"][0], pr["u"][0])
+    assert st["dense_tail_rows"] >= 256 and st["dense_tail_rows"] % 64 == 0
+    monkeypatch.setenv("MI_OSQP_DENSE_TAIL", "0")
+    st0 = _kkt_check(P, A, pr["l"][0], pr["u"][0])
+    assert st0["dense_tail_rows"] == 0 and st0["fwd_levels"] > 3 * st["fwd_levels"]
+    # the whole point: fewer values streamed per solve
+    assert st["fwd_slots"] + st["bwd_slots"] + st["dense_tail_slots"] < 0.7 * (st0["fwd_slots"] + st0["bwd_slots"])
+
+
+@pytest.mark.parametrize("k", [64, 128, 192])
+def test_forced_dense_tail_on_patterns_that_would_not_pick_one(k, monkeypatch):
+    """Forcing a tail exercises Schur complements with structural zeros, odd panel counts and tails that cut
+    through supernodes; solve replay and device-refactorisation replay must still agree with the plain factor."""
+    monkeypatch.setenv("MI_OSQP_DENSE_TAIL", str(k))
+    P, (l, A, u), _ = PR.gomp_qp(6, 50, np.zeros(6), np.ones(6))
+    assert _kkt_check(P, A, l, u)["dense_tail_rows"] == k
+    dL, dD, _ = M.debug_host_block_factor(P, A, l, u)
+    assert dL <= 1e-9 and dD <= 1e-9
+    pr = PR.random_box_qp(1, n=96, mg=64, nnz_per_row=6)
+    P, A = PR.qp_matrices(pr, 0)
+    assert _kkt_check(P, A, pr["l"][0], pr["u"][0], scaling=0)["dense_tail_rows"] == k
+    dL, dD, _ = M.debug_host_block_factor(P, A, pr["l"][0], pr["u"][0])
+    assert dL <= 1e-9 and dD <= 1e-9
