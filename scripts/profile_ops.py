@@ -11,7 +11,7 @@ def mk(**kw):
     return M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
 s = mk()
 st = s.stats()
-print({k: st[k] for k in ("tile", "n_tiles", "nnz_L", "fwd_levels", "bwd_levels", "fwd_slots", "bwd_slots", "chk_slots", "lds_bytes", "threads_per_block")})
+print({k: st[k] for k in ("tile", "n_tiles", "nnz_L", "fwd_levels", "bwd_levels", "fwd_slots", "bwd_slots", "chk_slots", "dense_tail_rows", "dense_tail_slots", "lds_bytes", "threads_per_block")})
 n, m = pr["n"], pr["m"]
 rhs = torch.randn(B, n + m, dtype=torch.float64, device="cuda"); sol = torch.empty_like(rhs)
 x = torch.randn(B, n, dtype=torch.float64, device="cuda"); y = torch.randn(B, m, dtype=torch.float64, device="cuda")
@@ -23,8 +23,8 @@ def timeit(f, reps=20):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / reps
 t = timeit(lambda: s.kkt_solve_device(rhs, sol))
-bytes_solve = (st["fwd_slots"] + st["bwd_slots"]) * 8 * B
-print(f"kkt_solve op: {t*1e3:.3f} ms  -> {bytes_solve/t/1e9:.0f} GB/s of (padded) factor values; algorithmic {2*8*st['nnz_L']*B/t/1e9:.0f} GB/s")
+bytes_solve = (st["fwd_slots"] + st["bwd_slots"] + st["dense_tail_slots"]) * 8 * B
+print(f"kkt_solve op: {t*1e3:.3f} ms  -> {bytes_solve/t/1e9:.0f} GB/s of streamed (padded) factor values; SURVEY 8(d) algorithmic {2*8*st['nnz_L']*B/t/1e9:.0f} GB/s")
 t = timeit(lambda: s.spmv_device(x, y, Px, Aty, Ax))
 alg = (2 * (8 * st["nnz_A"] + 8 * n + 8 * m) + 8 * st["nnz_P_triu"] + 16 * n) * B
 print(f"spmv op: {t*1e6:.1f} us -> algorithmic {alg/t/1e9:.0f} GB/s, padded values {st['chk_slots']*8*B/t/1e9:.0f} GB/s")
