@@ -10,6 +10,7 @@ namespace miosqp {
 // device view of one host_core.hpp Schedule (tables are shared by all tiles)
 struct SchedDev {
   const uint32_t *step, *idxw;          // per step: descriptor (sched_format.h); per slot: index word
+  const uint64_t *idxw64;               // wide index words instead of idxw (KernelArgs::wide)
   const uint32_t *lvl_pos, *tail_bar;   // (n_levels+1) x nw stream positions; per wave: barriers owed after the last step
   int n_phases, nw, n_levels;
   uint32_t n_steps, n_slots;
@@ -45,6 +46,7 @@ struct KernelArgs {
   double *x_out, *y_out;                // QP-major [B][n], [B][m]
   double *xs_global;                    // non-null: the solve vector lives here ([tile][xs_len][BT]) instead of LDS
   int xs_len;                           // length of the solve vector: Analysis::Next >= n + m
+  int wide;                             // 32-bit gather / row indices (Schedule::idxw64): vectors of 65 535 entries and more; needs xs_global, BT = 1
   // settings (row S)
   double sigma, alpha, eps_abs, eps_rel, eps_prim_inf, eps_dual_inf, rho_tolerance;
   int check_termination, rho_interval, max_iter, scaled_termination, scaling, adaptive_rho;

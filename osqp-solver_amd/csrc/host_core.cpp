@@ -273,7 +273,7 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 // spread over the waves); the steps are then numbered WAVE-MAJOR: wave w's steps of all phases are contiguous
 // in memory and form the linear stream the device walks (sched_format.h); phase boundaries survive only as
 // barrier counts in the descriptors.
-void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers) {
+void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers, bool wide) {
   sch = Schedule();
   sch.n_levels = (int)levels.size();
   sch.nw = nw; sch.bt = bt; sch.barriers = barriers;
@@ -413,13 +413,16 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
   }
   sch.n_slots = sch.n_steps * 64u;
   // device index words
-  sch.idxw.assign((size_t)sch.n_steps * 64, 0xFFFF0000u);
+  if (wide) sch.idxw64.assign((size_t)sch.n_steps * 64, 0xFFFFFFFF00000000ull);
+  else sch.idxw.assign((size_t)sch.n_steps * 64, 0xFFFF0000u);
   for (uint32_t st = 0; st < sch.n_steps; st++) {
     const uint32_t d = sch.step[st], lt = MI_D_LT(d), ob = sch.step_ob[st];
     for (uint32_t ln = 0; ln < 64; ln++) {
-      uint32_t row = 0xFFFFu;
-      if (d & MI_D_FLUSH) { uint32_t r = sch.outA[ob + (ln >> lt)]; row = r == kNoRow ? 0xFFFFu : r; }
-      sch.idxw[(size_t)st * 64 + ln] = (sch.idx[(size_t)st * 64 + ln] & 0xFFFFu) | (row << 16);
+      uint32_t row = kNoRow;
+      if (d & MI_D_FLUSH) row = sch.outA[ob + (ln >> lt)];
+      const size_t slot = (size_t)st * 64 + ln;
+      if (wide) sch.idxw64[slot] = (uint64_t)sch.idx[slot] | ((uint64_t)row << 32);
+      else sch.idxw[slot] = (sch.idx[slot] & 0xFFFFu) | ((row == kNoRow ? 0xFFFFu : row) << 16);
     }
   }
   if (getenv("MI_OSQP_DEBUG_ORDER")) {
@@ -481,7 +484,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
         }
       }
     }
-    pack_schedule(lw, an.fwd, nw, bt, true);
+    pack_schedule(lw, an.fwd, nw, bt, true, an.wide);
   }
   // ---- backward: columns descending, sources are rows j > column.  Column k of a chunk: phase A works in
   // place at xloc[k] (where the scaled forward result lives), phase B stores inv(L_cc)' t at position k.
@@ -514,7 +517,7 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
         }
       }
     }
-    pack_schedule(lw, an.bwd, nw, bt, true);
+    pack_schedule(lw, an.bwd, nw, bt, true, an.wide);
   }
 }
 
@@ -539,7 +542,7 @@ static void build_chk_schedule(Analysis &an, int nw, int bt) {
       ax[r].ent.push_back({(uint32_t)c, nnzP + k});
     }
   lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
-  pack_schedule(lw, an.chk, nw, bt, false);
+  pack_schedule(lw, an.chk, nw, bt, false, an.wide);
 }
 
 
@@ -860,7 +863,10 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   for (int r = 0; r < m; r++) { int pos = nxt[n + r]++; an.Ki[pos] = n + r; an.rhotoK[r] = pos; }
   // ---- ordering: two candidates, chosen by the modelled time of one KKT solve on the device
   // (latency-bound regime of one tile, measured with scripts/trace_phases.py: ~0.4 us per phase, ~40 GB/s of factor stream)
-  if (max_extra_rows < 0 || max_extra_rows > 65534 - N) max_extra_rows = std::max(0, 65534 - N);
+  // 16-bit index words while every vector the streams address stays below 65 535 entries (0xFFFF = "no row")
+  an.wide = N >= 65535 || 2 * n + m >= 65535;
+  if (max_extra_rows < 0) max_extra_rows = N;
+  if (!an.wide && max_extra_rows > 65534 - N) max_extra_rows = 65534 - N;
   auto finalize = [&](const std::vector<int> &perm0, double &cost) {
     an.perm = perm0;
     an.pinv.assign(N, 0);

@@ -60,6 +60,8 @@ struct Schedule {
   std::vector<uint32_t> idx;    // per slot: gather index into the solve vector
   std::vector<uint32_t> idxw;   // DEVICE index words, one per slot: low 16 bits = gather index, high 16
                                 // bits = target row of the lane's group on flush steps (0xFFFF = none)
+  std::vector<uint64_t> idxw64; // wide form (vectors of 65 535 entries and more; replaces idxw): low 32 bits =
+                                // gather index, high 32 bits = target row (0xFFFFFFFF = none)
   std::vector<int32_t> src;     // per slot: canonical value index, MI_SRC_ZERO = structural zero, MI_SRC_ONE = 1.0
   uint32_t n_slots = 0;         // = n_steps * 64
   uint32_t n_steps = 0;
@@ -126,6 +128,7 @@ enum { DT_DIAG = 1, DT_SWAP = 2 };
 
 struct Analysis {
   int n = 0, m = 0, N = 0;
+  bool wide = false;               // n + m or 2n + m >= 65 535: 32-bit gather / row indices in the step streams (Schedule::idxw64)
   // triu(P) and A patterns (CSC, 32-bit on our side)
   std::vector<int> Pp, Pi, Psrc;   // Psrc: index into the caller's P value array
   std::vector<int> Ap, Ai;
@@ -168,7 +171,8 @@ struct Analysis {
 // `nwaves` = waves per workgroup the device kernels will run with, `bt` = QPs per
 // tile (the step streams are laid out per wave; bt only sizes the physical layout).
 // `max_extra_rows` = how many rows may get a second position in the solve vector (Analysis::xloc): the caller's
-// LDS capacity / the 16-bit index range minus n + m; negative = as many as the 16-bit range allows.
+// LDS capacity; negative = no limit of the caller's.  With 16-bit index words (Analysis::wide == false) the count
+// is also limited by the index range.
 // `dense_tail_max` = largest dense tail (rows) the caller can serve, 0 = never use one.
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
             const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1,

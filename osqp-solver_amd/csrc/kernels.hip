@@ -127,11 +127,11 @@ __device__ __forceinline__ int flush_q(int lane) {
   else if constexpr (BT == 2) return lane & 1;
   else return 0;
 }
-template <int BT>
+template <int BT, uint32_t NONE = 0xFFFFu>
 __device__ __forceinline__ void flush_prefetch(uint32_t lt, uint32_t row, const double *base, int lane, double (&oldv)[BT]) {
 #pragma unroll
   for (int b = 0; b < BT; b++) oldv[b] = 0.0;
-  if (row == 0xFFFFu) return;
+  if (row == NONE) return;
   const double *dst = base + (size_t)row * BT;
   if (lt == 0) { load_bt<BT>(dst, oldv); return; }
   if constexpr (BT == 4) {
@@ -140,10 +140,10 @@ __device__ __forceinline__ void flush_prefetch(uint32_t lt, uint32_t row, const 
   if (((uint32_t)lane & ((1u << lt) - 1u)) < (uint32_t)BT) oldv[0] = dst[flush_q<BT>(lane)];
 }
 
-template <int BT>
+template <int BT, uint32_t NONE = 0xFFFFu>
 __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uint32_t row, double *base, int lane, bool sub,
                                              const double (&oldv)[BT]) {
-  const bool has_row = row != 0xFFFFu;
+  const bool has_row = row != NONE;
   if (lt == 0) {
     if (has_row) {
       double *dst = base + (size_t)row * BT;
@@ -210,16 +210,21 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 #define MI_PFV 15
 #endif
 template <int BT, int PF>
-struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t desc; };
+struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t gr[PF]; uint32_t desc; };     // gr: target rows of the wide index words (unused otherwise)
 // The value streams of a tile: ONE stream per QP ([slot][step][64] doubles, 8 B per lane and load) plus the shared
 // index words / descriptors.  A QP that has finished (or a padding slot) gets a null descriptor: its loads
 // return 0 without touching memory, so a half-done tile streams half the bytes.
 template <int BT>
 struct ValSrc { mi_rsrc vals[BT], idx, step; };
 
-template <int BT>
-__device__ __forceinline__ void load_step(const ValSrc<BT> &vs, uint32_t stepno, int lane, double (&v)[BT], uint32_t &gi) {
-  gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, (uint32_t)lane * 4u, stepno * 256u, 0);
+template <int BT, bool WIDE>
+__device__ __forceinline__ void load_step(const ValSrc<BT> &vs, uint32_t stepno, int lane, double (&v)[BT], uint32_t &gi, uint32_t &gr) {
+  if constexpr (WIDE) {
+    const mi_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(vs.idx, (uint32_t)lane * 8u, stepno * 512u, 0);
+    gi = t.x; gr = t.y;
+  } else {
+    gi = __builtin_amdgcn_raw_buffer_load_b32(vs.idx, (uint32_t)lane * 4u, stepno * 256u, 0);
+  }
 #pragma unroll
   for (int b = 0; b < BT; b++) {
     const mi_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(vs.vals[b], (uint32_t)lane * 8u, stepno * 512u, 0);
@@ -238,7 +243,7 @@ __device__ __forceinline__ uint32_t load_desc(const ValSrc<BT> &vs, uint32_t pos
 //   BAR  = the schedule has barriers (GX: full __syncthreads, the vector is in global memory)
 //   TR   = debug instantiations: 1: lane 0 logs the shader clock before / after every barrier into
 //          tr[(ordinal of the barrier * nw + wave) * 2 + {0, 1}]; 2: also the time spent waiting for ring slots
-template <int BT, int PF, bool SUB, bool BAR, bool GX, int TR = 0>
+template <int BT, int PF, bool SUB, bool BAR, bool GX, int TR = 0, bool WIDE = false>
 __device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs,
                                            double *out, int lane, uint32_t *tr = nullptr, int wave = 0, int nw = 0,
                                            uint32_t *tw = nullptr) {
@@ -250,10 +255,11 @@ __device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin,
   r.desc = MI_D_NOOP;
 #pragma unroll
   for (int st = 0; st < PF; st++) {
-    r.gi[st] = 0u;
+    r.gi[st] = 0u; r.gr[st] = 0u;
 #pragma unroll
     for (int b = 0; b < BT; b++) r.v[st][b] = 0.0;
   }
+  constexpr uint32_t NONE = WIDE ? 0xFFFFFFFFu : 0xFFFFu;
   static_assert(PF % (MI_D_LOOKAHEAD + 1) == 0, "the gather slots must line up across ring revolutions");
   constexpr int GS = MI_D_LOOKAHEAD + 1;      // gather slots: step q uses slot q % GS
   double acc[BT], xq[GS][BT];
@@ -289,27 +295,27 @@ __device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin,
         // Vector gathers run MI_D_LOOKAHEAD steps ahead of their fma (flags set by the host: no barrier in
         // between).  Inside one phase no step reads what another one writes (pull schedule; checked by the
         // host replay), so a gather may pass the flushes of the steps before it.
-        if (!(d & MI_D_PRE)) load_bt<BT>(xs + (size_t)(w & 0xFFFFu) * BT, xq[st % GS]);
+        if (!(d & MI_D_PRE)) load_bt<BT>(xs + (size_t)(WIDE ? w : (w & 0xFFFFu)) * BT, xq[st % GS]);
         const bool sub = SUB && !(d & MI_D_STORE);
         const bool flush = d & MI_D_FLUSH;
         // the old value of the target row (read-modify-write) is fetched before the reduction starts
         double oldv[BT];
-        const uint32_t lt = MI_D_LT(d), row = w >> 16;
-        if (flush && sub) flush_prefetch<BT>(lt, row, base, lane, oldv);
+        const uint32_t lt = MI_D_LT(d), row = WIDE ? r.gr[st] : (w >> 16);
+        if (flush && sub) flush_prefetch<BT, NONE>(lt, row, base, lane, oldv);
         if (d & MI_D_AHEAD) {
           const int s2 = (st + MI_D_LOOKAHEAD) % PF;         // past the end of this revolution: the slot was refilled already
-          load_bt<BT>(xs + (size_t)(r.gi[s2] & 0xFFFFu) * BT, xq[(st + MI_D_LOOKAHEAD) % GS]);
+          load_bt<BT>(xs + (size_t)(WIDE ? r.gi[s2] : (r.gi[s2] & 0xFFFFu)) * BT, xq[(st + MI_D_LOOKAHEAD) % GS]);
         }
 #pragma unroll
         for (int b = 0; b < BT; b++) acc[b] = fma(r.v[st][b], xq[st % GS][b], acc[b]);
         if (flush) {
-          reduce_write<BT>(acc, lt, row, base, lane, sub, oldv);
+          reduce_write<BT, NONE>(acc, lt, row, base, lane, sub, oldv);
 #pragma unroll
           for (int b = 0; b < BT; b++) acc[b] = 0.0;
         }
       }
       // ring refill: this slot now carries step npos + st
-      load_step<BT>(vs, npos + (uint32_t)st, lane, r.v[st], r.gi[st]);
+      load_step<BT, WIDE>(vs, npos + (uint32_t)st, lane, r.v[st], r.gi[st], r.gr[st]);
     }
     r.desc = dnext;
   }
@@ -318,21 +324,21 @@ __device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin,
 }
 
 // One triangular solve: this wave's whole stream of the schedule.
-template <int BT, int PF, bool GX, int TR = 0>
+template <int BT, int PF, bool GX, int TR = 0, bool WIDE = false>
 __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc<BT> &vals, double *xs, int wave, int lane,
                                         uint32_t *tr = nullptr, uint32_t *tw = nullptr) {
   mi_cptr lp = as_const(s.lvl_pos);
   const uint32_t begin = lp[wave], end = lp[(size_t)s.n_levels * s.nw + wave], tail = as_const(s.tail_bar)[wave];
-  run_stream<BT, PF, true, true, GX, TR>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw, tw);
+  run_stream<BT, PF, true, true, GX, TR, WIDE>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw, tw);
 }
 
 // SpMV with the same streams: levels [l0, l1) of the check schedule (independent rows, no barriers)
-template <int BT, int PF>
+template <int BT, int PF, bool WIDE = false>
 __device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc<BT> &vals, double *xs, double *out, int wave,
                                          int lane, int l0, int l1) {
   mi_cptr lp = as_const(s.lvl_pos);
   const uint32_t begin = lp[(size_t)l0 * s.nw + wave], end = lp[(size_t)l1 * s.nw + wave];
-  run_stream<BT, PF, false, false, false>(vals, begin, end, 0u, xs, out, lane);
+  run_stream<BT, PF, false, false, false, 0, WIDE>(vals, begin, end, 0u, xs, out, lane);
 }
 
 // --------------------------------------------------------- block reductions
@@ -396,9 +402,10 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile,
   p.out1 = a.out1 + t * (2 * n + m) * BT; p.out2 = a.out2 + t * (2 * n + m) * BT;
   p.dscal = a.dscal + t * DS_COUNT * BT;
   p.iscal = a.iscal + t * IS_COUNT * BT;
-  p.vfwd.idx = make_rsrc(a.fwd.idxw, a.fwd.n_steps * 256u); p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
-  p.vbwd.idx = make_rsrc(a.bwd.idxw, a.bwd.n_steps * 256u); p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
-  p.vchk.idx = make_rsrc(a.chk.idxw, a.chk.n_steps * 256u); p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
+  auto idx_rsrc = [&](const SchedDev &sd) { return a.wide ? make_rsrc(sd.idxw64, sd.n_steps * 512u) : make_rsrc(sd.idxw, sd.n_steps * 256u); };
+  p.vfwd.idx = idx_rsrc(a.fwd); p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
+  p.vbwd.idx = idx_rsrc(a.bwd); p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
+  p.vchk.idx = idx_rsrc(a.chk); p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
 #pragma unroll
   for (int bb = 0; bb < BT; bb++) {
     const size_t slot = t * BT + bb;
@@ -519,18 +526,18 @@ __device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *di
 }
 
 // K solve on the LDS vector: fwd levels, D^-1, bwd levels (row E7)
-template <int BT, int PF, bool GX>
+template <int BT, int PF, bool GX, bool WIDE = false>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
                                               int tid, int nthr, int wave, int nw, int lane) {
-  run_tri<BT, PF, GX>(a.fwd, p.vfwd, xs, wave, lane);
+  run_tri<BT, PF, GX, 0, WIDE>(a.fwd, p.vfwd, xs, wave, lane);
   kkt_middle<BT, GX>(a, p.dinv, p.vdt, xs, tid, nthr, wave, lane);
-  run_tri<BT, PF, GX>(a.bwd, p.vbwd, xs, wave, lane);
+  run_tri<BT, PF, GX, 0, WIDE>(a.bwd, p.vbwd, xs, wave, lane);
 }
 
 // E6-E10 for iterations (iter_begin, iter_end] of one tile.  Lean on purpose: the
 // residual / termination / rho logic lives in check_kernel, so this kernel needs
 // little beyond the register ring of the step streams.
-template <int BT, int NT, bool GX>
+template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   for (int iter = a.iter_begin + 1; iter <= a.iter_end; iter++) {
     const bool do_info = a.info_at_end && iter == a.iter_end;     // delta_x / delta_y are only needed by check_kernel
     // ---- E7
-    kkt_solve_lds<BT, MI_PFV, GX>(a, p, xs, tid, nthr, wave, nw, lane);
+    kkt_solve_lds<BT, MI_PFV, GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
     // ---- E8-E10 fused with E6 of the next iteration (run_tri ends with a barrier): every thread replaces the
     // solution entry it has just consumed by the next right-hand side entry - same position, no other reader
     for (int e = tid; e < n * BT; e += nthr) {
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
 
 // E11-E14 at iteration iter_end: residuals, termination and infeasibility tests,
 // rho estimate / update request, solution store.  Runs once per segment.
-template <int BT, int NT, bool GX>
+template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
   __syncthreads();
   // residual vectors and the norms termination + rho estimate need
   double mx[14];
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
     si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
   }
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3);
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3);
   __syncthreads();
   for (int e = tid; e < n * BT; e += nthr) {
     const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
 // ---------------------------------------------------------- standalone ops
 
 // Px, A'y, Ax for QP-major x[B][n], y[B][m]  (rows E11 / E14)
-template <int BT, int NT, bool GX>
+template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__restrict__ gx,
                                                     const double *__restrict__ gy, double *gPx,
                                                     double *gAty, double *gAx) {
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
     for (int i = tid; i < m; i += nthr) xs[((size_t)n + i) * BT + bb] = (ok && gy) ? gy[(size_t)q * m + i] : 0.0;
   }
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, res, wave, lane, 0, 3);
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, res, wave, lane, 0, 3);
   __syncthreads();
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
 }
 
 // sol = K^-1 rhs for QP-major rhs[B][N]  (row E7)
-template <int BT, int NT, bool GX>
+template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -830,7 +837,7 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
     for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
   }
   __syncthreads();
-  kkt_solve_lds<BT, MI_PFV, GX>(a, p, xs, tid, nthr, wave, nw, lane);
+  kkt_solve_lds<BT, MI_PFV, GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
     if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
 }
 
 // warm start (row E14): x <- Dinv .* x0 ; z <- A x   (QP-major x0[B][n])
-template <int BT, int NT, bool GX>
+template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const double *__restrict__ x0) {
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const doub
   }
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
   __syncthreads();
-  run_spmv<BT, MI_PFV>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3);
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3);
   __syncthreads();
   for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
@@ -1497,6 +1504,10 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
       return hipGetLastError();                                                                    \
     };                                                                                             \
     if (threads > 1024) return hipErrorInvalidValue;                                               \
+    if (a.wide) {                 /* 32-bit index words: global vector, one QP per tile */         \
+      if (!a.xs_global || BT != 1 || threads > 512) return hipErrorInvalidValue;                   \
+      return go(&KERNEL<1, 512, true, true>);                                                      \
+    }                                                                                              \
     if (threads > 512) {          /* 16 waves per tile: one workgroup per CU */                    \
       if (a.xs_global) return hipErrorInvalidValue;                                                \
       if (BT == 1) return go(&KERNEL<1, 1024, false>);                                             \

@@ -99,15 +99,16 @@ struct DevBuf {
 
 struct SchedBufs {
   DevBuf<uint32_t> step, idxw, lvl_pos, tail_bar;
+  DevBuf<uint64_t> idxw64;
   DevBuf<int32_t> src;
   int upload(const Schedule &s) {
     int rc;
-    if ((rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = src.upload(s.src)) ||
+    if ((rc = step.upload(s.step)) || (rc = idxw.upload(s.idxw)) || (rc = idxw64.upload(s.idxw64)) || (rc = src.upload(s.src)) ||
         (rc = lvl_pos.upload(s.lvl_pos)) || (rc = tail_bar.upload(s.tail_bar))) return rc;
     return 0;
   }
   SchedDev view(const Schedule &s) const {
-    SchedDev d; d.step = step.p; d.idxw = idxw.p; d.lvl_pos = lvl_pos.p; d.tail_bar = tail_bar.p;
+    SchedDev d; d.step = step.p; d.idxw = idxw.p; d.idxw64 = idxw64.p; d.lvl_pos = lvl_pos.p; d.tail_bar = tail_bar.p;
     d.n_phases = s.n_phases; d.nw = s.nw; d.n_levels = s.n_levels;
     d.n_steps = s.n_steps; d.n_slots = s.n_slots;
     return d;
@@ -198,7 +199,7 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
-  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.Next;
+  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.Next; a.wide = h->an.wide ? 1 : 0;
   {
     const DenseTail &dt = h->an.dt;
     a.dt.s = dt.s; a.dt.k = dt.k; a.dt.n_phases = dt.n_phases; a.dt.n_steps = dt.n_steps;
@@ -402,10 +403,6 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const char *eth = getenv("MI_OSQP_THREADS");
     h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 512;
   }
-  if (n + m >= 65535 || 2 * n + m >= 65535) {
-    g_last_error = "KKT dimension too large for 16-bit gather / row indices (n + m and 2n + m must stay below 65535)";
-    return MI_OSQP_ERR_ALLOC;
-  }
   // ---- tile shape (needed by the schedule layout)
   // 2 QPs per tile: iterate_kernel<2> needs 112 VGPRs, so two 512-thread workgroups share a CU and
   // cover each other's barrier stalls; measured best on the 1024-QP headline batch (4 and 1 are slower)
@@ -414,15 +411,20 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const char *et = getenv("MI_OSQP_TILE");
     if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
   }
+  // vectors of 65 535 entries and more: 32-bit index words (twice the index bytes), the solve vector in global
+  // memory, one QP per tile, 512 threads (the only instantiation of the wide kernels)
+  const bool wide = n + m >= 65535 || 2 * n + m >= 65535;
+  if (wide) { BT = 1; h->threads = std::min(h->threads, 512); }
   const size_t lds_cap = 160 * 1024;
   while (BT > 1 && lds_bytes((int)(n + m), BT, h->threads) > lds_cap) BT /= 2;
   // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
-  h->global_xs = lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
-  // rows that may get a second vector position (phase B of the solves): what still fits LDS / 16-bit indices
-  int max_extra = 65534 - (int)(n + m);
+  h->global_xs = wide || lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
+  // rows that may get a second vector position (phase B of the solves): what still fits LDS (analyze() also
+  // respects the 16-bit index range of the narrow index words)
+  int max_extra = -1;
   if (!h->global_xs) {
     const size_t cap_rows = (lds_cap - lds_bytes(0, BT, h->threads)) / (sizeof(double) * BT);
-    max_extra = (int)std::min<size_t>((size_t)max_extra, cap_rows - (size_t)(n + m));
+    max_extra = (int)(cap_rows - (size_t)(n + m));
   }
   const double ta0 = now_s();
   // dense tail (inverted Schur complement of the trailing rows): needs the LDS vector and <= 512 rows (one row per

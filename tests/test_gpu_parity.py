@@ -338,8 +338,8 @@ def test_config4_full_size_gomp_batch():
 
 def test_config5_style_structured_sparse_qp():
     """BASELINE config 5 (single large sparse QP, deep level-set solve) at the largest size the
-    LDS-resident design takes: 64x64 grid, n=4096, m=12160, N=16256 (the literal n=1e5 needs
-    the global-memory-vector variant)."""
+    LDS-resident design takes: 64x64 grid, n=4096, m=12160, N=16256 (the literal size runs in
+    test_config5_literal_size_solves through the wide-index / global-vector variant)."""
     pr = PR.grid_qp(64)
     s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
     st = s.stats()
@@ -350,11 +350,48 @@ def test_config5_style_structured_sparse_qp():
     assert r["prim"] < 5e-3 and r["stat"] < 5e-2
 
 
-def test_too_large_problem_is_refused_loudly():
-    pr = PR.grid_qp(150)          # N = 89 700: beyond the 16-bit gather / row indices
-    with pytest.raises(M.MiOsqpError) as e:
-        M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
-    assert e.value.code == 7
+def test_wide_index_words_beyond_the_16_bit_range():
+    """n + m = 89 700: the step streams carry 32-bit gather / row indices (Schedule::idxw64), the solve vector
+    lives in global memory, one workgroup serves the QP.  Same checks as everywhere: oracle parity."""
+    pr = PR.grid_qp(150)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    st = s.stats()
+    assert st["N"] == 89700 and st["tile"] == 1
+    info = s.solve()
+    # the KKT-solve op on the same handle (current factor, after the rho update of the solve) against the oracle's
+    import torch
+    ref = _oracle_batch(pr, [0])
+    _compare(info, s.primal(), ref, [0])
+    rhs = np.random.default_rng(1).standard_normal((1, st["N"]))
+    d_rhs = torch.tensor(rhs, device="cuda"); d_sol = torch.empty_like(d_rhs)
+    s.kkt_solve_device(d_rhs, d_sol)
+    ko = ref[0][3].kkt_solve(rhs[0])
+    assert np.max(np.abs(d_sol.cpu().numpy()[0] - ko)) <= 1e-9 * np.max(np.abs(ko))
+
+
+def test_config5_literal_size_solves():
+    """BASELINE config 5 at its literal size: n = 99 856, m = 298 936 (316 x 316 grid), N = 398 792, nnz(L) = 3.3 M.
+    The oracle needs minutes here, so the check is size-independent: OSQP's own termination inequalities and the
+    KKT conditions of the returned point, recomputed in numpy."""
+    pr = PR.grid_qp(316)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    st = s.stats()
+    assert st["n"] == 99856 and st["m"] == 298936 and st["tile"] == 1
+    info = s.solve()[0]
+    assert info.exit_code == 0 and info.iter % 25 == 0
+    x, y = s.primal()[0], s.dual()[0]
+    P, A = PR.qp_matrices(pr, 0)
+    Pf = sym_from_any(P)
+    Ax = A @ x
+    z = np.clip(Ax, pr["l"][0], pr["u"][0])
+    pri = np.max(np.abs(Ax - z))
+    dua = np.max(np.abs(Pf @ x + pr["q"][0] + A.T @ y))
+    eps_pri = 1e-3 + 1e-3 * max(np.max(np.abs(Ax)), np.max(np.abs(z)))
+    eps_dua = 1e-3 + 1e-3 * max(np.max(np.abs(Pf @ x)), np.max(np.abs(A.T @ y)), np.max(np.abs(pr["q"][0])))
+    assert pri <= 2 * eps_pri and dua <= 2 * eps_dua, (pri, eps_pri, dua, eps_dua)
+    assert abs(info.pri_res - pri) <= 1e-6 + 1e-2 * pri or info.pri_res <= eps_pri
+    r = kkt_residuals(P, pr["q"][0], A, pr["l"][0], pr["u"][0], x, y)
+    assert r["prim"] < 5e-3 and r["stat"] < 5e-2 and r["dual_sign"] < 1e-9
 
 
 def test_global_solve_vector_mode_small(monkeypatch):
