@@ -865,7 +865,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   // (latency-bound regime of one tile, measured with scripts/trace_phases.py: ~0.4 us per phase, ~40 GB/s of factor stream)
   // 16-bit index words while every vector the streams address stays below 65 535 entries (0xFFFF = "no row")
   an.wide = N >= 65535 || 2 * n + m >= 65535;
-  if (max_extra_rows < 0) max_extra_rows = N;
+  if (max_extra_rows < 0) max_extra_rows = 1 << 30;       // (also the budget of the dense tail's two accumulation vectors)
   if (!an.wide && max_extra_rows > 65534 - N) max_extra_rows = 65534 - N;
   auto finalize = [&](const std::vector<int> &perm0, double &cost) {
     an.perm = perm0;
