@@ -846,7 +846,8 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
 
 // Debug twin of kkt_solve_kernel<2, 512, false> (MI_OSQP trace entry point, scripts/trace_phases.py): same
 // solve, plus per-phase / per-wave shader-clock stamps of tiles {0, gridDim/2} copied to trace[2][words].
-// Layout of one tile's words: [0..3] = memtime / memrealtime at start and end (low words),
+// Layout of one tile's words: [0..3] = memtime / memrealtime at start and end (low words), [4..5] = memtime before / after
+// the step between the sweeps (D^-1 scaling, dense tail), [6..7] unused,
 // then per sweep and wave (cycles spent waiting for ring slots, real steps), then fwd stamps [n_phases_fwd][nw][2], then bwd stamps.
 template <int TRL>
 __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol,
@@ -867,10 +868,12 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
   }
   __syncthreads();
   if (tid == 0) { tr[0] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
-  uint32_t *twf = tr + 4, *twb = twf + 2 * nw;          // per wave: cycles waited for ring slots, real steps
+  uint32_t *twf = tr + 8, *twb = twf + 2 * nw;          // per wave: cycles waited for ring slots, real steps
   uint32_t *trf = twb + 2 * nw, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
   run_tri<BT, MI_PFV, false, TRL>(a.fwd, p.vfwd, xs, wave, lane, trf, twf);
+  if (tid == 0) tr[4] = (uint32_t)__builtin_amdgcn_s_memtime();
   kkt_middle<BT, false>(a, p.dinv, p.vdt, xs, tid, nthr, wave, lane);
+  if (tid == 0) tr[5] = (uint32_t)__builtin_amdgcn_s_memtime();
   run_tri<BT, MI_PFV, false, TRL>(a.bwd, p.vbwd, xs, wave, lane, trb, twb);
   if (tid == 0) { tr[2] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }
   for (int bb = 0; bb < BT; bb++) {

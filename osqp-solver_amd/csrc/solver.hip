@@ -1024,7 +1024,7 @@ int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double 
                                   int64_t cap, int64_t *dims) {
   if (!h || !dims) return MI_OSQP_ERR_NULL;
   const int nw = h->threads / 64;
-  const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 4 + 4 * nw + (fp + bp) * nw * 2;
+  const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 8 + 4 * nw + (fp + bp) * nw * 2;
   dims[0] = fp; dims[1] = bp; dims[2] = nw; dims[3] = words;
   if (!out) return MI_OSQP_OK;
   if (which == 1 || which == 2) {

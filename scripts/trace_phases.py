@@ -19,10 +19,12 @@ print("trace solve == op solve:", bool(torch.equal(sol, sol2)))
 for ti in range(2):
     t = tr[ti]
     dt_clk = np.uint32(t[2] - t[0]); dt_real = np.uint32(t[3] - t[1])
+    if dt_real == 0: continue                              # (a batch of one tile has no second traced tile)
     mhz = float(dt_clk) / (float(dt_real) / 100.0)      # s_memrealtime ticks at 100 MHz
     print(f"tile sel {ti}: total {float(dt_real)/100.0:.1f} us, memtime clock {mhz:.0f} MHz")
-    tw = t[4: 4 + 4 * nw].reshape(2, nw, 2).astype(np.int64)
-    off = 4 + 4 * nw
+    print(f"  between the sweeps (D^-1 scaling, dense tail product): {float(np.uint32(t[5] - t[4])) / mhz:.1f} us")
+    tw = t[8: 8 + 4 * nw].reshape(2, nw, 2).astype(np.int64)
+    off = 8 + 4 * nw
     for si, (name, tab, P) in enumerate((("fwd", ftab, fp), ("bwd", btab, bp))):
         print(f"  {name}: per wave waiting for ring data (us): {[round(float(c) / mhz, 1) for c in tw[si, :, 0]]} steps {tw[si, :, 1].tolist()}")
         st = t[off: off + P * nw * 2].reshape(P, nw, 2).astype(np.int64); off += P * nw * 2

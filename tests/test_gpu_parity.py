@@ -464,7 +464,7 @@ def test_phase_trace_diagnostics_reproduce_the_op():
     s.kkt_solve_device(rhs, sol_o)
     assert torch.equal(sol_t, sol_o)
     assert ftab.shape == (fp, 4 * nw + 1) and btab.shape == (bp, 4 * nw + 1) and tr.shape == (2, words)
-    stamps = tr[0][4 + 4 * nw: 4 + 4 * nw + fp * nw * 2].reshape(fp, nw, 2).astype(np.int64)
+    stamps = tr[0][8 + 4 * nw: 8 + 4 * nw + fp * nw * 2].reshape(fp, nw, 2).astype(np.int64)
     assert np.all((stamps[:, :, 1] - stamps[:, :, 0]) % (1 << 32) < (1 << 28))     # every barrier was passed by every wave
     assert np.all(stamps[:, :, 1] != 0)
 
