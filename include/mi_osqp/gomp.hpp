@@ -25,6 +25,8 @@
 #include <optional>
 #include <tuple>
 #include <utility>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "qp_solver.hpp"
@@ -434,6 +436,9 @@ class BatchGOMPSolver {
     std::vector<char> alive(B, 1);
     segments_run.assign(B, 0); qp_solves.assign(B, 0); qp_updates.assign(B, 0);
     batch_solves = 0;
+    seconds_build = seconds_setup = seconds_solve = seconds_update = 0.0;
+    using clk_ = std::chrono::steady_clock;
+    auto since_ = [](clk_::time_point t) { return std::chrono::duration<double>(clk_::now() - t).count(); };
     for (size_t b = 0; b < B; ++b) {
       last_solution[b] = linspace<N_DIM>(starts[b], ends[b], max_waypoints);      // joint-space line, zero velocities
       last_solution[b].resize(2 * max_waypoints * N_DIM, 0.0);
@@ -447,27 +452,35 @@ class BatchGOMPSolver {
       std::vector<QPVector> warm(K), seg_solution(K);
       std::vector<ExitCode> seg_code(K, ExitCode::kUnknown);
       std::vector<ConstraintBuilder<N_DIM>> builders;
-      builders.reserve(K);
       std::vector<QPConstraints> cons(K);
-      for (size_t k = 0; k < K; ++k) {
+      auto tb_ = clk_::now();
+      builders.assign(K, ConstraintBuilder<N_DIM>{waypoints, mappers, obstacles});
+      // the K trajectories are independent: their constraints are built by a few host threads
+      parallel_for_(K, [&](size_t k) {
         const QPVector &prev = last_solution[ids[k]];
         warm[k].resize(waypoints * N_DIM * 2);
         for (size_t t = 0; t < waypoints * N_DIM; ++t) {        // same slicing as GOMPSolver::run
           warm[k][t] = prev[t];
           warm[k][waypoints * N_DIM + t] = prev[waypoints * N_DIM + t];
         }
-        builders.push_back(initConstraints(starts[ids[k]], ends[ids[k]], warm[k], waypoints));
+        builders[k] = initConstraints(starts[ids[k]], ends[ids[k]], warm[k], waypoints);
         cons[k] = builders[k].build();
         seg_solution[k] = warm[k];
-      }
+      });
+      seconds_build += since_(tb_);
+      auto ts_ = clk_::now();
       BatchSolverT qp{cons, triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * waypoints), (int)(waypoints * N_DIM), (int)N_DIM), verbose};
       qp.setWarmStart(warm);
+      seconds_setup += since_(ts_);
       std::vector<char> running(K, 1);
       size_t n_running = K;
       for (int it = 0; it < MAX_ITERATIONS && n_running; ++it) {
+        auto tq_ = clk_::now();
         auto res = qp.solve();
+        seconds_solve += since_(tq_);
         ++batch_solves;
         bool need_update = false;
+        auto tu_ = clk_::now();
         for (size_t k = 0; k < K; ++k) {
           if (!running[k]) continue;
           ++qp_solves[ids[k]];
@@ -481,6 +494,7 @@ class BatchGOMPSolver {
           }
         }
         if (need_update && n_running) qp.update(cons);
+        seconds_update += since_(tu_);
       }
       for (size_t k = 0; k < K; ++k) {
         const size_t b = ids[k];
@@ -500,6 +514,9 @@ class BatchGOMPSolver {
   // per-trajectory counters (comparable with GOMPSolver's) and the number of batched solves
   std::vector<int> segments_run, qp_solves, qp_updates;
   int batch_solves = 0;
+  // where the wall time of the last run() went: building constraints, QP setup (analysis + upload + factorisation),
+  // batched solves, feasibility checks + re-linearisation + update
+  double seconds_build = 0.0, seconds_setup = 0.0, seconds_solve = 0.0, seconds_update = 0.0;
 
  private:
   const size_t max_waypoints;
@@ -509,6 +526,17 @@ class BatchGOMPSolver {
   const std::vector<HorizontalLine> obstacles;
   const std::vector<RobotBall> mappers;
   const bool verbose;
+
+  // body(k) for k in [0, count) on up to 16 host threads (the FK / Jacobian callbacks of the balls must be re-entrant,
+  // which the reference's are: pure functions of the joint vector)
+  template <class F>
+  static void parallel_for_(size_t count, F &&body) {
+    const size_t nt = std::min<size_t>({count, 16, std::max(1u, std::thread::hardware_concurrency())});
+    if (nt <= 1) { for (size_t k = 0; k < count; ++k) body(k); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t k = t; k < count; k += nt) body(k); });
+    for (auto &x : th) x.join();
+  }
 
   ConstraintBuilder<N_DIM> initConstraints(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, const QPVector &warm_start,
                                            size_t waypoints) const {

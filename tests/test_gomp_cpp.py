@@ -22,7 +22,7 @@ def exe(tmp_path_factory):
     out = tmp_path_factory.mktemp("gomp") / "gomp_parity"
     libdir, ordir = os.path.join(ROOT, "osqp-solver_amd"), os.path.join(ROOT, "oracle", "_build")
     cmd = ["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "gomp_parity.cpp"),
-           "-o", str(out), "-L" + libdir, "-lmi_osqp", "-L" + ordir, "-loracle_osqp", "-fopenmp",
+           "-o", str(out), "-L" + libdir, "-lmi_osqp", "-L" + ordir, "-loracle_osqp", "-fopenmp", "-pthread",
            "-Wl,-rpath," + libdir, "-Wl,-rpath," + ordir]
     subprocess.run(cmd, check=True)
     return str(out)
@@ -72,7 +72,7 @@ def test_gomp_example_writes_reference_trajectory_files(tmp_path):
     libdir = os.path.join(ROOT, "osqp-solver_amd")
     out = tmp_path / "gomp_example"
     subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "gomp_example.cpp"),
-                    "-o", str(out), "-L" + libdir, "-lmi_osqp", "-Wl,-rpath," + libdir], check=True)
+                    "-o", str(out), "-L" + libdir, "-lmi_osqp", "-pthread", "-Wl,-rpath," + libdir], check=True)
     r = subprocess.run([str(out), "40", "1", str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.splitlines()[0] == "kOptimal", r.stdout + r.stderr
     ctrl = (tmp_path / "output_trajectory_ctrl.data").read_text().strip().splitlines()
