@@ -7,10 +7,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
-f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-34:]) for r in csv.DictReader(open(f)))
+f = sorted(glob.glob("$OUT/**/*kernel_trace.csv", recursive=True))[-1]
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("miosqp::", "")[:44]) for r in csv.DictReader(open(f)))
 big = [e for e in ev if ("iterate" in e[2] or "factor" in e[2] or "check" in e[2] or "dense" in e[2])]
 last = big[-24:]
 for s, e, n in last:
-    print(f"{n:36s} {(e - s) / 1e3:9.1f} us")
+    print(f"{n:46s} {(e - s) / 1e3:9.1f} us")
 PY
