@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <set>
+#include <chrono>
 
 #include "../../include/mi_osqp.h"
 
@@ -41,27 +43,19 @@ static void min_degree(int N, const std::vector<int> &Kp, const std::vector<int>
     }
   for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
   std::vector<char> dead(N, 0);
-  // bucket lists by degree (lazy: entries may be stale, checked on pop)
-  std::vector<std::vector<int>> bucket(N + 1);
-  for (int v = 0; v < N; v++) bucket[adj[v].size()].push_back(v);
-  for (auto &b : bucket) std::sort(b.begin(), b.end(), std::greater<int>());  // pop_back = smallest index
+  // ordered by (degree, index): the smallest index among the nodes of minimum degree goes first
+  std::set<std::pair<int, int>> pq;
+  std::vector<int> deg(N);
+  for (int v = 0; v < N; v++) { deg[v] = (int)adj[v].size(); pq.insert({deg[v], v}); }
   perm.assign(N, 0);
   std::vector<int> tmp;
-  int alive = N, mind = 0;
-  for (int step = 0; step < N;) {
-    int v = -1;
-    while (true) {
-      while (mind <= N && bucket[mind].empty()) mind++;
-      if (mind > N) break;
-      int cand = bucket[mind].back(); bucket[mind].pop_back();
-      if (!dead[cand] && (int)adj[cand].size() == mind) { v = cand; break; }
-    }
-    if (v < 0) break;
+  int alive = N;
+  for (int step = 0; step < N && !pq.empty();) {
+    const int v = pq.begin()->second;
+    pq.erase(pq.begin());
     if ((int)adj[v].size() == alive - 1) {        // remaining graph is a clique
       perm[step++] = v; dead[v] = 1;
-      std::vector<int> rest;
-      for (int u = 0; u < N; u++) if (!dead[u]) rest.push_back(u);
-      for (int u : rest) { perm[step++] = u; dead[u] = 1; }
+      for (int u = 0; u < N; u++) if (!dead[u]) { perm[step++] = u; dead[u] = 1; }
       break;
     }
     perm[step++] = v; dead[v] = 1; alive--;
@@ -71,11 +65,9 @@ static void min_degree(int N, const std::vector<int> &Kp, const std::vector<int>
       std::set_union(adj[u].begin(), adj[u].end(), S.begin(), S.end(), std::back_inserter(tmp));
       tmp.erase(std::remove_if(tmp.begin(), tmp.end(), [&](int x) { return x == u || x == v; }), tmp.end());
       adj[u].swap(tmp);
-      int d = (int)adj[u].size();
-      // keep buckets sorted descending so that pop_back yields the smallest index
-      auto &b = bucket[d];
-      b.insert(std::upper_bound(b.begin(), b.end(), u, std::greater<int>()), u);
-      if (d < mind) mind = d;
+      pq.erase({deg[u], u});
+      deg[u] = (int)adj[u].size();
+      pq.insert({deg[u], u});
     }
     std::vector<int>().swap(adj[v]);
   }
@@ -115,20 +107,25 @@ void nd_leaf(NDCtx &c, const std::vector<int> &nodes) {
 
 void nd_rec(NDCtx &c, std::vector<int> nodes) {
   if ((int)nodes.size() <= c.leaf) { nd_leaf(c, nodes); return; }
-  // connected components of the induced subgraph
+  // connected components of the induced subgraph, all in one pass (removing a separator of a GOMP-like KKT graph
+  // leaves thousands of single constraint nodes behind: peeling them off one per recursion level is quadratic),
+  // numbered in the order of their first node
   int st = ++c.cur;
   for (int v : nodes) c.stamp[v] = st;
   {
-    int seen = ++c.cur;
-    std::vector<int> comp0, q;
-    q.push_back(nodes[0]); c.stamp[nodes[0]] = seen;
-    for (size_t h = 0; h < q.size(); h++)
-      for (int u : c.adj[q[h]]) if (c.stamp[u] == st) { c.stamp[u] = seen; q.push_back(u); }
-    if (q.size() < nodes.size()) {
-      std::vector<int> rest;
-      for (int v : nodes) if (c.stamp[v] != seen) rest.push_back(v);
-      nd_rec(c, q);
-      nd_rec(c, rest);
+    const int seen = ++c.cur;
+    std::vector<std::vector<int>> comps;
+    for (int v : nodes) {
+      if (c.stamp[v] != st) continue;
+      std::vector<int> q{v};
+      c.stamp[v] = seen;
+      for (size_t h = 0; h < q.size(); h++)
+        for (int u : c.adj[q[h]]) if (c.stamp[u] == st) { c.stamp[u] = seen; q.push_back(u); }
+      if (q.size() == nodes.size()) break;                 // connected: carry on below
+      comps.push_back(std::move(q));
+    }
+    if (!comps.empty()) {
+      for (auto &comp : comps) nd_rec(c, std::move(comp));       // each in BFS order from its first node
       return;
     }
     for (int v : nodes) c.stamp[v] = st;
@@ -964,15 +961,28 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   {
     std::vector<int> p_md, p_nd;
     double c_md = 0.0, c_nd = 0.0;
-    min_degree(N, an.Kp, an.Ki, p_md);
-    nested_dissection(N, an.Kp, an.Ki, p_nd);
+    const bool dbg_t = getenv("MI_OSQP_DEBUG_ORDER") != nullptr;
+    auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt = now_();
     const char *force = getenv("MI_OSQP_ORDERING");       // "md" / "nd": experiments
+    // minimum degree works on the explicit elimination graph (quadratic on big meshes: 0.9 s at N = 160 k, where nested
+    // dissection takes 0.2 s and wins anyway): beyond 60 k rows it is a candidate only on request
+    const bool try_md = N <= 60000 || (force && force[0] == 'm');
+    if (try_md) min_degree(N, an.Kp, an.Ki, p_md);
+    if (dbg_t) { fprintf(stderr, "[mi_osqp] min_degree %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
+    nested_dissection(N, an.Kp, an.Ki, p_nd);
+    if (dbg_t) { fprintf(stderr, "[mi_osqp] nested_dissection %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
     finalize(p_nd, c_nd);
-    finalize(p_md, c_md);
-    bool use_nd = c_nd < c_md;
-    if (getenv("MI_OSQP_DEBUG_ORDER")) fprintf(stderr, "[mi_osqp] ordering cost md %.3e nd %.3e\n", c_md, c_nd);
-    if (force) use_nd = force[0] == 'n';
-    if (use_nd) finalize(p_nd, c_nd);
+    if (dbg_t) { fprintf(stderr, "[mi_osqp] finalize(nd) %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
+    bool use_nd = true;
+    if (try_md) {
+      finalize(p_md, c_md);
+      if (dbg_t) { fprintf(stderr, "[mi_osqp] finalize(md) %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
+      use_nd = c_nd < c_md;
+      if (getenv("MI_OSQP_DEBUG_ORDER")) fprintf(stderr, "[mi_osqp] ordering cost md %.3e nd %.3e\n", c_md, c_nd);
+      if (force) use_nd = force[0] == 'n';
+      if (use_nd) finalize(p_nd, c_nd);
+    }
     an.ordering = use_nd ? 1 : 0;
   }
   build_tri_schedules(an, nwaves, bt);
