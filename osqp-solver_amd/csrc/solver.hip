@@ -598,7 +598,6 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
         (void)hipMemcpy(h->h_npos, h->npos.p, (size_t)h->ntiles * BT * sizeof(int), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mi_osqp] slot %d: %d positive pivots, expected %d\n", s, h->h_npos[s], h->an.n);
       }
-      if (getenv("MI_OSQP_DEBUG_IGNORE_INERTIA")) continue;
       g_last_error = "the KKT factor lost its inertia"; return MI_OSQP_ERR_NONCONVEX;
     }
   return 0;
