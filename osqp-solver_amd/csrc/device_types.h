@@ -94,6 +94,16 @@ hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, s
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                        const double *x, const double *y, double *Px, double *Aty, double *Ax);
+// fused P x / A'y / A x (spmv_fused_kernel): the compact P and A values of a tile staged in LDS once and used for all
+// three products; row r of [P x ; A'y ; A x] = sum over ent[ptr[r] .. ptr[r+1]) of val[e & 0xFFFF] * [x ; y][e >> 16]
+struct SpmvFused {
+  const uint32_t *ptr, *ent;
+  const double *pa_val;          // [tile][pa_len][BT]
+  int pa_len;
+};
+hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, int tiles, hipStream_t st,
+                             const double *x, const double *y, double *Px, double *Aty, double *Ax);
+size_t spmv_fused_lds_bytes(int n, int m, int pa_len, int BT);
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                             const double *rhs, double *sol);
 hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,

@@ -822,6 +822,67 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
   }
 }
 
+
+// P x, A'y, A x with ONE read of the matrices (rows E11 / E14 as an op).  The three products share their values: P is
+// symmetric (upper triangle stored, each entry serves two rows) and A serves A x by rows and A'y by columns, so the
+// compact values of a tile (pa_val, 8 (nnz(P) + nnz(A)) bytes per QP: 57 KB at config 3) are staged in LDS once and every
+// output row is a short gather-dot-product over LDS in a fixed order (one thread per row: no atomics, deterministic).
+// SURVEY 8(d) counts the three SpMVs separately (A twice); this kernel moves 0.65x those bytes.
+template <int BT>
+__global__ __launch_bounds__(512) void spmv_fused_kernel(KernelArgs a, SpmvFused t, const double *__restrict__ gx,
+                                                         const double *__restrict__ gy, double *gPx, double *gAty, double *gAx) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int n = a.n, m = a.m, len = t.pa_len;
+  double *vals = smem, *xs = smem + (size_t)len * BT;
+  {     // the tile's values: one contiguous block of len * BT doubles
+    const double *src = t.pa_val + (size_t)tile * len * BT;
+    const int tot = len * BT, pairs = tot / 2;
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(vals);
+    for (int e = tid; e < pairs; e += nthr) d2[e] = s2[e];
+    if (tid == 0 && (tot & 1)) vals[tot - 1] = src[tot - 1];
+  }
+  for (int bb = 0; bb < BT; bb++) {           // coalesced QP-major input
+    const int q = tile * BT + bb;
+    const bool ok = q < a.B;
+    for (int i = tid; i < n; i += nthr) xs[(size_t)i * BT + bb] = (ok && gx) ? gx[(size_t)q * n + i] : 0.0;
+    for (int i = tid; i < m; i += nthr) xs[((size_t)n + i) * BT + bb] = (ok && gy) ? gy[(size_t)q * m + i] : 0.0;
+  }
+  __syncthreads();
+  for (int r = tid; r < 2 * n + m; r += nthr) {
+    double *out; size_t stride; int idx;
+    if (r < n) { out = gPx; stride = (size_t)n; idx = r; }
+    else if (r < 2 * n) { out = gAty; stride = (size_t)n; idx = r - n; }
+    else { out = gAx; stride = (size_t)m; idx = r - 2 * n; }
+    if (!out) continue;
+    double acc[BT];
+#pragma unroll
+    for (int b = 0; b < BT; b++) acc[b] = 0.0;
+    for (uint32_t e = t.ptr[r]; e < t.ptr[r + 1]; e++) {
+      const uint32_t w = t.ent[e], vp = w & 0xFFFFu, vi = w >> 16;
+#pragma unroll
+      for (int b = 0; b < BT; b++) acc[b] = fma(vals[(size_t)vp * BT + b], xs[(size_t)vi * BT + b], acc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < BT; b++) { const int q = tile * BT + b; if (q < a.B) out[(size_t)q * stride + idx] = acc[b]; }
+  }
+}
+size_t spmv_fused_lds_bytes(int n, int m, int pa_len, int BT) { return ((size_t)pa_len + n + m) * BT * sizeof(double); }
+hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, int tiles, hipStream_t st,
+                             const double *x, const double *y, double *Px, double *Aty, double *Ax) {
+  const size_t lds = spmv_fused_lds_bytes(a.n, a.m, t.pa_len, BT);
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, st, a, t, x, y, Px, Aty, Ax);
+    return hipGetLastError();
+  };
+  if (BT == 1) return go(&spmv_fused_kernel<1>);
+  if (BT == 2) return go(&spmv_fused_kernel<2>);
+  return go(&spmv_fused_kernel<4>);
+}
+
 // sol = K^-1 rhs for QP-major rhs[B][N]  (row E7)
 template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {

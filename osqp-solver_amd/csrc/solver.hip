@@ -139,6 +139,7 @@ struct mi_osqp_batch {
   DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar, dt_sblk, dt_micro;
   DevBuf<int32_t> dt_src;
   DevBuf<double> dt_val, dt_val0, dt_Sd;
+  DevBuf<uint32_t> sp_ptr, sp_ent;      // fused SpMV op (spmv_fused_kernel); empty when not eligible
   bool host_rho_stale = false;
   bool clear_rho_updates = true;          // the next solve starts counting rho updates from 0 (setup / update_* / reset happened)
   int *h_npos = nullptr;
@@ -481,6 +482,28 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
         (rc = h->Lblk.alloc((size_t)bf.storage * (T + 4))) || (rc = h->Dl.alloc((size_t)an.N * (T + 4))) || (rc = h->Dl.zero(h->stream)) ||
         (rc = h->dinv_scratch.alloc((size_t)an.N * (T + 4))) || (rc = h->npos.alloc(T))) return rc;
     HIPCHK(hipHostMalloc((void **)&h->h_npos, T * sizeof(int)));
+  }
+  // tables of the fused SpMV op: rows of [P x ; A'y ; A x] as (value position, vector index) pairs, 16 bits each; used
+  // when the compact values of a tile and [x ; y] fit LDS together
+  if (!h->global_xs && an.Pp[n] + an.Ap[n] < 65536 && n + m < 65536 &&
+      spmv_fused_lds_bytes((int)n, (int)m, an.Pp[n] + an.Ap[n], BT) <= 150 * 1024) {
+    const int nnzP = an.Pp[n];
+    std::vector<std::vector<uint32_t>> rows((size_t)2 * n + m);
+    for (int c = 0; c < (int)n; c++)
+      for (int k = an.Pp[c]; k < an.Pp[c + 1]; k++) {
+        const int r = an.Pi[k];
+        rows[r].push_back((uint32_t)k | ((uint32_t)c << 16));
+        if (r != c) rows[c].push_back((uint32_t)k | ((uint32_t)r << 16));
+      }
+    for (int c = 0; c < (int)n; c++)
+      for (int k = an.Ap[c]; k < an.Ap[c + 1]; k++) {
+        const int r = an.Ai[k];
+        rows[(size_t)n + c].push_back((uint32_t)(nnzP + k) | ((uint32_t)(n + r) << 16));
+        rows[(size_t)2 * n + r].push_back((uint32_t)(nnzP + k) | ((uint32_t)c << 16));
+      }
+    std::vector<uint32_t> ptr{0u}, ent;
+    for (auto &rw : rows) { ent.insert(ent.end(), rw.begin(), rw.end()); ptr.push_back((uint32_t)ent.size()); }
+    if ((rc = h->sp_ptr.upload(ptr)) || (rc = h->sp_ent.upload(ent))) return rc;
   }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
@@ -1002,6 +1025,12 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
   if (!h) return MI_OSQP_ERR_NULL;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
+  if (h->sp_ptr.n && !getenv("MI_OSQP_SPMV_STREAM")) {      // one read of P and A for all three products
+    SpmvFused t{h->sp_ptr.p, h->sp_ent.p, h->pa_val.p, h->an.Pp[h->an.n] + h->an.Ap[h->an.n]};
+    HIPCHK(launch_spmv_fused(a, t, h->BT, h->ntiles, s, d_x, d_y, d_Px, d_Aty, d_Ax));
+    HIPCHK(hipStreamSynchronize(s));
+    return MI_OSQP_OK;
+  }
   size_t lds = (size_t)(h->an.Next + 2 * h->an.n + h->an.m) * h->BT * sizeof(double);
   a.op_out_lds = !h->global_xs && lds <= 160 * 1024;
   if (!a.op_out_lds) lds = h->lds;
