@@ -100,8 +100,14 @@ struct SpmvFused {
   const uint32_t *ptr, *ent;
   const double *pa_val;          // [tile][pa_len][BT]
   int pa_len;
+  // ELL form of the same rows for the prefetching variant (ell != null): the rows sorted by length (descending) and cut
+  // into passes of 512 rows; pass p holds its rows' entries as ell[ell_off[p] + k * 512 + thread], k < ell_k[p], padded
+  // with entries that point at a zero value (position pa_len); rowid[pass * 512 + thread] = output row or 0xFFFFFFFF
+  const uint32_t *ell, *rowid;
+  int n_pass;
+  uint32_t ell_off[4], ell_k[4];
 };
-hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, int tiles, hipStream_t st,
+hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, int tiles, int n_cus, hipStream_t st,
                              const double *x, const double *y, double *Px, double *Aty, double *Ax);
 size_t spmv_fused_lds_bytes(int n, int m, int pa_len, int BT);
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,

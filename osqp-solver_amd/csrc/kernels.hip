@@ -834,7 +834,7 @@ __global__ __launch_bounds__(512) void spmv_fused_kernel(KernelArgs a, SpmvFused
   extern __shared__ double smem[];
   const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int n = a.n, m = a.m, len = t.pa_len;
-  double *vals = smem, *xs = smem + (size_t)len * BT;
+  double *vals = smem, *xs = smem + (size_t)(len + 1) * BT;
   {     // the tile's values: one contiguous block of len * BT doubles
     const double *src = t.pa_val + (size_t)tile * len * BT;
     const int tot = len * BT, pairs = tot / 2;
@@ -849,13 +849,47 @@ __global__ __launch_bounds__(512) void spmv_fused_kernel(KernelArgs a, SpmvFused
     for (int i = tid; i < n; i += nthr) xs[(size_t)i * BT + bb] = (ok && gx) ? gx[(size_t)q * n + i] : 0.0;
     for (int i = tid; i < m; i += nthr) xs[((size_t)n + i) * BT + bb] = (ok && gy) ? gy[(size_t)q * m + i] : 0.0;
   }
+  auto put = [&](uint32_t r, const double (&acc)[BT]) {
+    double *out; size_t stride; int idx;
+    if (r < (uint32_t)n) { out = gPx; stride = (size_t)n; idx = (int)r; }
+    else if (r < (uint32_t)(2 * n)) { out = gAty; stride = (size_t)n; idx = (int)r - n; }
+    else { out = gAx; stride = (size_t)m; idx = (int)r - 2 * n; }
+    if (!out) return;
+#pragma unroll
+    for (int b = 0; b < BT; b++) { const int q = tile * BT + b; if (q < a.B) out[(size_t)q * stride + idx] = acc[b]; }
+  };
+  if (t.ell) {
+    // Prefetching variant: the index words of this thread's (<= 4) rows are loaded BEFORE the staging barrier - coalesced,
+    // independent, hidden behind the value loads - so that only LDS work is left after it.
+    constexpr int PMAX = 4, KMAX = 24;
+    uint32_t w[PMAX][KMAX], rid[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; p++) {
+      rid[p] = p < t.n_pass ? t.rowid[p * 512 + tid] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) w[p][k] = (p < t.n_pass && (uint32_t)k < t.ell_k[p]) ? t.ell[t.ell_off[p] + (uint32_t)k * 512u + (uint32_t)tid] : 0u;
+    }
+    vals[(size_t)len * BT + (tid % BT)] = 0.0;        // the zero the padding entries point at
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PMAX; p++) {
+      if (p >= t.n_pass) break;
+      double acc[BT];
+#pragma unroll
+      for (int b = 0; b < BT; b++) acc[b] = 0.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; k++) {
+        if ((uint32_t)k >= t.ell_k[p]) break;
+        const uint32_t vp = w[p][k] & 0xFFFFu, vi = w[p][k] >> 16;
+#pragma unroll
+        for (int b = 0; b < BT; b++) acc[b] = fma(vals[(size_t)vp * BT + b], xs[(size_t)vi * BT + b], acc[b]);
+      }
+      if (rid[p] != 0xFFFFFFFFu) put(rid[p], acc);
+    }
+    return;
+  }
   __syncthreads();
   for (int r = tid; r < 2 * n + m; r += nthr) {
-    double *out; size_t stride; int idx;
-    if (r < n) { out = gPx; stride = (size_t)n; idx = r; }
-    else if (r < 2 * n) { out = gAty; stride = (size_t)n; idx = r - n; }
-    else { out = gAx; stride = (size_t)m; idx = r - 2 * n; }
-    if (!out) continue;
     double acc[BT];
 #pragma unroll
     for (int b = 0; b < BT; b++) acc[b] = 0.0;
@@ -864,13 +898,67 @@ __global__ __launch_bounds__(512) void spmv_fused_kernel(KernelArgs a, SpmvFused
 #pragma unroll
       for (int b = 0; b < BT; b++) acc[b] = fma(vals[(size_t)vp * BT + b], xs[(size_t)vi * BT + b], acc[b]);
     }
-#pragma unroll
-    for (int b = 0; b < BT; b++) { const int q = tile * BT + b; if (q < a.B) out[(size_t)q * stride + idx] = acc[b]; }
+    put((uint32_t)r, acc);
   }
 }
-size_t spmv_fused_lds_bytes(int n, int m, int pa_len, int BT) { return ((size_t)pa_len + n + m) * BT * sizeof(double); }
-hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, int tiles, hipStream_t st,
+
+// The same product with ONE QP per workgroup (69 KB of LDS at config 3: two workgroups per CU, so that the staging of
+// one overlaps the row work and the stores of the other; the tile-wide kernel above needs 138 KB and runs its tiles in
+// non-overlapping rounds).  The QP's values are every BT-th double of its tile's block; the BT workgroups of a tile
+// get block ids 8 apart, i.e. the same XCD (block -> XCD is round-robin), so the lines one of them fetches serve the other
+// from the shared L2.  Tried and slower: persistent workgroups with the index words kept in registers and double-buffered
+// staging (one workgroup of 8 waves per CU has too few loads in flight: 47 us instead of 33-35), and one workgroup
+// per tile serving its QPs one after the other (47 us).
+__global__ __launch_bounds__(512) void spmv_fused_qp_kernel(KernelArgs a, SpmvFused t, int BT, const double *__restrict__ gx,
+                                                           const double *__restrict__ gy, double *gPx, double *gAty, double *gAx) {
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int g = blockIdx.x, grp = g / (8 * BT), within = g % (8 * BT);
+  const int tile = grp * 8 + within % 8, b = within / 8, q = tile * BT + b;
+  const int n = a.n, m = a.m, len = t.pa_len;
+  if (q >= a.B) return;
+  double *vals = smem, *xs = smem + (size_t)len + 1;
+  const double *src = t.pa_val + (size_t)tile * len * BT + b;
+  for (int e = tid; e < len; e += nthr) vals[e] = src[(size_t)e * BT];
+  for (int i = tid; i < n; i += nthr) xs[i] = gx ? gx[(size_t)q * n + i] : 0.0;
+  for (int i = tid; i < m; i += nthr) xs[n + i] = gy ? gy[(size_t)q * m + i] : 0.0;
+  constexpr int PMAX = 4, KMAX = 24;
+  uint32_t w[PMAX][KMAX], rid[PMAX];
+#pragma unroll
+  for (int p = 0; p < PMAX; p++) {
+    rid[p] = p < t.n_pass ? t.rowid[p * 512 + tid] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) w[p][k] = (p < t.n_pass && (uint32_t)k < t.ell_k[p]) ? t.ell[t.ell_off[p] + (uint32_t)k * 512u + (uint32_t)tid] : 0u;
+  }
+  if (tid == 0) vals[len] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < PMAX; p++) {
+    if (p >= t.n_pass) break;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; k++) {
+      if ((uint32_t)k >= t.ell_k[p]) break;
+      acc = fma(vals[w[p][k] & 0xFFFFu], xs[w[p][k] >> 16], acc);
+    }
+    const uint32_t r = rid[p];
+    if (r == 0xFFFFFFFFu) continue;
+    if (r < (uint32_t)n) { if (gPx) gPx[(size_t)q * n + r] = acc; }
+    else if (r < (uint32_t)(2 * n)) { if (gAty) gAty[(size_t)q * n + (r - n)] = acc; }
+    else if (gAx) gAx[(size_t)q * m + (r - 2 * n)] = acc;
+  }
+}
+size_t spmv_fused_lds_bytes(int n, int m, int pa_len, int BT) { return ((size_t)pa_len + 1 + n + m) * BT * sizeof(double); }
+hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, int tiles, int n_cus, hipStream_t st,
                              const double *x, const double *y, double *Px, double *Aty, double *Ax) {
+  (void)n_cus;
+  if (t.ell && tiles % 8 == 0 && !getenv("MI_OSQP_SPMV_TILE")) {      // one QP per workgroup
+    const size_t lq = spmv_fused_lds_bytes(a.n, a.m, t.pa_len, 1);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_fused_qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(spmv_fused_qp_kernel, dim3(tiles * BT), dim3(512), lq, st, a, t, BT, x, y, Px, Aty, Ax);
+    return hipGetLastError();
+  }
   const size_t lds = spmv_fused_lds_bytes(a.n, a.m, t.pa_len, BT);
   auto go = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

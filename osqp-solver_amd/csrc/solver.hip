@@ -140,6 +140,9 @@ struct mi_osqp_batch {
   DevBuf<int32_t> dt_src;
   DevBuf<double> dt_val, dt_val0, dt_Sd;
   DevBuf<uint32_t> sp_ptr, sp_ent;      // fused SpMV op (spmv_fused_kernel); empty when not eligible
+  DevBuf<uint32_t> sp_ell, sp_rowid;    // its prefetching form (rows sorted by length, <= 4 passes of 512 rows, <= 24 entries per row)
+  int sp_npass = 0;
+  uint32_t sp_ell_off[4] = {0, 0, 0, 0}, sp_ell_k[4] = {0, 0, 0, 0};
   bool host_rho_stale = false;
   bool clear_rho_updates = true;          // the next solve starts counting rho updates from 0 (setup / update_* / reset happened)
   int *h_npos = nullptr;
@@ -504,6 +507,31 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     std::vector<uint32_t> ptr{0u}, ent;
     for (auto &rw : rows) { ent.insert(ent.end(), rw.begin(), rw.end()); ptr.push_back((uint32_t)ent.size()); }
     if ((rc = h->sp_ptr.upload(ptr)) || (rc = h->sp_ent.upload(ent))) return rc;
+    // prefetching form
+    const size_t nrows = rows.size();
+    size_t maxlen = 0;
+    for (auto &rw : rows) maxlen = std::max(maxlen, rw.size());
+    if (nrows <= 4 * 512 && maxlen <= 24) {
+      std::vector<uint32_t> order(nrows);
+      for (size_t r = 0; r < nrows; r++) order[r] = (uint32_t)r;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return rows[x].size() > rows[y].size(); });
+      const int npass = (int)((nrows + 511) / 512);
+      std::vector<uint32_t> ell, rowid((size_t)npass * 512, 0xFFFFFFFFu);
+      const uint32_t pad = (uint32_t)(an.Pp[n] + an.Ap[n]);          // value position of the zero, vector index 0
+      for (int p = 0; p < npass; p++) {
+        const size_t r0 = (size_t)p * 512, r1 = std::min(nrows, r0 + 512);
+        const uint32_t K = (uint32_t)rows[order[r0]].size();
+        h->sp_ell_off[p] = (uint32_t)ell.size(); h->sp_ell_k[p] = K;
+        ell.resize(ell.size() + (size_t)K * 512, pad);
+        for (size_t r = r0; r < r1; r++) {
+          rowid[r] = order[r];
+          const auto &rw = rows[order[r]];
+          for (size_t k = 0; k < rw.size(); k++) ell[h->sp_ell_off[p] + k * 512 + (r - r0)] = rw[k];
+        }
+      }
+      h->sp_npass = npass;
+      if ((rc = h->sp_ell.upload(ell)) || (rc = h->sp_rowid.upload(rowid))) return rc;
+    }
   }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
@@ -1026,8 +1054,13 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
   if (h->sp_ptr.n && !getenv("MI_OSQP_SPMV_STREAM")) {      // one read of P and A for all three products
-    SpmvFused t{h->sp_ptr.p, h->sp_ent.p, h->pa_val.p, h->an.Pp[h->an.n] + h->an.Ap[h->an.n]};
-    HIPCHK(launch_spmv_fused(a, t, h->BT, h->ntiles, s, d_x, d_y, d_Px, d_Aty, d_Ax));
+    SpmvFused t{};
+    t.ptr = h->sp_ptr.p; t.ent = h->sp_ent.p; t.pa_val = h->pa_val.p; t.pa_len = h->an.Pp[h->an.n] + h->an.Ap[h->an.n];
+    if (h->sp_npass && !getenv("MI_OSQP_SPMV_NO_PREFETCH")) {
+      t.ell = h->sp_ell.p; t.rowid = h->sp_rowid.p; t.n_pass = h->sp_npass;
+      for (int p = 0; p < 4; p++) { t.ell_off[p] = h->sp_ell_off[p]; t.ell_k[p] = h->sp_ell_k[p]; }
+    }
+    HIPCHK(launch_spmv_fused(a, t, h->BT, h->ntiles, h->n_cus, s, d_x, d_y, d_Px, d_Aty, d_Ax));
     HIPCHK(hipStreamSynchronize(s));
     return MI_OSQP_OK;
   }
