@@ -17,6 +17,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mi_osqp.h"
@@ -75,15 +77,54 @@ static void parallel_for(int count, F &&fn) {
   for (auto &x : th) x.join();
 }
 
+// Device memory of freed handles is kept for the next one (the GOMP drivers build a new solver per horizon segment:
+// hipMalloc / hipFree of ~60 buffers cost ~11 ms per segment otherwise).  A block is reused for requests between half
+// its size and its size; at most 8 GiB are kept, mi_osqp_release_device_cache() returns them to the runtime.
+namespace devpool {
+static std::mutex mu;
+static std::multimap<std::pair<int, size_t>, void *> blocks;      // (device, capacity in bytes) -> pointer
+static size_t kept = 0;
+constexpr size_t kMaxKept = (size_t)8 << 30;
+static void *take(int dev, size_t bytes, size_t &cap) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = blocks.lower_bound({dev, bytes});
+  if (it == blocks.end() || it->first.first != dev || it->first.second > 2 * bytes + 4096) return nullptr;
+  void *p = it->second; cap = it->first.second; kept -= cap;
+  blocks.erase(it);
+  return p;
+}
+static bool give(int dev, void *p, size_t cap) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (kept + cap > kMaxKept) return false;
+  blocks.emplace(std::make_pair(dev, cap), p); kept += cap;
+  return true;
+}
+static void release_all() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &b : blocks) (void)hipFree(b.second);
+  blocks.clear(); kept = 0;
+}
+}  // namespace devpool
+
 template <class T>
 struct DevBuf {
   T *p = nullptr; size_t n = 0;
+  size_t cap = 0;            // bytes of the underlying block
+  int dev = 0;               // the device it lives on
   int alloc(size_t count) {
     free();
     n = count;
     if (!count) return 0;
-    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (void *q = devpool::take(dev, bytes, cap)) { p = (T *)q; return 0; }
+    hipError_t e = hipMalloc((void **)&p, bytes);
+    if (e != hipSuccess) {          // the kept blocks may be what is in the way
+      devpool::release_all();
+      e = hipMalloc((void **)&p, bytes);
+    }
     if (e != hipSuccess) { p = nullptr; g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return MI_OSQP_ERR_ALLOC; }
+    cap = bytes;
     return 0;
   }
   int zero(hipStream_t s) { if (n && hipMemsetAsync(p, 0, n * sizeof(T), s) != hipSuccess) return MI_OSQP_ERR_DEVICE; return 0; }
@@ -93,7 +134,7 @@ struct DevBuf {
     if (v.size() && hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return MI_OSQP_ERR_DEVICE;
     return 0;
   }
-  void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void free() { if (p && !devpool::give(dev, p, cap)) (void)hipFree(p); p = nullptr; n = 0; cap = 0; }
   ~DevBuf() { free(); }
 };
 
@@ -162,7 +203,7 @@ struct mi_osqp_batch {
     if (h_npos) (void)hipHostFree(h_npos);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }   // (the buffers go back to the pool right after)
   }
 };
 
@@ -847,6 +888,7 @@ int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m, co
 }
 
 void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }
+void mi_osqp_release_device_cache(void) { devpool::release_all(); }
 
 int mi_osqp_batch_solve(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
