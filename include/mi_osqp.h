@@ -98,6 +98,7 @@ typedef struct {
   int64_t lds_bytes, threads_per_block;
   int64_t dense_tail_rows, dense_tail_slots;   /* trailing rows served by the inverted Schur complement (0 = none), its stream slots */
   double  setup_seconds_host, setup_seconds_factor, setup_seconds_upload;
+  int64_t nnz_L_before_tail;   /* entries of L in the columns before the dense tail (= nnz_L without one): what the two sweeps stream */
 } mi_osqp_stats;
 
 typedef struct mi_osqp_solver mi_osqp_solver; /* one QP  */
@@ -182,6 +183,32 @@ int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64
                                    double *device_seconds, double *refactor_seconds, int64_t *refactor_count,
                                    double *compact_seconds);
 
+/* ---------------------------------------------------------- multi-GPU batch
+ * The batch is the shard axis across the GPUs of a node (the runs of a planner are independent,
+ * [REF] src/gomp-solver.h:38-55): the B QPs are cut into n_devices contiguous blocks (the first B % n_devices one QP
+ * longer), block k lives on HIP device devices[k] (devices == NULL: 0 .. n_devices-1; a device may be listed more than
+ * once - two shards then share it), every call fans out over one host thread + stream per shard and joins.  There is
+ * no data-path collective; results come back QP-major in the order of the whole batch.  Arguments as for
+ * mi_osqp_batch_*; the return value is the first shard error (0 = ok). */
+typedef struct mi_osqp_multi mi_osqp_multi;
+int mi_osqp_multi_batch_setup(mi_osqp_multi **out, int64_t n_devices, const int64_t *devices,
+                              int64_t B, int64_t n, int64_t m,
+                              const int64_t *P_colptr, const int64_t *P_rowidx, const double *P_val,
+                              const double *q,
+                              const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                              const double *l, const double *u, const mi_osqp_settings *settings);
+int mi_osqp_multi_batch_update_A(mi_osqp_multi *h, const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val);
+int mi_osqp_multi_batch_update_bounds(mi_osqp_multi *h, const double *l, const double *u);
+int mi_osqp_multi_batch_warm_start_x(mi_osqp_multi *h, const double *x);
+int mi_osqp_multi_batch_solve(mi_osqp_multi *h);
+int mi_osqp_multi_batch_get_primal(mi_osqp_multi *h, double *x_out /*[B][n]*/);
+int mi_osqp_multi_batch_get_dual(mi_osqp_multi *h, double *y_out /*[B][m]*/);
+int mi_osqp_multi_batch_get_info(mi_osqp_multi *h, mi_osqp_info *info /*[B]*/);
+/* shard k: its device, its QP range [begin, end) and its single-device handle (owned by the multi handle) */
+int64_t mi_osqp_multi_batch_shards(mi_osqp_multi *h);
+int mi_osqp_multi_batch_shard(mi_osqp_multi *h, int64_t k, int64_t *device, int64_t *begin, int64_t *end, mi_osqp_batch **handle);
+void mi_osqp_multi_batch_free(mi_osqp_multi *h);
+
 /* ------------------------------------------------- the path's kernels as ops
  * (parity tests and roofline measurements call these; all pointers HBM)
  * KKT-structured SpMV on the scaled data: from x[B][n], y[B][m] compute
@@ -198,6 +225,9 @@ int mi_osqp_batch_refactor_device(mi_osqp_batch *h);
 /* average duration (ms) of the last `iterate` launches measured with HIP events
  * on the launch stream, and their count (bench.py's roofline leg). */
 int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launches);
+/* the same for the refactorisation kernels (row E13) since the last call: summed durations (ms, HIP events on the
+ * launch stream) of factor_kernel and of dense_inverse_kernel, their launches and the QPs they refactored. */
+int mi_osqp_batch_refactor_time(mi_osqp_batch *h, double *factor_ms, double *dense_inverse_ms, int64_t *launches, int64_t *qps);
 
 /* --------------------------------------------------- host-only diagnostics
  * No GPU needed: analyse a pattern + one value set and replay the DEVICE

@@ -51,7 +51,8 @@ class Stats(C.Structure):
                 ("n", "m", "N", "batch", "tile", "n_tiles", "nnz_P_triu", "nnz_A", "nnz_KKT", "nnz_L",
                  "n_supernodes", "n_blocks", "fwd_levels", "bwd_levels", "fwd_slots", "bwd_slots",
                  "chk_slots", "lds_bytes", "threads_per_block", "dense_tail_rows", "dense_tail_slots")] + \
-               [(k, C.c_double) for k in ("setup_seconds_host", "setup_seconds_factor", "setup_seconds_upload")]
+               [(k, C.c_double) for k in ("setup_seconds_host", "setup_seconds_factor", "setup_seconds_upload")] + \
+               [("nnz_L_before_tail", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -101,6 +102,7 @@ def lib():
         L.mi_osqp_batch_spmv.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.mi_osqp_batch_kkt_solve.argtypes = [vp, vp, vp, vp]
         L.mi_osqp_batch_kernel_time.argtypes = [vp, dp, ip]
+        L.mi_osqp_batch_refactor_time.argtypes = [vp, dp, dp, ip, ip]
         L.mi_osqp_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, ip, ip, dp, dp, ip, ip, dp, dp, dp, C.POINTER(Settings)]
         L.mi_osqp_update_A.argtypes = [vp, ip, ip, dp]
         L.mi_osqp_update_bounds.argtypes = [vp, dp, dp]
@@ -110,6 +112,18 @@ def lib():
         L.mi_osqp_get_dual.argtypes = [vp, dp]
         L.mi_osqp_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mi_osqp_free.argtypes = [vp]; L.mi_osqp_free.restype = None
+        L.mi_osqp_multi_batch_setup.argtypes = [C.POINTER(vp), C.c_int64, ip, C.c_int64, C.c_int64, C.c_int64, ip, ip, dp, dp,
+                                                ip, ip, dp, dp, dp, C.POINTER(Settings)]
+        L.mi_osqp_multi_batch_update_A.argtypes = [vp, ip, ip, dp]
+        L.mi_osqp_multi_batch_update_bounds.argtypes = [vp, dp, dp]
+        L.mi_osqp_multi_batch_warm_start_x.argtypes = [vp, dp]
+        L.mi_osqp_multi_batch_solve.argtypes = [vp]
+        L.mi_osqp_multi_batch_get_primal.argtypes = [vp, dp]
+        L.mi_osqp_multi_batch_get_dual.argtypes = [vp, dp]
+        L.mi_osqp_multi_batch_get_info.argtypes = [vp, C.POINTER(Info)]
+        L.mi_osqp_multi_batch_shards.argtypes = [vp]; L.mi_osqp_multi_batch_shards.restype = C.c_int64
+        L.mi_osqp_multi_batch_shard.argtypes = [vp, C.c_int64, ip, ip, ip, C.POINTER(vp)]
+        L.mi_osqp_multi_batch_free.argtypes = [vp]; L.mi_osqp_multi_batch_free.restype = None
         L.mi_osqp_debug_host_kkt_solve.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
                                                    C.POINTER(Settings), C.c_int64, dp, dp, dp, C.POINTER(Stats)]
         L.mi_osqp_debug_host_block_factor.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
@@ -274,6 +288,12 @@ class BatchSolver:
         _chk(lib().mi_osqp_batch_kernel_time(self._h, C.byref(ms), C.byref(cnt)), "kernel_time")
         return ms.value, cnt.value
 
+    def refactor_time(self):
+        """(factor_kernel ms, dense_inverse_kernel ms, launches, QPs refactored) since the last call."""
+        f, d, ln, nq = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
+        _chk(lib().mi_osqp_batch_refactor_time(self._h, C.byref(f), C.byref(d), C.byref(ln), C.byref(nq)), "refactor_time")
+        return f.value, d.value, ln.value, nq.value
+
     # ---- device-resident variants (torch tensors on the solver's GPU)
     def solve_device(self, x_out=None, status=None, iters=None, stream=None):
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
@@ -311,6 +331,76 @@ class BatchSolver:
     def kkt_solve_device(self, rhs, sol, stream=None):
         _chk(lib().mi_osqp_batch_kkt_solve(self._h, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()),
                                            None if stream is None else C.c_void_p(stream)), "kkt_solve")
+
+
+class MultiBatchSolver:
+    """The batch sharded over several HIP devices inside ONE process (mi_osqp_multi_batch_*: block partition, one host
+    thread per shard, no data-path collective).  `devices` may list a device more than once."""
+
+    def __init__(self, P_pattern, Px, q, A_pattern, Ax, l, u, devices=(0,), **settings):
+        L = lib()
+        P, A = _csc(P_pattern), _csc(A_pattern)
+        self.n, self.m = A.shape[1], A.shape[0]
+        Px, Ax, l, u = _f64(Px), _f64(Ax), _f64(l), _f64(u)
+        self.B = Ax.shape[0]
+        q = None if q is None else _f64(q)
+        self._Pp, self._Pi = _i64(P.indptr), _i64(P.indices)
+        self._Ap, self._Ai = _i64(A.indptr), _i64(A.indices)
+        self.settings = default_settings(**settings)
+        devs = _i64(list(devices))
+        self._h = C.c_void_p()
+        _chk(L.mi_osqp_multi_batch_setup(C.byref(self._h), len(devs), _ip(devs), self.B, self.n, self.m, _ip(self._Pp),
+                                         _ip(self._Pi), _dp(Px), _dp(q), _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(l), _dp(u),
+                                         C.byref(self.settings)), "mi_osqp_multi_batch_setup")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().mi_osqp_multi_batch_free(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    close = __del__
+
+    def shards(self):
+        out = []
+        for k in range(lib().mi_osqp_multi_batch_shards(self._h)):
+            d, b, e = C.c_int64(), C.c_int64(), C.c_int64()
+            _chk(lib().mi_osqp_multi_batch_shard(self._h, k, C.byref(d), C.byref(b), C.byref(e), None), "shard")
+            out.append((d.value, b.value, e.value))
+        return out
+
+    def solve(self):
+        _chk(lib().mi_osqp_multi_batch_solve(self._h), "mi_osqp_multi_batch_solve")
+        return self.info()
+
+    def info(self):
+        arr = (Info * self.B)()
+        _chk(lib().mi_osqp_multi_batch_get_info(self._h, arr), "multi get_info")
+        return list(arr)
+
+    def primal(self):
+        x = np.empty((self.B, self.n))
+        _chk(lib().mi_osqp_multi_batch_get_primal(self._h, _dp(x)), "multi get_primal")
+        return x
+
+    def dual(self):
+        y = np.empty((self.B, self.m))
+        _chk(lib().mi_osqp_multi_batch_get_dual(self._h, _dp(y)), "multi get_dual")
+        return y
+
+    def update_A(self, Ax):
+        Ax = _f64(Ax).reshape(self.B, -1)
+        _chk(lib().mi_osqp_multi_batch_update_A(self._h, _ip(self._Ap), _ip(self._Ai), _dp(Ax)), "multi update_A")
+
+    def update_bounds(self, l, u):
+        l, u = _f64(l).reshape(self.B, -1), _f64(u).reshape(self.B, -1)
+        _chk(lib().mi_osqp_multi_batch_update_bounds(self._h, _dp(l), _dp(u)), "multi update_bounds")
+
+    def warm_start_x(self, x):
+        x = _f64(x).reshape(self.B, -1)
+        _chk(lib().mi_osqp_multi_batch_warm_start_x(self._h, _dp(x)), "multi warm_start_x")
 
 
 class QPSolver:

@@ -124,6 +124,7 @@ hipError_t launch_swap_int(int *base, const int2 *pairs, int npairs, int len, in
 hipError_t launch_swap_sched(double *base, const int2 *pairs, int npairs, const SchedDev &sd, int BT, hipStream_t st);
 hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st);
 hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
+hipError_t launch_fail_slots(const KernelArgs &a, const int *slots, int nfail, int BT, int iter, hipStream_t st);
 hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,
                          const double *rho_vec, const double *dscal, int *changed, int B, int m, int BT,
                          int scaling, hipStream_t st);

@@ -32,6 +32,13 @@ namespace miosqp {
 #define MI_RHO_MIN 1e-6
 #define MI_RHO_MAX 1e6
 #define MI_NOROW 0xFFFFFFFFu
+// Timing experiments that skip parts of the refactorisation (wrong results by design) exist only in a diagnostic build
+// (MI_OSQP_CXXFLAGS=-DMI_OSQP_DEBUG_BUILD, scripts/profile_factor.py); the product binary has no such switch.
+#ifdef MI_OSQP_DEBUG_BUILD
+#define MI_DBG_SKIP(a) ((a).debug_skip)
+#else
+#define MI_DBG_SKIP(a) 0
+#endif
 
 template <int BT>
 struct VecBT;
@@ -732,7 +739,9 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
     double e = rho * sqrt(pr / du);
     return fmin(fmax(e, MI_RHO_MIN), MI_RHO_MAX);
   };
-  if (!done && new_status == 0 && is_rho) {
+  // (at max_iter on a rho-update iteration that is not a check iteration upstream adapts rho BEFORE its final
+  //  check_termination: the update happens even when that check then reports "solved")
+  if (!done && is_rho && (new_status == 0 || (is_last && !is_check))) {
     const double rn = rho_estimate();
     rho_est = rn;
     if (rn > rho * a.rho_tolerance || rn < rho / a.rho_tolerance) {
@@ -750,7 +759,8 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   if (!done && new_status != 0) {
     // ---- E14: store_solution
     done = 1; status = new_status;
-    if (!need_refactor) rho_est = rho_estimate();
+    rho_est = rho_estimate();            // upstream's closing compute_rho_estimate: with the rho in force now
+
     if (tid < BT) {
       p.dscal[DS_PRI_RES * BT + b] = pri_res; p.dscal[DS_DUA_RES * BT + b] = dua_res;
       p.dscal[DS_OBJ * BT + b] = (status == -3 || status == 3) ? MI_INFTY
@@ -1093,7 +1103,7 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
   // ---- rank-1 sources (one-column chunks), 8 per batch: all operand loads of a batch are in flight
   // together, the 8 scaled B columns go through wave-private LDS; group hh applies members g = hh mod H
   constexpr int G = 8;                     // rank-1 sources per batch (16 at BT = 1 fits the registers but is not faster)
-  for (uint32_t q = q0; q < ((a.debug_skip & 1) ? q0 : qm); q += G) {
+  for (uint32_t q = q0; q < ((MI_DBG_SKIP(a) & 1) ? q0 : qm); q += G) {
     double av[G / H], bv[G / H];
 #pragma unroll
     for (int gg = 0; gg < G / H; gg++) {
@@ -1122,7 +1132,7 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
     wave_sync();
   }
   // ---- general sources (width > 1): group hh handles the columns k = hh mod H
-  for (uint32_t q = qm; q < ((a.debug_skip & 2) ? qm : q1); q++) {
+  for (uint32_t q = qm; q < ((MI_DBG_SKIP(a) & 2) ? qm : q1); q++) {
     const uint32_t ao = tri4[4 * q], bo = tri4[4 * q + 1], kc0 = tri4[4 * q + 2], pk = tri4[4 * q + 3];
     const uint32_t ah = pk >> 16, aw = (pk >> 8) & 255u, bh = pk & 255u;
     // all operand loads of the triple are issued up front (fixed unroll, predicated):
@@ -1324,9 +1334,9 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
       for (uint32_t t = lv[0] + wave; t < lv[1]; t += nw) fct_update<BT>(a, Lb, Dl, Ss, t, lane);
       __syncthreads();
     }
-    if (!(a.debug_skip & 4)) for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
+    if (!(MI_DBG_SKIP(a) & 4)) for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
     __syncthreads();
-    if (lv[5] > lv[4] && !(a.debug_skip & 8)) {
+    if (lv[5] > lv[4] && !(MI_DBG_SKIP(a) & 8)) {
       for (uint32_t t = lv[4] + wave; t < lv[5]; t += nw) fct_trsm<BT>(a, Lb, Dl, dnew, Ss, t, lane);
       __syncthreads();
     }
@@ -1339,10 +1349,10 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     if (npos) atomicAdd(&s_npos[b], npos);
     __syncthreads();
     if (tid < BT && slot >= 0) a.npos[slot] = s_npos[b];
-    if (tid < BT && flag && s_npos[b] != a.n && !a.debug_skip && !a.dt_k) bad_inertia = 1;   // (dense tail: dense_inverse_kernel adds its pivots and checks)
+    if (tid < BT && flag && s_npos[b] != a.n && !MI_DBG_SKIP(a) && !a.dt_k) bad_inertia = 1;   // (dense tail: dense_inverse_kernel adds its pivots and checks)
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
-  if (flag && !(a.debug_skip & 16)) {
+  if (flag && !(MI_DBG_SKIP(a) & 16)) {
     double *fv = a.fwd_val + (size_t)slot * a.fwd.n_steps * 64, *bv = a.bwd_val + (size_t)slot * a.bwd.n_steps * 64;   // this thread's QP stream
     auto scatter = [&](double *dst, const int32_t *map, uint32_t n_slots) {
       constexpr int US = 4;                 // table reads, then value reads, then stores: 4 independent chains per thread
@@ -1622,6 +1632,35 @@ __global__ void gather_status_kernel(const int *__restrict__ iscal, int32_t *sta
   if (status) status[q] = t[IS_STATUS * BT + q % BT];
   if (iters) iters[q] = t[IS_ITER * BT + q % BT];
 }
+// Per-QP failure isolation (the KKT factor of a QP lost its inertia): the listed slots become kNonConvex - done, status -7,
+// NaN solution, objective NaN, cold-started iterates ([EXT] store_solution of a status without solution) - and the batch
+// goes on without them.  One workgroup per failed slot.
+__global__ void fail_slots_kernel(KernelArgs a, const int *__restrict__ slots, int BT, int iter) {
+  const int slot = slots[blockIdx.x], tid = threadIdx.x, nthr = blockDim.x;
+  if (slot < 0) return;
+  const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
+  const int qp = a.qp_of_slot ? a.qp_of_slot[slot] : slot;
+  const double nanv = __builtin_nan("");
+  for (int i = tid; i < a.n; i += nthr) {
+    a.x[(tile * a.n + i) * BT + b] = 0.0;
+    if (qp >= 0 && qp < a.B) a.x_out[(size_t)qp * a.n + i] = nanv;
+  }
+  for (int j = tid; j < a.m; j += nthr) {
+    a.z[(tile * a.m + j) * BT + b] = 0.0; a.y[(tile * a.m + j) * BT + b] = 0.0;
+    if (qp >= 0 && qp < a.B) a.y_out[(size_t)qp * a.m + j] = nanv;
+  }
+  if (tid == 0) {
+    int *is = a.iscal + tile * IS_COUNT * BT;
+    is[IS_DONE * BT + b] = 1; is[IS_STATUS * BT + b] = -7; is[IS_NEED_REFACTOR * BT + b] = 0; is[IS_ITER * BT + b] = iter;
+    double *ds = a.dscal + tile * DS_COUNT * BT;
+    ds[DS_OBJ * BT + b] = nanv; ds[DS_PRI_RES * BT + b] = nanv; ds[DS_DUA_RES * BT + b] = nanv;
+  }
+}
+hipError_t launch_fail_slots(const KernelArgs &a, const int *slots, int nfail, int BT, int iter, hipStream_t st) {
+  if (!nfail) return hipSuccess;
+  hipLaunchKernelGGL(fail_slots_kernel, dim3(nfail), dim3(256), 0, st, a, slots, BT, iter);
+  return hipGetLastError();
+}
 // bounds update on device: l,u <- E .* clip(l,u); flags a constraint-type change
 __global__ void bounds_kernel(const double *__restrict__ gl, const double *__restrict__ gu, double *l, double *u,
                               const double *__restrict__ Esc, const double *__restrict__ rho_vec,
@@ -1696,8 +1735,12 @@ hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads,
   const size_t total = ((size_t)a.xs_len + 2 * (size_t)a.dt.k) * BT * sizeof(double) + (size_t)words * 4;
   if (total > 160 * 1024) return hipErrorInvalidValue;
   (void)lds;
+#ifdef MI_OSQP_DEBUG_BUILD
   const bool waits = getenv("MI_OSQP_TRACE_WAITS") != nullptr;     // per-step ring-wait timing (slows every step down)
   auto kern = waits ? &kkt_trace_kernel<2> : &kkt_trace_kernel<1>;
+#else
+  auto kern = &kkt_trace_kernel<1>;
+#endif
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)total);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), total, st, a, rhs, sol, trace, words);

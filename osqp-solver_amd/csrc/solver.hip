@@ -38,6 +38,18 @@ static thread_local std::string g_last_error;
     }                                                                                    \
   } while (0)
 
+// Every entry point that touches the device runs with the handle's device current and restores the caller's afterwards:
+// a handle may be used from any host thread, whatever device that thread had selected.
+struct DevGuard {
+  int prev = -1; bool switched = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+  DevGuard(const DevGuard &) = delete;
+  DevGuard &operator=(const DevGuard &) = delete;
+};
+
 static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -190,20 +202,29 @@ struct mi_osqp_batch {
   DevBuf<double> stage; DevBuf<int> ids, work;
   int *h_iscal = nullptr;     // pinned
   double *h_dscal = nullptr;  // pinned
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evf0 = nullptr, evf1 = nullptr, evf2 = nullptr;
+  double factor_ms_sum = 0.0, dense_ms_sum = 0.0;
+  int64_t refactor_launches = 0, refactor_qps = 0;
   mi_osqp_stats stats{};
   // last-solve accounting
   int64_t last_total_iters = 0, last_launches = 0, last_refactors = 0;
   double last_device_s = 0.0, last_refactor_s = 0.0, last_compact_s = 0.0, kernel_ms_sum = 0.0;
   int64_t kernel_launches = 0, kernel_qp_iters = 0;
   bool solved_once = false;
+  // per-QP failure isolation: QPs whose KKT factor lost its inertia (at setup, in an update or in a rho update).  They
+  // report kNonConvex with a NaN solution on every solve until a later refactorisation of theirs succeeds; the rest
+  // of the batch is unaffected ([REF] src/osqp-wrapper.h:51-54: solve() never throws, one exit code per solver).
+  std::vector<char> failed;
+  DevBuf<int> fail_list;
   ~mi_osqp_batch() {
+    DevGuard guard(device);
     if (h_iscal) (void)hipHostFree(h_iscal);
     if (h_dscal) (void)hipHostFree(h_dscal);
     if (h_npos) (void)hipHostFree(h_npos);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
-    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }   // (the buffers go back to the pool right after)
+    for (hipEvent_t e : {evf0, evf1, evf2}) if (e) (void)hipEventDestroy(e);
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }   // (the buffers go back to the pool right after: DevBuf remembers its device)
   }
 };
 
@@ -273,7 +294,9 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
   a.sigma = h->st.sigma; a.home_bt = h->BT; a.dt_k = an.dt.k;
-  { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }
+#ifdef MI_OSQP_DEBUG_BUILD
+  { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }      // timing experiments, diagnostic build only
+#endif
   return a;
 }
 
@@ -435,6 +458,8 @@ static int reset_solve_state(mi_osqp_batch *h, bool cold) {
 
 // ------------------------------------------------------------------- setup
 
+static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
+
 static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
                             const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai,
                             const double *Av, const double *l, const double *u, int64_t device) {
@@ -479,16 +504,20 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if (rc) return rc;
   const Analysis &an = h->an;
   h->B = (int)B;
+  h->failed.assign((size_t)B, 0);
   // ---- device
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_last_error = "no HIP device visible"; return MI_OSQP_ERR_DEVICE; }
-  if (device >= 0) { HIPCHK(hipSetDevice((int)device)); h->device = (int)device; } else HIPCHK(hipGetDevice(&h->device));
+  if (device >= ndev) { g_last_error = "no such HIP device"; return MI_OSQP_ERR_DEVICE; }
+  if (device >= 0) h->device = (int)device; else HIPCHK(hipGetDevice(&h->device));
+  DevGuard guard(h->device);            // (the caller's current device is restored when setup returns)
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
   h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_last_error = std::string("device is not gfx950: ") + prop.gcnArchName; return MI_OSQP_ERR_DEVICE; }
   HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+  HIPCHK(hipEventCreate(&h->evf0)); HIPCHK(hipEventCreate(&h->evf1)); HIPCHK(hipEventCreate(&h->evf2));
   h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT);
   h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.Next + 2 * an.dt.k, BT, h->threads);
   if (h->lds > lds_cap) { g_last_error = "internal: LDS budget exceeded"; return MI_OSQP_ERR_ALLOC; }
@@ -627,7 +656,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   // streams of every QP (the kernel every later rho / A update uses); a wrong inertia comes back as an error
   {
     double tb = now_s();
-    if ((rc = mi_osqp_batch_refactor_device(h))) return rc;
+    std::vector<int> all(B);
+    for (int i = 0; i < (int)B; i++) all[i] = i;
+    if ((rc = refactor_qps(h, std::move(all)))) return rc;
     t_factor += now_s() - tb;
   }
   if ((rc = reset_solve_state(h, true))) return rc;
@@ -642,6 +673,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   s.lds_bytes = (int64_t)h->lds; s.threads_per_block = h->threads;
   s.dense_tail_rows = an.dt.k; s.dense_tail_slots = (int64_t)an.dt.n_steps * 64;
   s.setup_seconds_host = t1 - t0; s.setup_seconds_factor = t_factor; s.setup_seconds_upload = t_upload;
+  s.nnz_L_before_tail = an.dt.k ? an.Lp[an.dt.s] : an.nnzL();
   if (getenv("MI_OSQP_DEBUG_TIMING"))
     fprintf(stderr, "[mi_osqp] setup B=%d N=%d: analysis+alloc %.1f ms (analysis %.1f), numeric %.1f ms, upload %.1f ms, rest %.1f ms\n", (int)B, an.N,
             1e3 * (t1 - t0), 1e3 * t_analysis, 1e3 * t_factor, 1e3 * t_upload, 1e3 * (now_s() - t1 - t_factor - t_upload));
@@ -650,9 +682,24 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
 
 // ------------------------------------------------------------------- solve
 
+// Per-QP failure isolation: the slots of `bad` (slot = tile * BT + b; outside a solve slot == QP) become kNonConvex on
+// the device (fail_slots_kernel) and are remembered in h->failed.  qp_of_slot: the slot -> QP table of a solve in flight.
+static int fail_slots(mi_osqp_batch *h, KernelArgs a, const std::vector<int> &bad, const std::vector<int> *qp_of_slot, int iter) {
+  if (bad.empty()) return 0;
+  int rc;
+  if (h->fail_list.n < bad.size() && (rc = h->fail_list.alloc(std::max<size_t>(bad.size(), (size_t)h->ntiles * h->BT)))) return rc;
+  if (!qp_of_slot) a.qp_of_slot = nullptr;                   // identity layout
+  HIPCHK(hipMemcpyAsync(h->fail_list.p, bad.data(), bad.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(launch_fail_slots(a, h->fail_list.p, (int)bad.size(), h->BT, iter, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int s : bad) { const int q = qp_of_slot ? (*qp_of_slot)[s] : s; if (q >= 0 && q < h->B) h->failed[q] = 1; }
+  return 0;
+}
+
 // Row E13 on the device for a list of slots (tile * BT + b): rho vector from the current bounds and rho, KKT
 // assembly, block LDL', scatter into the solve streams.  The work list packs the slots kbt per workgroup.
-static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
+// Slots whose new factor has the wrong inertia are appended to *bad (the caller isolates them).
+static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::vector<int> *bad) {
   if (work.empty()) return 0;
   const int BT = h->BT;
   int rc;
@@ -668,7 +715,9 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
   if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT + 4))) return rc;
   HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   fa.work = h->work.p;
+  HIPCHK(hipEventRecord(h->evf0, h->stream));
   HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
+  HIPCHK(hipEventRecord(h->evf1, h->stream));
   if (h->an.dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
     const DenseTail &dt = h->an.dt;
     DenseInvArgs da{};
@@ -682,16 +731,37 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work) {
     { const char *e = getenv("MI_OSQP_DENSE_THREADS"); if (e) dthreads = std::max(512, std::min(1024, atoi(e) / 64 * 64)); }
     HIPCHK(launch_dense_inverse(da, wtiles * kbt, dthreads, h->stream));
   }
+  HIPCHK(hipEventRecord(h->evf2, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  {
+    float f = 0.f, d = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, h->evf0, h->evf1)); HIPCHK(hipEventElapsedTime(&d, h->evf1, h->evf2));
+    h->factor_ms_sum += f; h->dense_ms_sum += h->an.dt.k ? d : 0.0; h->refactor_launches++; h->refactor_qps += nq;
+  }
   for (int s : work)            // (only the listed slots: at setup the flags of padding slots are not initialised yet)
     if (s >= 0 && h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
       if (getenv("MI_OSQP_DEBUG_TIMING")) {
         (void)hipMemcpy(h->h_npos, h->npos.p, (size_t)h->ntiles * BT * sizeof(int), hipMemcpyDeviceToHost);
         fprintf(stderr, "[mi_osqp] slot %d: %d positive pivots, expected %d\n", s, h->h_npos[s], h->an.n);
       }
-      g_last_error = "the KKT factor lost its inertia"; return MI_OSQP_ERR_NONCONVEX;
+      if (bad) bad->push_back(s);
     }
+  return 0;
+}
+
+// Refactorisation outside a solve (setup, update_A, constraint-type changes; slot == QP): QPs whose factor loses its
+// inertia are isolated (kNonConvex on every solve until a later refactorisation of theirs succeeds); the call fails
+// only when that happens to EVERY QP of the handle (a single QP: OsqpSolver::Init / the update reports the error).
+static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps) {
+  if (qps.empty()) return 0;
+  std::vector<int> bad;
+  const std::vector<int> listed = qps;
+  int rc = device_refactor_slots(h, std::move(qps), &bad);
+  if (rc) return rc;
+  for (int q : listed) h->failed[q] = 0;
+  if ((rc = fail_slots(h, make_args(h), bad, nullptr, 0))) return rc;
+  if ((int)bad.size() == h->B) { g_last_error = "the KKT factor lost its inertia"; return MI_OSQP_ERR_NONCONVEX; }
   return 0;
 }
 
@@ -717,10 +787,10 @@ static int apply_swaps(mi_osqp_batch *h, const std::vector<int2> &pairs) {
 
 // The ADMM loop runs in segments that end at every termination-check / rho-update
 // point: iterate_kernel (E6-E10) -> check_kernel (E11-E14) -> host reads the flags,
-// compacts the QPs still iterating into the leading tiles (slot swaps on the device),
-// runs the device refactorisation for the QPs whose rho changed, and continues with a
-// smaller grid.  The swaps are undone at the end, so outside a solve every array is in
-// the identity layout.
+// (optionally) compacts the QPs still iterating into the leading tiles (slot swaps on the device),
+// runs the device refactorisation for the QPs whose rho changed, and continues.
+// The swaps are undone at the end - also when the loop ends with an error - so outside a solve
+// every array is in the identity layout.
 static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream) {
   hipStream_t keep = h->stream;
   struct Restore { mi_osqp_batch *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, keep};
@@ -736,90 +806,110 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
   std::vector<int> qp_of_slot(nslots);
   for (int s = 0; s < nslots; s++) qp_of_slot[s] = s < h->B ? s : -1;
   HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, qp_of_slot.data(), nslots * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  {     // QPs without a valid factor (isolated earlier) are kNonConvex from the start
+    std::vector<int> bad;
+    for (int q = 0; q < h->B; q++) if (h->failed[q]) bad.push_back(q);
+    if ((rc = fail_slots(h, a, bad, &qp_of_slot, 0))) return rc;
+  }
   std::vector<std::vector<int2>> rounds;
   // compaction (re-pairing the QPs still iterating into fewer tiles) is implemented and tested but OFF by default:
   // since the value streams are per QP, a finished QP costs no bytes anyway, and moving data only breaks even
   const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr || h->an.dt.k != 0;      // (and not combined with the dense tail)
-  int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
-  while (true) {
-    int seg_end = (int)S.max_iter;
-    if (S.check_termination > 0) seg_end = std::min<int64_t>(seg_end, (iter / S.check_termination + 1) * S.check_termination);
-    if (S.adaptive_rho && S.adaptive_rho_interval > 0)
-      seg_end = std::min<int64_t>(seg_end, (iter / S.adaptive_rho_interval + 1) * S.adaptive_rho_interval);
-    a.iter_begin = iter; a.iter_end = seg_end; a.info_at_end = 1;
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(launch_iterate(a, BT, ntl, h->threads, h->lds, h->stream));
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(launch_check(a, BT, ntl, h->threads, h->lds, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
-    h->kernel_qp_iters += 0;
-    iter = seg_end;
-    // slots still iterating / asking for a refactorisation.  A QP that runs into max_iter at a rho-update iteration
-    // has finished AND asks for its refactorisation: upstream adapts rho (and refactors) before it leaves the loop,
-    // and the next Solve() of a warm-started solver continues from that factor.
-    std::vector<int> active, work;
-    for (int s = 0; s < ntl * BT; s++) {
-      const int *t = h->h_iscal + (size_t)(s / BT) * IS_COUNT * BT;
-      if (qp_of_slot[s] < 0) continue;
-      if (!t[IS_DONE * BT + s % BT]) active.push_back(s);
-      if (t[IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
-    }
-    const int n_ref = (int)work.size();
-    if (active.empty() && !n_ref) break;
-    // ---- compaction
-    int target = ((int)active.size() + BT - 1) / BT;
-    bool compacted_now = false;
-    const int ntl_before = ntl;
-    if (!no_compact && target < ntl && !active.empty()) {
-      compacted_now = true;
-      double tc = now_s();
-      std::vector<char> is_active(ntl * BT, 0);
-      for (int s : active) is_active[s] = 1;
-      std::vector<int2> pairs;
-      int hole = 0;
-      for (int k = (int)active.size() - 1; k >= 0 && active[k] >= target * BT; k--) {
-        while (hole < target * BT && is_active[hole]) hole++;
-        pairs.push_back(int2{hole, active[k]});
-        std::swap(qp_of_slot[hole], qp_of_slot[active[k]]);
-        is_active[hole] = 1;
+  auto loop = [&]() -> int {
+    int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
+    while (true) {
+      int seg_end = (int)S.max_iter;
+      if (S.check_termination > 0) seg_end = std::min<int64_t>(seg_end, (iter / S.check_termination + 1) * S.check_termination);
+      if (S.adaptive_rho && S.adaptive_rho_interval > 0)
+        seg_end = std::min<int64_t>(seg_end, (iter / S.adaptive_rho_interval + 1) * S.adaptive_rho_interval);
+      a.iter_begin = iter; a.iter_end = seg_end; a.info_at_end = 1;
+      HIPCHK(hipEventRecord(h->ev0, h->stream));
+      HIPCHK(launch_iterate(a, BT, ntl, h->threads, h->lds, h->stream));
+      HIPCHK(hipEventRecord(h->ev1, h->stream));
+      HIPCHK(launch_check(a, BT, ntl, h->threads, h->lds, h->stream));
+      HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
+      iter = seg_end;
+      // slots still iterating / asking for a refactorisation.  A QP that runs into max_iter at a rho-update iteration
+      // has finished AND asks for its refactorisation: upstream adapts rho (and refactors) before it leaves the loop,
+      // and the next Solve() of a warm-started solver continues from that factor.
+      std::vector<int> active, work;
+      for (int s = 0; s < ntl * BT; s++) {
+        const int *t = h->h_iscal + (size_t)(s / BT) * IS_COUNT * BT;
+        if (qp_of_slot[s] < 0) continue;
+        if (!t[IS_DONE * BT + s % BT]) active.push_back(s);
+        if (t[IS_NEED_REFACTOR * BT + s % BT]) work.push_back(s);
       }
-      if ((rc = apply_swaps(h, pairs))) return rc;
-      HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, qp_of_slot.data(), nslots * sizeof(int), hipMemcpyHostToDevice, h->stream));
-      rounds.push_back(std::move(pairs));
-      ntl = target;
-      h->last_compact_s += now_s() - tc;
-    }
-    // ---- row E13 on the device: rho vector, KKT assembly, block LDL', scatter into the schedules
-    if (n_ref) {
-      double tr = now_s();
-      if (!compacted_now) {
-        // work list: the flagged slots of the whole batch (fewer, fuller tiles = fewer rounds over the CUs)
-        if ((rc = device_refactor_slots(h, std::move(work)))) return rc;
-      } else {
-        // after a compaction of this segment the host copy of the flags is stale: flag-driven sweep over the tiles
-        FactorArgs fa = make_factor_args(h, 0);
-        HIPCHK(launch_factor(fa, BT, ntl_before, factor_threads(), h->stream));
-        HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl_before * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        for (int s = 0; s < ntl_before * BT; s++)
-          if (h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
-            g_last_error = "rho update made the KKT factor lose its inertia"; return MI_OSQP_ERR_NONCONVEX;
-          }
+      const int n_ref = (int)work.size();
+      if (active.empty() && !n_ref) break;
+      // ---- compaction
+      int target = ((int)active.size() + BT - 1) / BT;
+      bool compacted_now = false;
+      const int ntl_before = ntl;
+      std::vector<int> bad;             // slots whose refactorisation lost the inertia: isolated below
+      if (!no_compact && target < ntl && !active.empty()) {
+        compacted_now = true;
+        double tc = now_s();
+        std::vector<char> is_active(ntl * BT, 0);
+        for (int s : active) is_active[s] = 1;
+        std::vector<int2> pairs;
+        int hole = 0;
+        for (int k = (int)active.size() - 1; k >= 0 && active[k] >= target * BT; k--) {
+          while (hole < target * BT && is_active[hole]) hole++;
+          pairs.push_back(int2{hole, active[k]});
+          std::swap(qp_of_slot[hole], qp_of_slot[active[k]]);
+          is_active[hole] = 1;
+        }
+        int rc2 = apply_swaps(h, pairs);
+        rounds.push_back(std::move(pairs));              // (recorded first: the caller undoes whatever part was applied)
+        if (rc2) return rc2;
+        HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, qp_of_slot.data(), nslots * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        ntl = target;
+        h->last_compact_s += now_s() - tc;
       }
-      h->host_rho_stale = true;
-      h->last_refactors += n_ref;
-      h->last_refactor_s += now_s() - tr;
+      // ---- row E13 on the device: rho vector, KKT assembly, block LDL', scatter into the schedules
+      if (n_ref) {
+        double tr = now_s();
+        int rc2;
+        if (!compacted_now) {
+          // work list: the flagged slots of the whole batch (fewer, fuller tiles = fewer rounds over the CUs)
+          if ((rc2 = device_refactor_slots(h, std::move(work), &bad))) return rc2;
+        } else {
+          // after a compaction of this segment the host copy of the flags is stale: flag-driven sweep over the tiles
+          FactorArgs fa = make_factor_args(h, 0);
+          HIPCHK(launch_factor(fa, BT, ntl_before, factor_threads(), h->stream));
+          HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl_before * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+          HIPCHK(hipStreamSynchronize(h->stream));
+          for (int s = 0; s < ntl_before * BT; s++)
+            if (qp_of_slot[s] >= 0 && h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) bad.push_back(s);
+        }
+        // a rho update that makes the factor lose its inertia ends THAT QP as kNonConvex ([EXT] osqp_solve: adapt_rho
+        // fails -> OSQP_NON_CVX, break); every other QP of the batch goes on
+        if ((rc2 = fail_slots(h, a, bad, &qp_of_slot, iter))) return rc2;
+        h->host_rho_stale = true;
+        h->last_refactors += n_ref;
+        h->last_refactor_s += now_s() - tr;
+      }
+      if (!bad.empty()) {
+        // (with a compaction in this segment `active` holds pre-swap slot numbers: rebuild it from the table)
+        std::vector<char> isbad(nslots, 0);
+        for (int s : bad) isbad[s] = 1;
+        if (compacted_now) { active.clear(); for (int s = 0; s < ntl * BT; s++) if (qp_of_slot[s] >= 0 && !isbad[s]) active.push_back(s); }
+        else active.erase(std::remove_if(active.begin(), active.end(), [&](int s) { return isbad[s] != 0; }), active.end());
+      }
+      if (active.empty()) break;
     }
-    if (active.empty()) break;
-  }
-  // ---- undo the compaction (reverse order; swaps are involutions)
+    return MI_OSQP_OK;
+  };
+  rc = loop();
+  // ---- undo the compaction (reverse order; swaps are involutions) - also after an error, so that the handle stays usable
   {
     double tc = now_s();
-    for (int r = (int)rounds.size() - 1; r >= 0; r--) if ((rc = apply_swaps(h, rounds[r]))) return rc;
+    for (int r = (int)rounds.size() - 1; r >= 0; r--) { int rc2 = apply_swaps(h, rounds[r]); if (rc2 && !rc) rc = rc2; }
+    if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
     HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)nslots * IS_COUNT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->last_compact_s += now_s() - tc;
@@ -892,11 +982,13 @@ void mi_osqp_release_device_cache(void) { devpool::release_all(); }
 
 int mi_osqp_batch_solve(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   return solve_impl(h, nullptr, nullptr);
 }
 
 int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream) {
   if (!h) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   int rc = solve_impl(h, d_x_out, (hipStream_t)stream);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -910,17 +1002,20 @@ int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_sta
 
 int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x) {
   if (!h || !x) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   HIPCHK(hipMemcpy(x, h->x_out.p, (size_t)h->B * h->an.n * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OSQP_OK;
 }
 int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y) {
   if (!h || !y) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   if (h->an.m) HIPCHK(hipMemcpy(y, h->y_out.p, (size_t)h->B * h->an.m * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OSQP_OK;
 }
 
 int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info) {
   if (!h || !info) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
   HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
@@ -963,8 +1058,19 @@ int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launche
   return MI_OSQP_OK;
 }
 
+int mi_osqp_batch_refactor_time(mi_osqp_batch *h, double *factor_ms, double *dense_ms, int64_t *launches, int64_t *qps) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (factor_ms) *factor_ms = h->factor_ms_sum;
+  if (dense_ms) *dense_ms = h->dense_ms_sum;
+  if (launches) *launches = h->refactor_launches;
+  if (qps) *qps = h->refactor_qps;
+  h->factor_ms_sum = h->dense_ms_sum = 0.0; h->refactor_launches = h->refactor_qps = 0;
+  return MI_OSQP_OK;
+}
+
 int mi_osqp_batch_reset(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   h->clear_rho_updates = true;
   auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
     if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -983,6 +1089,7 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
 
 int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
   if (!h || !x) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   h->st.warm_start = 1;
   size_t cnt = (size_t)h->B * h->an.n;
   int rc = ensure_stage(h, cnt, 0);
@@ -996,6 +1103,7 @@ int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
 
 int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u) {
   if (!h || !l || !u) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   h->clear_rho_updates = true;
   const Analysis &an = h->an;
   int m = an.m, B = h->B, rc;
@@ -1014,13 +1122,14 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
   std::vector<int> all(B);
   for (int i = 0; i < B; i++) all[i] = i;
   if ((rc = upload_problem(h, all, false))) return rc;
-  if ((rc = device_refactor_slots(h, changed))) return rc;      // constraint types changed: new rho vector + factor on the device
+  if ((rc = refactor_qps(h, changed))) return rc;      // constraint types changed: new rho vector + factor on the device
   if (!changed.empty() && (rc = snapshot(h))) return rc;
   return MI_OSQP_OK;
 }
 
 int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream) {
   if (!h || !d_l || !d_u) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   h->clear_rho_updates = true;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   int m = h->an.m, B = h->B;
@@ -1048,6 +1157,7 @@ int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, cons
 
 int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   h->clear_rho_updates = true;
   const Analysis &an = h->an;
   int n = an.n, B = h->B, nnzA = an.Ap[n], rc;
@@ -1076,23 +1186,16 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
 
 int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
-  if (h->an.dt.k) {        // with a dense tail every refactorisation goes through the work list (factor + dense inverse per QP)
-    std::vector<int> all(h->B);
-    for (int i = 0; i < h->B; i++) all[i] = i;
-    return device_refactor_slots(h, std::move(all));
-  }
-  FactorArgs fa = make_factor_args(h, 1);
-  HIPCHK(launch_factor(fa, h->BT, h->ntiles, factor_threads(), h->stream));
-  HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * h->BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  for (int q = 0; q < h->B; q++)
-    if (h->h_iscal[(size_t)(q / h->BT) * IS_COUNT * h->BT + IS_NEED_REFACTOR * h->BT + q % h->BT] < 0) return MI_OSQP_ERR_NONCONVEX;
-  return MI_OSQP_OK;
+  DevGuard guard(h->device);
+  std::vector<int> all(h->B);
+  for (int i = 0; i < h->B; i++) all[i] = i;
+  return refactor_qps(h, std::move(all));
 }
 
 int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, double *d_Px, double *d_Aty, double *d_Ax,
                        void *stream) {
   if (!h) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
   if (h->sp_ptr.n && !getenv("MI_OSQP_SPMV_STREAM")) {      // one read of P and A for all three products
@@ -1116,6 +1219,7 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
 
 int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol, void *stream) {
   if (!h || !d_rhs || !d_sol) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
   HIPCHK(launch_kkt_solve(a, h->BT, h->ntiles, h->threads, h->lds, s, d_rhs, d_sol));
@@ -1126,6 +1230,7 @@ int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol
 int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double *d_rhs, double *d_sol, uint32_t *out,
                                   int64_t cap, int64_t *dims) {
   if (!h || !dims) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
   const int nw = h->threads / 64;
   const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 8 + 4 * nw + (fp + bp) * nw * 2;
   dims[0] = fp; dims[1] = bp; dims[2] = nw; dims[3] = words;
@@ -1183,6 +1288,108 @@ int mi_osqp_get_primal(mi_osqp_solver *h, double *x) { return h ? mi_osqp_batch_
 int mi_osqp_get_dual(mi_osqp_solver *h, double *y) { return h ? mi_osqp_batch_get_dual(h->b, y) : MI_OSQP_ERR_NULL; }
 int mi_osqp_get_stats(mi_osqp_solver *h, mi_osqp_stats *st) { return h ? mi_osqp_batch_get_stats(h->b, st) : MI_OSQP_ERR_NULL; }
 
+// ------------------------------------------------------------ multi-GPU batch
+// block partition of the batch over the devices, one host thread per shard, no data-path collective.
+
+}  // extern "C"
+
+struct mi_osqp_multi {
+  int64_t B = 0, n = 0, m = 0;
+  std::vector<int64_t> dev, begin;                 // begin has one entry more than there are shards
+  std::vector<mi_osqp_batch *> shard;
+  ~mi_osqp_multi() { for (mi_osqp_batch *b : shard) delete b; }
+  size_t count() const { return shard.size(); }
+};
+
+// run fn(shard index) on one host thread per shard; first error wins, its text becomes this thread's last error
+template <class F>
+static int multi_fan_out(mi_osqp_multi *h, F &&fn) {
+  const size_t ns = h->count();
+  std::vector<int> rcs(ns, 0);
+  std::vector<std::string> errs(ns);
+  auto body = [&](size_t k) { rcs[k] = fn(k); if (rcs[k]) errs[k] = g_last_error; };
+  if (ns == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < ns; k++) th.emplace_back(body, k);
+    for (auto &t : th) t.join();
+  }
+  for (size_t k = 0; k < ns; k++) if (rcs[k]) { g_last_error = "shard " + std::to_string(k) + ": " + errs[k]; return rcs[k]; }
+  return MI_OSQP_OK;
+}
+
+extern "C" {
+
+int mi_osqp_multi_batch_setup(mi_osqp_multi **out, int64_t n_devices, const int64_t *devices, int64_t B, int64_t n, int64_t m,
+                              const int64_t *Pp, const int64_t *Pi, const double *Pv, const double *q, const int64_t *Ap,
+                              const int64_t *Ai, const double *Av, const double *l, const double *u,
+                              const mi_osqp_settings *settings) {
+  if (!out) return MI_OSQP_ERR_NULL;
+  *out = nullptr;
+  if (n_devices <= 0 || B <= 0 || n <= 0 || m < 0 || !Pp || !Ap) return MI_OSQP_ERR_INVALID_DATA;
+  if (n_devices > B) n_devices = B;                 // never an empty shard
+  mi_osqp_multi *h = new (std::nothrow) mi_osqp_multi();
+  if (!h) return MI_OSQP_ERR_ALLOC;
+  h->B = B; h->n = n; h->m = m;
+  const int64_t base = B / n_devices, rem = B % n_devices;
+  h->begin.push_back(0);
+  for (int64_t k = 0; k < n_devices; k++) {
+    h->dev.push_back(devices ? devices[k] : k);
+    h->begin.push_back(h->begin.back() + base + (k < rem ? 1 : 0));
+  }
+  h->shard.assign((size_t)n_devices, nullptr);
+  const int64_t nnzP = Pp[n], nnzA = Ap[n];
+  int rc = multi_fan_out(h, [&](size_t k) -> int {
+    const int64_t b0 = h->begin[k], nb = h->begin[k + 1] - b0;
+    return mi_osqp_batch_setup(&h->shard[k], nb, n, m, Pp, Pi, Pv ? Pv + b0 * nnzP : nullptr, q ? q + b0 * n : nullptr, Ap, Ai,
+                               Av ? Av + b0 * nnzA : nullptr, l ? l + b0 * m : nullptr, u ? u + b0 * m : nullptr, settings, h->dev[k]);
+  });
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return MI_OSQP_OK;
+}
+
+void mi_osqp_multi_batch_free(mi_osqp_multi *h) { delete h; }
+int64_t mi_osqp_multi_batch_shards(mi_osqp_multi *h) { return h ? (int64_t)h->count() : 0; }
+int mi_osqp_multi_batch_shard(mi_osqp_multi *h, int64_t k, int64_t *device, int64_t *begin, int64_t *end, mi_osqp_batch **handle) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (k < 0 || k >= (int64_t)h->count()) return MI_OSQP_ERR_INVALID_DATA;
+  if (device) *device = h->shard[k]->device;
+  if (begin) *begin = h->begin[k];
+  if (end) *end = h->begin[k + 1];
+  if (handle) *handle = h->shard[k];
+  return MI_OSQP_OK;
+}
+int mi_osqp_multi_batch_update_A(mi_osqp_multi *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
+  if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
+  const int64_t nnzA = Ap[h->n];
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_update_A(h->shard[k], Ap, Ai, Av + h->begin[k] * nnzA); });
+}
+int mi_osqp_multi_batch_update_bounds(mi_osqp_multi *h, const double *l, const double *u) {
+  if (!h || !l || !u) return MI_OSQP_ERR_NULL;
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_update_bounds(h->shard[k], l + h->begin[k] * h->m, u + h->begin[k] * h->m); });
+}
+int mi_osqp_multi_batch_warm_start_x(mi_osqp_multi *h, const double *x) {
+  if (!h || !x) return MI_OSQP_ERR_NULL;
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_warm_start_x(h->shard[k], x + h->begin[k] * h->n); });
+}
+int mi_osqp_multi_batch_solve(mi_osqp_multi *h) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_solve(h->shard[k]); });
+}
+int mi_osqp_multi_batch_get_primal(mi_osqp_multi *h, double *x) {
+  if (!h || !x) return MI_OSQP_ERR_NULL;
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_get_primal(h->shard[k], x + h->begin[k] * h->n); });
+}
+int mi_osqp_multi_batch_get_dual(mi_osqp_multi *h, double *y) {
+  if (!h || !y) return MI_OSQP_ERR_NULL;
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_get_dual(h->shard[k], y + h->begin[k] * h->m); });
+}
+int mi_osqp_multi_batch_get_info(mi_osqp_multi *h, mi_osqp_info *info) {
+  if (!h || !info) return MI_OSQP_ERR_NULL;
+  return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_get_info(h->shard[k], info + h->begin[k]); });
+}
+
 // ------------------------------------------------------ host-only diagnostics
 
 int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const double *Pv,
@@ -1213,6 +1420,7 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const 
     st->fwd_levels = an.fwd.n_phases; st->bwd_levels = an.bwd.n_phases;
     st->fwd_slots = (int64_t)an.fwd.phys_steps() * 64; st->bwd_slots = (int64_t)an.bwd.phys_steps() * 64; st->chk_slots = (int64_t)an.chk.phys_steps() * 64;
     st->dense_tail_rows = an.dt.k; st->dense_tail_slots = (int64_t)an.dt.n_steps * 64;
+    st->nnz_L_before_tail = an.dt.k ? an.Lp[an.dt.s] : an.nnzL();
   }
   return MI_OSQP_OK;
 }

@@ -41,6 +41,38 @@ def gather_solutions(x_local, status_local=None, group=None):
     return x, torch.cat([b[:c] for b, c in zip(sb, counts)])
 
 
+class SolutionGatherer:
+    """The gather of solutions with STATIC shard sizes: the per-rank counts are exchanged once, here (outside any
+    timed step); gather() is then one all_gather_into_tensor into a preallocated buffer and involves no host
+    synchronisation.  Ragged shards (counts differ by one) are padded to the largest and trimmed."""
+
+    def __init__(self, count, n, device, dtype=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group, self.n = group, n
+        self.world = dist.get_world_size(group)
+        dtype = dtype or torch.float64
+        cnt = torch.tensor([count], device=device, dtype=torch.int64)
+        counts = torch.zeros(self.world, device=device, dtype=torch.int64)
+        dist.all_gather_into_tensor(counts, cnt, group=group)
+        self.counts = [int(c) for c in counts.cpu()]
+        self.count, self.mx = count, max(self.counts)
+        self.even = all(c == self.mx for c in self.counts)
+        self.buf = torch.empty((self.world * self.mx, n), device=device, dtype=dtype)
+        self.pad = None if count == self.mx else torch.zeros((self.mx, n), device=device, dtype=dtype)
+
+    def gather(self, x_local):
+        import torch
+        import torch.distributed as dist
+        src = x_local
+        if self.pad is not None:
+            self.pad[:self.count].copy_(x_local); src = self.pad
+        dist.all_gather_into_tensor(self.buf, src.contiguous(), group=self.group)
+        if self.even:
+            return self.buf
+        return torch.cat([self.buf[r * self.mx: r * self.mx + c] for r, c in enumerate(self.counts)])
+
+
 def shard_problem(prob, rank, world):
     """Slice a problems.py batch dict down to this rank's QPs."""
     B = prob["Ax"].shape[0]

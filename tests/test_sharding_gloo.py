@@ -28,7 +28,7 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     import numpy as np, torch, torch.distributed as dist
     from osqp_solver_amd import problems as PR
-    from osqp_solver_amd.sharding import shard_problem, gather_solutions
+    from osqp_solver_amd.sharding import shard_problem, gather_solutions, SolutionGatherer
     from oracle import oracle as O
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -39,6 +39,9 @@ WORKER = textwrap.dedent("""
     full = O.batch_solve(prob["P"], prob["Px"], prob["q"], prob["A"], prob["Ax"], prob["l"], prob["u"])
     assert x.shape == (5, 24) and np.array_equal(x.numpy(), full["x"]), "gathered solutions differ"
     assert np.array_equal(st.numpy(), full["status"])
+    g = SolutionGatherer(b1 - b0, 24, torch.device("cpu"))        # static counts (what bench.py's timed step uses)
+    for _ in range(2):
+        assert np.array_equal(g.gather(torch.tensor(r["x"])).numpy(), full["x"]), "static-count gather differs"
     dist.barrier()
     if rank == 0: print("GLOO_OK", b0, b1)
     dist.destroy_process_group()
@@ -55,3 +58,16 @@ def test_two_rank_gather_over_gloo(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
     assert "GLOO_OK" in res.stdout
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_requested():
+    """`python bench.py --gpus N` starts its own N ranks; with fewer GPUs visible it must fail loudly instead of
+    printing a smaller job's number as the N-GPU point."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("a multi-GPU machine")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and "GPU(s) are visible" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
