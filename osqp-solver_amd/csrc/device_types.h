@@ -73,20 +73,23 @@ struct FactorArgs {
   int dt_k;           // rows of the dense tail: their pivots are counted by dense_inverse_kernel, which then checks the inertia
 };
 
-// inversion of the dense tail's Schur complement (one workgroup per refactored QP, after factor_kernel)
-struct DenseInvArgs {
+// dense tail: assembly of the Schur complement + its inversion (tail_kernel; one workgroup per refactored QP, after
+// factor_kernel).  Tables: host_core.hpp DenseTail.
+struct TailArgs {
   int n, N, s, k, kbt, home_bt;
   uint32_t storage, n_slots;
+  int n_lt, n_ltcol;
+  int nh;                       // row tiles of one staged half of the panel
+  uint32_t cs_doubles;          // LDS doubles reserved for the staged panel / the pivot block's image (Ps follows)
   const int *work;              // slot of every (work tile, lane class), -1 = none
-  const uint32_t *sblk;         // k x k column-major (lower): block-storage position of S[i, j]
-  const int32_t *src;           // per stream slot: position in the dense k x k array, MI_SRC_ZERO = 0
-  const uint32_t *micro;        // the 4 x 4 tiles of the lower triangle (row tile | column tile << 16), rows fastest
-  int n_micro;
-  const double *Lblk;
+  const uint32_t *lt_pos, *ltcol_col, *tile_tab, *wave_tiles, *asm_q, *diag_tile;
+  const uint16_t *asm_qcol;
+  const int32_t *src_tile;      // per stream slot: tile-order offset in the scratch, MI_SRC_ZERO = 0
+  const double *Lblk, *Dl;
   double *Sd, *dt_val, *dinv;
   int *npos, *iscal;
 };
-hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, int threads, hipStream_t st);
+hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds, hipStream_t st);
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
 

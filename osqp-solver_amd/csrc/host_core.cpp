@@ -708,6 +708,7 @@ static void build_block_factor(Analysis &an) {
     for (int J : cols_of_level[L]) {
       const auto &rj = rowlist[J];
       for (const auto &[I, id] : colblk[J]) {
+        if (J >= ct0) continue;          // the tail tiles get their updates in tail_kernel (matrix cores), not through update tasks
         std::vector<std::pair<uint32_t, uint32_t>> tl;
         if (I == J) {
           for (const auto &[K, bid] : rj) if (K < ct0) tl.push_back({bid, bid});
@@ -807,6 +808,75 @@ static void build_block_factor(Analysis &an) {
     const int k = an.dt.k;
     an.dt.sblk.assign((size_t)k * k, 0u);
     for (int j = 0; j < k; j++) for (int i = j; i < k; i++) an.dt.sblk[(size_t)j * k + i] = pos_of(ts + i, ts + j);
+    // ---- tail_kernel tables (host_core.hpp DenseTail)
+    DenseTail &dt = an.dt;
+    const int nt = k / 16;
+    // compact entries: L[i, c], i >= ts, c < ts; fragments (tile row, column) -> 16 compact indices
+    dt.lt_pos.clear(); dt.ltcol_col.clear();
+    std::vector<std::vector<std::pair<int, std::vector<uint16_t>>>> frag(nt);      // per tile row: (compact column, 16 indices), ascending column
+    for (int c = 0; c < ts; c++) {
+      int ci = -1;
+      for (int p = an.Lp[c]; p < an.Lp[c + 1]; p++) {
+        const int i = an.Li[p];
+        if (i < ts) continue;
+        if (ci < 0) { ci = (int)dt.ltcol_col.size(); dt.ltcol_col.push_back((uint32_t)c); }
+        const int I = (i - ts) / 16;
+        if (frag[I].empty() || frag[I].back().first != ci) frag[I].push_back({ci, std::vector<uint16_t>(16, 0xFFFFu)});
+        frag[I].back().second[(i - ts) % 16] = (uint16_t)dt.lt_pos.size();
+        dt.lt_pos.push_back((uint32_t)bf.lpos[p]);
+      }
+    }
+    dt.n_lt = (int)dt.lt_pos.size(); dt.n_ltcol = (int)dt.ltcol_col.size();
+    const uint16_t zero_slot = (uint16_t)dt.n_lt;          // (analyze() keeps n_lt below 65 535 when it picks a dense tail)
+    for (auto &fr : frag) for (auto &f : fr) for (uint16_t &v : f.second) if (v == 0xFFFFu) v = zero_slot;
+    struct TileRec { int I, J; std::vector<std::pair<int, int>> src; };           // src: (fragment of I, fragment of J) with a common column
+    std::vector<TileRec> tiles;
+    for (int I = 0; I < nt; I++)
+      for (int J = 0; J <= I; J++) {
+        TileRec t{I, J, {}};
+        size_t a = 0, b = 0;
+        while (a < frag[I].size() && b < frag[J].size()) {
+          if (frag[I][a].first < frag[J][b].first) a++;
+          else if (frag[I][a].first > frag[J][b].first) b++;
+          else { t.src.push_back({(int)a, (int)b}); a++; b++; }
+        }
+        tiles.push_back(std::move(t));
+      }
+    // tiles to waves: longest first, dealt in snake order (balanced without a queue on the device)
+    const int nw = 8;
+    std::vector<int> order(tiles.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tiles[x].src.size() > tiles[y].src.size(); });
+    std::vector<std::vector<int>> mine(nw);
+    for (size_t d = 0; d < order.size(); d++) { const size_t round = d / nw, pos = d % nw; mine[(round & 1) ? nw - 1 - pos : pos].push_back(order[d]); }
+    dt.tile_tab.clear(); dt.wave_tiles.assign(nw + 1, 0u); dt.asm_q.clear(); dt.asm_qcol.clear();
+    for (int w = 0; w < nw; w++) {
+      dt.wave_tiles[w] = (uint32_t)(dt.tile_tab.size() / 4);
+      for (int ti : mine[w]) {
+        const TileRec &t = tiles[ti];
+        const uint32_t q0 = (uint32_t)(dt.asm_q.size() / 64);
+        for (size_t s0 = 0; s0 < t.src.size(); s0 += 4) {
+          for (int g = 0; g < 4; g++) {
+            const bool real = s0 + g < t.src.size();
+            const auto *fa = real ? &frag[t.I][t.src[s0 + g].first] : nullptr;
+            const auto *fb = real ? &frag[t.J][t.src[s0 + g].second] : nullptr;
+            dt.asm_qcol.push_back(real ? (uint16_t)fa->first : (uint16_t)0);
+            for (int e = 0; e < 16; e++) dt.asm_q.push_back(real ? ((uint32_t)fa->second[e] | ((uint32_t)fb->second[e] << 16)) : ((uint32_t)zero_slot | ((uint32_t)zero_slot << 16)));
+          }
+        }
+        const uint32_t blk_id = find_blk(ct0 + t.I, ct0 + t.J);
+        dt.tile_tab.insert(dt.tile_tab.end(), {((uint32_t)t.I << 16) | (uint32_t)t.J, bf.blk[4 * blk_id], q0, (uint32_t)(dt.asm_q.size() / 64)});
+      }
+    }
+    dt.wave_tiles[nw] = (uint32_t)(dt.tile_tab.size() / 4);
+    // asm_q is [quad][lane]: lane = source * 16 + tile row -- the loops above emitted exactly that order
+    dt.src_tile.resize(dt.src.size());
+    for (size_t e = 0; e < dt.src.size(); e++) {
+      const int32_t sc = dt.src[e];
+      dt.src_tile[e] = sc < 0 ? sc : (int32_t)dt_tile_offset(sc % k, sc / k);
+    }
+    dt.diag_tile.resize(k);
+    for (int i = 0; i < k; i++) dt.diag_tile[i] = dt_tile_offset(i, i);
   }
 }
 
@@ -913,8 +983,17 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
         const int64_t gain = 2 * tail_nnz - (int64_t)k * k / 2 - k;
         if (forced > 0 ? k == forced / 64 * 64 : gain > best_gain) { best_gain = gain; best_k = k; tail_nnz_used = tail_nnz; }
       }
-      if (best_k && (forced > 0 || best_gain * 10 >= 2 * (int64_t)an.Lp[N])) { an.dt.k = best_k; an.dt.s = N - best_k; }
-      else tail_nnz_used = 0;
+      if (best_k && (forced > 0 || best_gain * 10 >= 2 * (int64_t)an.Lp[N])) {
+        // tail_kernel stages the entries of L in the tail rows of the columns before the tail (and the D of those
+        // columns) in LDS and addresses them with 16-bit indices: a pattern that exceeds either keeps its triangle
+        int64_t n_lt = 0, n_ltcol = 0;
+        for (int c = 0; c < N - best_k; c++) {
+          const auto lo = std::lower_bound(cols[c].begin(), cols[c].end(), N - best_k);
+          n_lt += cols[c].end() - lo; n_ltcol += lo != cols[c].end();
+        }
+        if (n_lt <= 65534 && 8 * (n_lt + 1 + n_ltcol) <= 144 * 1024) { an.dt.k = best_k; an.dt.s = N - best_k; }
+        else tail_nnz_used = 0;
+      } else tail_nnz_used = 0;
     }
     const int ts = an.dt.k ? an.dt.s : N;
     // fundamental supernodes: j+1 joins j when parent(j)=j+1 and |col j| = |col j+1| + 1
@@ -1371,8 +1450,35 @@ int replay_block_factor(const Analysis &an, const Settings &st, const QPNumeric 
     // the tail blocks now hold the Schur complement; invert it the way dense_inverse_kernel does: symmetric sweep with
     // 16 x 16 pivot tiles  (P = inv(A_pp); G = A_:p P; A -= G A_p:; A_:p = G; A_pp = -P;  result = -inv(S))
     const int k = an.dt.k;
+    const DenseTail &dt = an.dt;
     std::vector<double> A((size_t)k * k);
-    for (int j = 0; j < k; j++) for (int i = j; i < k; i++) A[(size_t)j * k + i] = A[(size_t)i * k + j] = S[an.dt.sblk[(size_t)j * k + i]];
+    {   // assembly of S exactly as tail_kernel does it: KKT block minus the quads of 4 source columns (one MFMA step each)
+      std::vector<double> La((size_t)dt.n_lt + 1, 0.0), Dc(dt.n_ltcol);
+      for (int e = 0; e < dt.n_lt; e++) La[e] = S[dt.lt_pos[e]];
+      for (int ci = 0; ci < dt.n_ltcol; ci++) Dc[ci] = D[dt.ltcol_col[ci]];
+      for (size_t t = 0; t < dt.tile_tab.size() / 4; t++) {
+        const uint32_t I = dt.tile_tab[4 * t] >> 16, J = dt.tile_tab[4 * t] & 0xFFFFu, boff = dt.tile_tab[4 * t + 1];
+        double tile[16][16];
+        for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) {
+          const int rr = (I == J && r < c) ? c : r, cc = (I == J && r < c) ? r : c;
+          tile[r][c] = S[boff + (uint32_t)cc * 16 + (uint32_t)rr];
+        }
+        for (uint32_t q = dt.tile_tab[4 * t + 2]; q < dt.tile_tab[4 * t + 3]; q++)
+          for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) {
+            double acc = tile[r][c];
+            for (int g = 0; g < 4; g++) {
+              const double av = -La[dt.asm_q[(size_t)q * 64 + g * 16 + r] & 0xFFFFu];
+              const double bv = La[dt.asm_q[(size_t)q * 64 + g * 16 + c] >> 16] * Dc[dt.asm_qcol[(size_t)q * 4 + g]];
+              acc = std::fma(av, bv, acc);
+            }
+            tile[r][c] = acc;
+          }
+        for (int r = 0; r < 16; r++) for (int c = 0; c < 16; c++) {
+          const size_t i = (size_t)I * 16 + r, j = (size_t)J * 16 + c;
+          if (I != J || r >= c) A[j * k + i] = A[i * k + j] = tile[r][c];
+        }
+      }
+    }
     std::vector<double> G((size_t)k * 16), C((size_t)k * 16);
     for (int p0 = 0; p0 < k; p0 += 16) {
       double T[16][16];

@@ -122,8 +122,30 @@ struct DenseTail {
   std::vector<uint32_t> wave_step;   // nw + 1: stream range of every wave
   std::vector<uint32_t> tail_bar;    // nw: barriers owed after the last task (every wave passes n_phases)
   std::vector<int32_t> src;          // per slot: j * k + i (tail-local, i > j: column-major position in the dense k x k array) or MI_SRC_ZERO
-  std::vector<uint32_t> sblk;        // k x k column-major, lower triangle incl. diagonal: block-storage position of S[i, j]
+  std::vector<uint32_t> sblk;        // k x k column-major, lower triangle incl. diagonal: block-storage position of S[i, j] (host replay)
+  // ---- tables of tail_kernel (assembly of S on the matrix cores + blocked sweep inversion)
+  // The k x k Schur complement lives as 16 x 16 TILES (I >= J, tile index I (I + 1) / 2 + J, 256 doubles each) in the register
+  // order of v_mfma_f64_16x16x4_f64 accumulators: element (row, col) of a tile at ((row % 4) * 16 + col) * 4 + row / 4.
+  // Assembly: S(I, J) = KKT block - sum over the columns c before the tail with entries in both tile rows of
+  // L[I, c] d_c L[J, c]'.  The entries of L in tail rows / pre-tail columns ("compact entries", lt_*) are staged in LDS once
+  // per QP; a QUAD is one MFMA step = 4 source columns: lane l (tile row / column l % 16, source l / 16) gathers compact
+  // entry asm_q[quad][l] & 0xFFFF (operand A, tile row I) and >> 16 (operand B, tile row J); index n_lt = the zero slot.
+  int n_lt = 0, n_ltcol = 0;
+  std::vector<uint32_t> lt_pos;      // [n_lt]: block-storage position of the compact entry
+  std::vector<uint32_t> ltcol_col;   // [n_ltcol]: permuted column of the compact source column (its D)
+  std::vector<uint32_t> tile_tab;    // 4 / tile, in processing order (wave-major): (I << 16) | J, block-storage offset of the KKT block, first quad, end quad
+  std::vector<uint32_t> wave_tiles;  // nw + 1: range of tile_tab entries of every wave
+  std::vector<uint32_t> asm_q;       // [quads][64]
+  std::vector<uint16_t> asm_qcol;    // [quads][4]: compact source column of the quad's 4 sources
+  std::vector<int32_t> src_tile;     // per stream slot: tile-order offset of its element (src translated) or MI_SRC_ZERO
+  std::vector<uint32_t> diag_tile;   // [k]: tile-order offset of S[i, i]
+  size_t asm_lds_bytes() const { return ((size_t)n_lt + 1 + (size_t)n_ltcol) * sizeof(double); }
 };
+// tile-order offset of element (i, j), i >= j (tail-local), of the lower-triangular tile array
+inline uint32_t dt_tile_offset(int i, int j) {
+  const int I = i / 16, J = j / 16, r = i % 16, c = j % 16;
+  return (uint32_t)((I * (I + 1) / 2 + J) * 256 + ((r % 4) * 16 + c) * 4 + r / 4);
+}
 enum { DT_DIAG = 1, DT_SWAP = 2 };
 
 struct Analysis {

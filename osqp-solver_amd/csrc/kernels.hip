@@ -1395,157 +1395,299 @@ hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hi
 }
 
 
-// ---- dense tail: M = S^-1 (host_core.hpp DenseTail) ------------------------------------------------------------
-// factor_kernel leaves the Schur complement S of the trailing k rows in the tail blocks of the work tile's block
-// storage.  One workgroup per QP gathers it into a dense column-major array (lower triangle) and inverts it in place
-// with the symmetric sweep operator on 16 x 16 pivot tiles:
-//     P = inv(A_pp);  G = A_:p P;  A_ij -= G_i A_pj (i, j outside p);  A_:p = G;  A_pp = -P        ->  A = -inv(S)
-// (no pivoting, like the LDL' it replaces: the scalar pivots met inside the pivot tiles ARE the pivots of LDL', which
-// is how the inertia check still works).  The panel C = A_:p and G live in LDS ([16][k] each); the trailing update
-// is register-tiled 4 x 4 per thread and runs over the lower triangle in global memory (L2).  The result goes
-// straight into the QP's value stream of the symmetric product (dense_tail_apply) and its diagonal into dinv.
-template <int NT>
-__global__ __launch_bounds__(NT) void dense_inverse_kernel(DenseInvArgs a) {
+// ---- dense tail: S and M = S^-1 (host_core.hpp DenseTail) -----------------------------------------------------
+// One workgroup (8 waves) per refactored QP, after factor_kernel.  Everything dense runs on the matrix cores
+// (v_mfma_f64_16x16x4_f64: the fp64 vector rate with 1/16 of the instructions and a quarter of the LDS operand traffic).
+//
+// Data: the k x k Schur complement as 16 x 16 tiles (lower triangle, I >= J) in a per-QP scratch, each tile stored in the
+// register order of an MFMA accumulator ([lane][reg]: row = lane / 16 + 4 reg, col = lane % 16), so accumulator loads and
+// stores are contiguous 32-byte pieces per lane.
+//
+// Phase 0, assembly: S(I, J) = KKT block - sum_c L[I, c] d_c L[J, c]' over the columns c before the tail.  The entries of
+// L in the tail rows of those columns (10 k values at config 3) and their D are staged in LDS once; per tile, 4 source
+// columns make one MFMA step whose operands are LDS gathers through a per-step index word (host tables, shared by all
+// QPs, L2 resident).  factor_kernel used to do this with 16 x 16 rank-1 block updates at ~10 % useful work from global
+// memory.
+//
+// Phases 1 .. k/64, inversion: symmetric sweep operator on 64 x 64 pivot blocks,
+//     Pn = -inv(A_pp);  Gn = A_:p Pn;  A_ij += Gn_i A_pj (i, j outside p);  A_:p = -Gn;  A_pp = Pn      ->  A = -inv(S)
+// (no pivoting, like the LDL' it replaces; the scalar pivots met inside the pivot blocks ARE the pivots of LDL', which is
+// how the inertia check still works).  Per pass: the pivot block is swept inside LDS (its 16 x 16 diagonal tiles scalar,
+// by one wave; the rest of its 64 x 64 as MFMA tile products); the panel C = A_:p is staged in LDS in halves, in MFMA
+// operand order; every wave owns row tiles (snake-dealt by work), computes their Gn' = Pn C' - whose accumulator
+// registers ARE the A-operand fragments of the trailing update, no transposition - and updates its tiles A_ij, j <= i,
+// with a 3-deep prefetch of the accumulator tiles.  Traffic per QP: k/64 read-modify-write passes over the triangle
+// instead of k/16 (12 MB instead of 45 MB at k = 448); flops k^3 on the matrix cores.
+typedef double mi_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mi_v4d mfma_f64(double a, double b, mi_v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ mi_v4d ld_tile(const double *A, uint32_t tix, int lane) {
+  const double2 *p = reinterpret_cast<const double2 *>(A + (size_t)tix * 256 + (size_t)lane * 4);
+  const double2 v0 = p[0], v1 = p[1];
+  return mi_v4d{v0.x, v0.y, v1.x, v1.y};
+}
+__device__ __forceinline__ void st_tile(double *A, uint32_t tix, int lane, mi_v4d v) {
+  double2 *p = reinterpret_cast<double2 *>(A + (size_t)tix * 256 + (size_t)lane * 4);
+  p[0] = make_double2(v[0], v[1]); p[1] = make_double2(v[2], v[3]);
+}
+__device__ __forceinline__ uint32_t tile_ix(int I, int J) { return (uint32_t)(I * (I + 1) / 2 + J); }
+
+#define MI_TAIL_NW 8
+#define MI_TAIL_MAXSLOT 4          // row tiles a wave may own: ceil((512 / 16 - 4) / 8)
+#define MI_TAIL_TS 65              // row stride of the pivot block's LDS image
+
+__global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
   extern __shared__ double smem[];
   const int g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = a.work[g];
   if (slot < 0) return;
-  const int k = a.k, kbt = a.kbt, wt = g / kbt, wb = g % kbt;
+  const int k = a.k, kbt = a.kbt, wt = g / kbt, wb = g % kbt, nt = k / 16;
   const size_t hbt = (size_t)a.home_bt, home = (size_t)slot / hbt, hb = (size_t)slot % hbt;
   auto H = [&](size_t len, size_t i) { return (home * len + i) * hbt + hb; };
   double *A = a.Sd + (size_t)g * k * k;
-  const double *Lb = a.Lblk + (size_t)wt * a.storage * kbt;
-  double *Ts = smem;                       // [16][17] pivot tile
-  double *Cs = smem + 16 * 17;             // [16][k]: Cs[q * k + r] = A[r, p0 + q]
-  double *Gs = Cs + (size_t)16 * k;        // [16][k]
-  for (int e = tid; e < k * k; e += nthr) {
-    const int j = e / k, i = e % k;
-    A[e] = i >= j ? Lb[(size_t)a.sblk[e] * kbt + wb] : 0.0;       // (the strict upper triangle is only touched inside diagonal 4 x 4 tiles)
+  const double *Lb = a.Lblk + (size_t)wt * a.storage * kbt + wb;
+  const double *Dl = a.Dl + (size_t)wt * a.N * kbt + wb;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // ------------------------------------------------------------------ phase 0: assembly
+  {
+    double *La = smem, *Dc = smem + a.n_lt + 1;
+    for (int e = tid; e < a.n_lt; e += nthr) La[e] = Lb[(size_t)a.lt_pos[e] * kbt];
+    if (tid == 0) La[a.n_lt] = 0.0;
+    for (int c = tid; c < a.n_ltcol; c += nthr) Dc[c] = Dl[(size_t)a.ltcol_col[c] * kbt];
+    __syncthreads();
+    for (uint32_t ti = a.wave_tiles[wave]; ti < a.wave_tiles[wave + 1]; ti++) {
+      const uint4 tt = reinterpret_cast<const uint4 *>(a.tile_tab)[ti];
+      const int I = (int)(tt.x >> 16), J = (int)(tt.x & 0xFFFFu);
+      mi_v4d acc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int row = l4 + 4 * r, col = l15;
+        if (I == J && row < col) { const int t = row; row = col; col = t; }        // diagonal blocks hold their lower triangle
+        acc[r] = Lb[((size_t)tt.y + (size_t)col * 16 + row) * kbt];
+      }
+      constexpr int UQ = 4;          // quads in flight: table words, then LDS gathers, then the MFMAs
+      for (uint32_t q0 = tt.z; q0 < tt.w; q0 += UQ) {
+        uint32_t w[UQ], ci[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+          const uint32_t q = q0 + u < tt.w ? q0 + u : tt.w - 1;
+          w[u] = a.asm_q[(size_t)q * 64 + lane]; ci[u] = a.asm_qcol[(size_t)q * 4 + l4];
+        }
+        double av[UQ], bv[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) { av[u] = -La[w[u] & 0xFFFFu]; bv[u] = La[w[u] >> 16] * Dc[ci[u]]; }
+#pragma unroll
+        for (int u = 0; u < UQ; u++) if (q0 + u < tt.w) acc = mfma_f64(av[u], bv[u], acc);
+      }
+      st_tile(A, tile_ix(I, J), lane, acc);
+    }
   }
   __syncthreads();
+  // ------------------------------------------------------------------ phases 1 .. k/64: blocked sweep
+  const int nrt = nt - 4;                                   // row tiles outside a pivot block
+  const int nh = a.nh;                                      // row tiles of one staged half of the panel (host: <= 14)
+  double *Cs = smem;                                        // [nh][16 steps][64 lanes]: C in MFMA operand order; doubles as the pivot block's image T
+  double *Ps = smem + (size_t)a.cs_doubles;                 // [4][16][64]: Pn as A operand of Gn' = Pn C'
+  double *Ts = Cs;                                          // [64][MI_TAIL_TS]
   int npos = 0;
-  for (int p0 = 0; p0 < k; p0 += 16) {
-    // ---- pivot tile (full symmetric copy) -> LDS, swept by wave 0: Ts <- -inv(Ts)
-    if (tid < 256) {
-      const int r = tid & 15, c = tid >> 4;
-      Ts[r * 17 + c] = r >= c ? A[(size_t)(p0 + c) * k + p0 + r] : A[(size_t)(p0 + r) * k + p0 + c];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      const int r = lane & 15, c0 = (lane >> 4) * 4;
-      for (int kk = 0; kk < 16; kk++) {
-        const double d = Ts[kk * 17 + kk], di = 1.0 / d, ta = Ts[r * 17 + kk];
-        if (lane == 0 && d > 0.0) npos++;
-        double nv[4];
+  for (int p = 0; p < k / 64; p++) {
+    const int P0 = 4 * p;
+    auto nonp = [&](int x) { return x < P0 ? x : x + 4; };  // x-th row tile outside the pivot block
+    // ---- pivot block -> LDS (full symmetric image)
+    for (int t = wave; t < 10; t += MI_TAIL_NW) {
+      int ta = 0, tb = t;                                   // t -> (ta >= tb) in the 4 x 4 lower triangle
+      while (tb > ta) { tb -= ta + 1; ta++; }
+      const mi_v4d v = ld_tile(A, tile_ix(P0 + ta, P0 + tb), lane);
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
-          const int c = c0 + cc;
-          const double tb = Ts[kk * 17 + c];
-          double v = Ts[r * 17 + c];
-          if (r != kk && c != kk) v -= ta * di * tb;
-          else if (r == kk && c == kk) v = -di;
-          else if (c == kk) v = ta * di;
-          else v = tb * di;
-          nv[cc] = v;
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * ta + l4 + 4 * r, col = 16 * tb + l15;
+        if (ta != tb || row >= col) {       // (a diagonal tile is symmetric only up to round-off: its lower triangle is the truth)
+          Ts[row * MI_TAIL_TS + col] = v[r];
+          Ts[col * MI_TAIL_TS + row] = v[r];
         }
-        wave_sync();
-#pragma unroll
-        for (int cc = 0; cc < 4; cc++) Ts[r * 17 + c0 + cc] = nv[cc];
-        wave_sync();
       }
     }
     __syncthreads();
-    // ---- panel: row r of C = A[:, p0 .. p0+15] (zero inside the pivot rows) and of G = C P, P = -Ts
-    const int r = tid;                      // k <= blockDim.x: one row per thread
-    const bool has_row = r < k, piv = r >= p0 && r < p0 + 16;
-    if (has_row) {
-      double cr[16], gr[16];
+    // ---- Ts <- -inv(Ts): four 16-wide sub-sweeps
+    for (int q = 0; q < 4; q++) {
+      if (wave == 0) {                                      // the 16 x 16 diagonal tile, scalar: U <- -inv(U)
+        double *U = Ts + (16 * q) * MI_TAIL_TS + 16 * q;
+        const int r = l15, c0 = l4 * 4;
+        for (int kk = 0; kk < 16; kk++) {
+          const double d = U[kk * MI_TAIL_TS + kk], di = 1.0 / d, ta = U[r * MI_TAIL_TS + kk];
+          if (lane == 0 && d > 0.0) npos++;
+          double nv[4];
 #pragma unroll
-      for (int q = 0; q < 16; q++) cr[q] = piv ? 0.0 : (r > p0 ? A[(size_t)(p0 + q) * k + r] : A[(size_t)r * k + p0 + q]);
+          for (int cc = 0; cc < 4; cc++) {
+            const int c = c0 + cc;
+            const double tb = U[kk * MI_TAIL_TS + c];
+            double v = U[r * MI_TAIL_TS + c];
+            if (r != kk && c != kk) v -= ta * di * tb;
+            else if (r == kk && c == kk) v = -di;
+            else if (c == kk) v = ta * di;
+            else v = tb * di;
+            nv[cc] = v;
+          }
+          wave_sync();
 #pragma unroll
-      for (int c = 0; c < 16; c++) {
-        double gsum = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) gsum = fma(cr[q], -Ts[q * 17 + c], gsum);
-        gr[c] = gsum;
+          for (int cc = 0; cc < 4; cc++) U[r * MI_TAIL_TS + c0 + cc] = nv[cc];
+          wave_sync();
+        }
       }
+      __syncthreads();
+      // the other three tile rows a of the block: gn_a' = Un c_a' (accumulator registers = A-operand fragments of gn_a),
+      // then T[a, b] += gn_a c_b' for the three b != q
+      int ta = -1;
+      mi_v4d gnT = {0.0, 0.0, 0.0, 0.0};
+      if (wave < 3) {
+        ta = wave < q ? wave : wave + 1;
 #pragma unroll
-      for (int q = 0; q < 16; q++) { Cs[(size_t)q * k + r] = cr[q]; Gs[(size_t)q * k + r] = gr[q]; }
-      // the pivot column takes G right away: row r of it is read and written by this thread only, and the trailing
-      // update below stays outside the pivot rows / columns
-      if (!piv) {
+        for (int s = 0; s < 4; s++)
+          gnT = mfma_f64(Ts[(16 * q + l15) * MI_TAIL_TS + 16 * q + 4 * s + l4], Ts[(16 * ta + l15) * MI_TAIL_TS + 16 * q + 4 * s + l4], gnT);
+        for (int bi = 0; bi < 3; bi++) {
+          const int tb = bi < q ? bi : bi + 1;
+          mi_v4d acc;
 #pragma unroll
-        for (int c = 0; c < 16; c++) { if (r > p0) A[(size_t)(p0 + c) * k + r] = gr[c]; else A[(size_t)r * k + p0 + c] = gr[c]; }
+          for (int r = 0; r < 4; r++) acc[r] = Ts[(16 * ta + l4 + 4 * r) * MI_TAIL_TS + 16 * tb + l15];
+#pragma unroll
+          for (int s = 0; s < 4; s++) acc = mfma_f64(gnT[s], Ts[(16 * tb + l15) * MI_TAIL_TS + 16 * q + 4 * s + l4], acc);
+#pragma unroll
+          for (int r = 0; r < 4; r++) Ts[(16 * ta + l4 + 4 * r) * MI_TAIL_TS + 16 * tb + l15] = acc[r];
+        }
       }
+      __syncthreads();
+      if (wave < 3) {                                       // the panel column takes g_a = -gn_a (and its mirror image)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int arow = 16 * ta + l15, kcol = 16 * q + l4 + 4 * r;
+          Ts[arow * MI_TAIL_TS + kcol] = -gnT[r];
+          Ts[kcol * MI_TAIL_TS + arow] = -gnT[r];
+        }
+      }
+      __syncthreads();
+    }
+    // ---- Pn: to the scratch (A_pp = Pn) and, in A-operand order, to Ps
+    for (int t = wave; t < 10; t += MI_TAIL_NW) {
+      int ta = 0, tb = t;
+      while (tb > ta) { tb -= ta + 1; ta++; }
+      mi_v4d v;
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = Ts[(16 * ta + l4 + 4 * r) * MI_TAIL_TS + 16 * tb + l15];
+      st_tile(A, tile_ix(P0 + ta, P0 + tb), lane, v);
+    }
+    for (int e = tid; e < 4 * 16 * 64; e += nthr) {
+      const int kt = e >> 10, sp = (e >> 6) & 15, l = e & 63;
+      Ps[e] = Ts[(16 * kt + (l & 15)) * MI_TAIL_TS + 4 * sp + (l >> 4)];
     }
     __syncthreads();
-    // ---- trailing update of the lower triangle outside the pivot rows / columns: 4 x 4 per thread, two tiles in
-    // flight per thread (the loads of both are issued before the fmas of the first)
-    const uint32_t pm = (uint32_t)p0 / 4u;
-    auto tile_of = [&](int t, uint32_t &mi, uint32_t &mj) -> bool {
-      if (t >= a.n_micro) return false;
-      const uint32_t w = a.micro[t];
-      mi = w & 0xFFFFu; mj = w >> 16;
-      return !((mi >= pm && mi < pm + 4u) || (mj >= pm && mj < pm + 4u));
-    };
-    auto load_tile = [&](double *dst, double (&acc)[4][4]) {
+    if (nrt == 0) continue;
+    // ---- panel staging: positions [x0, x1) of the non-pivot row tiles -> Cs (16 steps x 64 lanes per row tile)
+    auto stage = [&](int x0, int x1) {
+      for (int e = wave; e < (x1 - x0) * 4; e += MI_TAIL_NW) {
+        const int x = x0 + (e >> 2), qq = e & 3, t = nonp(x);
+        double *dst = Cs + (size_t)(x - x0) * 1024;
+        if (t < P0) {                 // stored tile (P0 + qq, t): rows = pivot columns, cols = the rows of C: already operand order
+          const mi_v4d v = ld_tile(A, tile_ix(P0 + qq, t), lane);
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const double2 v0 = *reinterpret_cast<const double2 *>(dst + (size_t)c * k), v1 = *reinterpret_cast<const double2 *>(dst + (size_t)c * k + 2);
-        acc[0][c] = v0.x; acc[1][c] = v0.y; acc[2][c] = v1.x; acc[3][c] = v1.y;
+          for (int r = 0; r < 4; r++) dst[(4 * qq + r) * 64 + lane] = v[r];
+        } else {                      // stored tile (t, P0 + qq): rows = the rows of C, cols = pivot columns: transpose on the way
+          const mi_v4d v = ld_tile(A, tile_ix(t, P0 + qq), lane);
+#pragma unroll
+          for (int r = 0; r < 4; r++) dst[(4 * qq + (l15 >> 2)) * 64 + ((l15 & 3) << 4) + l4 + 4 * r] = v[r];
+        }
       }
     };
-    auto update_tile = [&](double *dst, uint32_t mi, uint32_t mj, double (&acc)[4][4]) {
+    // row tile of this wave's slot sl: the (sl * 8 + (sl even ? wave : 7 - wave))-th largest, i.e. position nrt - 1 - that
+    auto slot_pos = [&](int sl) { const int d = sl * MI_TAIL_NW + ((sl & 1) ? MI_TAIL_NW - 1 - wave : wave); return d < nrt ? nrt - 1 - d : -1; };
+    double Gn[MI_TAIL_MAXSLOT][16];
+    auto compute_g = [&](int x0, int x1) {                  // Gn' = Pn C' for the owned row tiles staged in [x0, x1)
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const double2 g0 = *reinterpret_cast<const double2 *>(&Gs[(size_t)q * k + 4 * mi]), g1 = *reinterpret_cast<const double2 *>(&Gs[(size_t)q * k + 4 * mi + 2]);
-        const double2 c0v = *reinterpret_cast<const double2 *>(&Cs[(size_t)q * k + 4 * mj]), c1v = *reinterpret_cast<const double2 *>(&Cs[(size_t)q * k + 4 * mj + 2]);
-        const double gg[4] = {g0.x, g0.y, g1.x, g1.y}, cc[4] = {c0v.x, c0v.y, c1v.x, c1v.y};
+      for (int sl = 0; sl < MI_TAIL_MAXSLOT; sl++) {
+        const int x = slot_pos(sl);
+        if (x < x0 || x >= x1) continue;
+        const double *cs = Cs + (size_t)(x - x0) * 1024 + lane;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int kt = 0; kt < 4; kt++) {
+          mi_v4d gacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int c = 0; c < 4; c++) acc[i][c] = fma(-gg[i], cc[c], acc[i][c]);
-      }
+          for (int sp = 0; sp < 16; sp++) gacc = mfma_f64(Ps[(kt * 16 + sp) * 64 + lane], cs[sp * 64], gacc);
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        *reinterpret_cast<double2 *>(dst + (size_t)c * k) = make_double2(acc[0][c], acc[1][c]);
-        *reinterpret_cast<double2 *>(dst + (size_t)c * k + 2) = make_double2(acc[2][c], acc[3][c]);
+          for (int r = 0; r < 4; r++) Gn[sl][4 * kt + r] = gacc[r];
+        }
       }
     };
-    if constexpr (NT > 512) {               // 128 VGPRs: one tile at a time
-      for (int t0 = tid; t0 < a.n_micro; t0 += nthr) {
-        uint32_t mi0 = 0, mj0 = 0;
-        if (!tile_of(t0, mi0, mj0)) continue;
-        double acc0[4][4];
-        double *d0 = A + (size_t)(4 * mj0) * k + 4 * mi0;
-        load_tile(d0, acc0);
-        update_tile(d0, mi0, mj0, acc0);
+    // A(I, J) += Gn_I C_J' for the owned row tiles at positions [rx0, rx1) and the column positions [y0, y1) staged in Cs
+    auto trailing = [&](int rx0, int rx1, int y0, int y1) {
+#pragma unroll
+      for (int sl = 0; sl < MI_TAIL_MAXSLOT; sl++) {
+        const int x = slot_pos(sl);
+        if (x < rx0 || x >= rx1) continue;
+        const int I = nonp(x), yend = x < y1 - 1 ? x : y1 - 1;           // columns y0 .. yend (y <= x)
+        if (yend < y0) continue;
+        auto upd = [&](mi_v4d c, int y) {
+          const double *cs = Cs + (size_t)(y - y0) * 1024 + lane;
+#pragma unroll
+          for (int s = 0; s < 16; s++) c = mfma_f64(Gn[sl][s], cs[s * 64], c);
+          return c;
+        };
+        auto tix = [&](int y) { return tile_ix(I, nonp(y)); };
+        mi_v4d c0 = ld_tile(A, tix(y0), lane), c1 = c0, c2 = c0;
+        if (y0 + 1 <= yend) c1 = ld_tile(A, tix(y0 + 1), lane);
+        if (y0 + 2 <= yend) c2 = ld_tile(A, tix(y0 + 2), lane);
+        for (int y = y0; y <= yend; y += 3) {
+          c0 = upd(c0, y); st_tile(A, tix(y), lane, c0);
+          if (y + 3 <= yend) c0 = ld_tile(A, tix(y + 3), lane);
+          if (y + 1 <= yend) {
+            c1 = upd(c1, y + 1); st_tile(A, tix(y + 1), lane, c1);
+            if (y + 4 <= yend) c1 = ld_tile(A, tix(y + 4), lane);
+          }
+          if (y + 2 <= yend) {
+            c2 = upd(c2, y + 2); st_tile(A, tix(y + 2), lane, c2);
+            if (y + 5 <= yend) c2 = ld_tile(A, tix(y + 5), lane);
+          }
+        }
       }
-    } else {
-      for (int t0 = tid; t0 < a.n_micro; t0 += 2 * nthr) {
-        uint32_t mi0 = 0, mj0 = 0, mi1 = 0, mj1 = 0;
-        const bool ok0 = tile_of(t0, mi0, mj0), ok1 = tile_of(t0 + nthr, mi1, mj1);
-        double acc0[4][4], acc1[4][4];
-        double *d0 = A + (size_t)(4 * mj0) * k + 4 * mi0, *d1 = A + (size_t)(4 * mj1) * k + 4 * mi1;
-        if (ok0) load_tile(d0, acc0);
-        if (ok1) load_tile(d1, acc1);
-        if (ok0) update_tile(d0, mi0, mj0, acc0);
-        if (ok1) update_tile(d1, mi1, mj1, acc1);
-      }
+    };
+    // steps of a pass: (stage [sx0, sx1)) -> (Gn of the owned rows staged there, when gflag) -> (trailing update of the
+    // owned rows [rx0, rx1) against the staged columns).  One staging when the whole panel fits; else the halves
+    // [0, h0) and [h0, nrt), h0 <= nh:  H1 (Gn only) -> H0 (Gn; every row against the columns of H0) -> H1 (its rows against itself)
+    const int h0 = nrt <= nh ? 0 : nrt - nh, nsteps = nrt <= nh ? 1 : 3;
+    for (int stp = 0; stp < nsteps; stp++) {
+      int sx0, sx1, rx0, rx1, gflag;
+      if (nsteps == 1) { sx0 = 0; sx1 = nrt; rx0 = 0; rx1 = nrt; gflag = 1; }
+      else if (stp == 0) { sx0 = h0; sx1 = nrt; rx0 = 0; rx1 = 0; gflag = 1; }
+      else if (stp == 1) { sx0 = 0; sx1 = h0; rx0 = 0; rx1 = nrt; gflag = 1; }
+      else { sx0 = h0; sx1 = nrt; rx0 = h0; rx1 = nrt; gflag = 0; }
+      if (stp) __syncthreads();         // everybody is done with the previous staging
+      stage(sx0, sx1);
+      __syncthreads();
+      if (gflag) compute_g(sx0, sx1);
+      trailing(rx0, rx1, sx0, sx1);
     }
-    // ---- the pivot tile takes -P
-    if (tid < 256) {
-      const int rr = tid & 15, c = tid >> 4;
-      if (rr >= c) A[(size_t)(p0 + c) * k + p0 + rr] = Ts[rr * 17 + c];
+    // ---- the panel takes G = -Gn (nobody reads the old panel from the scratch any more: every staging is behind us)
+#pragma unroll
+    for (int sl = 0; sl < MI_TAIL_MAXSLOT; sl++) {
+      const int x = slot_pos(sl);
+      if (x < 0) continue;
+      const int t = nonp(x);
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++) {
+        if (t < P0) {
+          st_tile(A, tile_ix(P0 + kt, t), lane, mi_v4d{-Gn[sl][4 * kt], -Gn[sl][4 * kt + 1], -Gn[sl][4 * kt + 2], -Gn[sl][4 * kt + 3]});
+        } else {                      // element (row i = lane % 16, col kk = lane / 16 + 4 r) of tile (t, P0 + kt)
+          double *dst = A + (size_t)tile_ix(t, P0 + kt) * 256;
+#pragma unroll
+          for (int r = 0; r < 4; r++) dst[(((l15 & 3) << 4) + l4 + 4 * r) * 4 + (l15 >> 2)] = -Gn[sl][4 * kt + r];
+        }
+      }
     }
     __syncthreads();
   }
   // ---- M = -A into the QP's stream of the symmetric product, its diagonal into dinv
   {
     double *dv = a.dt_val + (size_t)slot * a.n_slots;
-    for (uint32_t e = tid; e < a.n_slots; e += nthr) { const int32_t sc = a.src[e]; dv[e] = sc >= 0 ? -A[sc] : 0.0; }
-    for (int i = tid; i < k; i += nthr) a.dinv[H(a.N, (size_t)a.s + i)] = -A[(size_t)i * k + i];
+    for (uint32_t e = tid; e < a.n_slots; e += nthr) { const int32_t sc = a.src_tile[e]; dv[e] = sc >= 0 ? -A[sc] : 0.0; }
+    for (int i = tid; i < k; i += nthr) a.dinv[H(a.N, (size_t)a.s + i)] = -A[a.diag_tile[i]];
   }
   if (tid == 0) {
     const int total = a.npos[slot] + npos;
@@ -1553,13 +1695,11 @@ __global__ __launch_bounds__(NT) void dense_inverse_kernel(DenseInvArgs a) {
     if (total != a.n) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = -1;
   }
 }
-hipError_t launch_dense_inverse(const DenseInvArgs &a, int nwork, int threads, hipStream_t st) {
-  if (a.k > 512 || (a.k & 63) || threads < a.k || threads > 1024 || (threads & 63)) return hipErrorInvalidValue;
-  const size_t lds = ((size_t)16 * 17 + (size_t)32 * a.k) * sizeof(double);
-  auto kern = threads > 512 ? &dense_inverse_kernel<1024> : &dense_inverse_kernel<512>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds, hipStream_t st) {
+  if (a.k > 512 || (a.k & 63) || a.k < 64) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(nwork), dim3(threads), lds, st, a);
+  hipLaunchKernelGGL(tail_kernel, dim3(nwork), dim3(512), lds, st, a);
   return hipGetLastError();
 }
 

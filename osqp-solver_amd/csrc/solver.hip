@@ -189,7 +189,11 @@ struct mi_osqp_batch {
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
   // dense tail (host_core.hpp DenseTail): task tables, the per-QP stream of S^-1 (+ setup snapshot), dense scratch
-  DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar, dt_sblk, dt_micro;
+  DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar;
+  DevBuf<uint32_t> dt_lt_pos, dt_ltcol_col, dt_tile_tab, dt_wave_tiles, dt_asm_q, dt_diag_tile;     // tail_kernel tables
+  DevBuf<uint16_t> dt_asm_qcol;
+  DevBuf<int32_t> dt_src_tile;
+  int dt_nh = 0; uint32_t dt_cs_doubles = 0; size_t dt_lds = 0;
   DevBuf<int32_t> dt_src;
   DevBuf<double> dt_val, dt_val0, dt_Sd;
   DevBuf<uint32_t> sp_ptr, sp_ent;      // fused SpMV op (spmv_fused_kernel); empty when not eligible
@@ -536,11 +540,18 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const DenseTail &dt = an.dt;
     ALLOC(dt_val, (size_t)dt.n_steps * 64);
     if ((rc = h->dt_task.upload(dt.task)) || (rc = h->dt_wave_task.upload(dt.wave_task)) || (rc = h->dt_wave_step.upload(dt.wave_step)) ||
-        (rc = h->dt_tail_bar.upload(dt.tail_bar)) || (rc = h->dt_sblk.upload(dt.sblk)) || (rc = h->dt_src.upload(dt.src)) ||
+        (rc = h->dt_tail_bar.upload(dt.tail_bar)) || (rc = h->dt_src.upload(dt.src)) ||
+        (rc = h->dt_lt_pos.upload(dt.lt_pos)) || (rc = h->dt_ltcol_col.upload(dt.ltcol_col)) || (rc = h->dt_tile_tab.upload(dt.tile_tab)) ||
+        (rc = h->dt_wave_tiles.upload(dt.wave_tiles)) || (rc = h->dt_asm_q.upload(dt.asm_q)) || (rc = h->dt_asm_qcol.upload(dt.asm_qcol)) ||
+        (rc = h->dt_src_tile.upload(dt.src_tile)) || (rc = h->dt_diag_tile.upload(dt.diag_tile)) ||
         (rc = h->dt_Sd.alloc((size_t)dt.k * dt.k * (T + 4)))) return rc;
-    std::vector<uint32_t> micro;             // 4 x 4 tiles of the lower triangle for dense_inverse_kernel's trailing update
-    for (uint32_t mj = 0; mj < (uint32_t)dt.k / 4; mj++) for (uint32_t mi = mj; mi < (uint32_t)dt.k / 4; mi++) micro.push_back(mi | (mj << 16));
-    if ((rc = h->dt_micro.upload(micro))) return rc;
+    // LDS plan of tail_kernel: the staged half of the panel (<= 14 row tiles of 8 KiB; at least the 64 x 65 image of a pivot
+    // block) + Pn in operand order (32 KiB), or the compact factor entries of the assembly phase, whichever is larger
+    const int nrt = dt.k / 16 - 4;
+    h->dt_nh = nrt <= 14 ? std::max(nrt, 1) : (nrt + 1) / 2;
+    h->dt_cs_doubles = (uint32_t)std::max(h->dt_nh * 1024, 64 * 65 + 63) / 64 * 64;
+    h->dt_lds = std::max(((size_t)h->dt_cs_doubles + 4096) * sizeof(double), (dt.asm_lds_bytes() + 255) & ~(size_t)255);
+    if (h->dt_lds > lds_cap) { g_last_error = "internal: LDS budget of tail_kernel exceeded"; return MI_OSQP_ERR_ALLOC; }
   }
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
@@ -720,16 +731,14 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipEventRecord(h->evf1, h->stream));
   if (h->an.dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
     const DenseTail &dt = h->an.dt;
-    DenseInvArgs da{};
+    TailArgs da{};
     da.n = h->an.n; da.N = h->an.N; da.s = dt.s; da.k = dt.k; da.kbt = kbt; da.home_bt = BT;
-    da.storage = h->an.bf.storage; da.n_slots = dt.n_steps * 64u; da.work = h->work.p; da.sblk = h->dt_sblk.p; da.src = h->dt_src.p;
-    da.micro = h->dt_micro.p; da.n_micro = (int)h->dt_micro.n;
-    da.Lblk = h->Lblk.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
-    // a lone workgroup is latency-bound (more threads = fewer trips of the trailing update: 1.3 ms instead of 1.7);
-    // with every CU busy the kernel is bound by the read-modify-write traffic of the trailing updates and 512 threads do better
-    int dthreads = wtiles * kbt <= h->n_cus ? 1024 : 512;
-    { const char *e = getenv("MI_OSQP_DENSE_THREADS"); if (e) dthreads = std::max(512, std::min(1024, atoi(e) / 64 * 64)); }
-    HIPCHK(launch_dense_inverse(da, wtiles * kbt, dthreads, h->stream));
+    da.storage = h->an.bf.storage; da.n_slots = dt.n_steps * 64u; da.n_lt = dt.n_lt; da.n_ltcol = dt.n_ltcol;
+    da.nh = h->dt_nh; da.cs_doubles = h->dt_cs_doubles; da.work = h->work.p;
+    da.lt_pos = h->dt_lt_pos.p; da.ltcol_col = h->dt_ltcol_col.p; da.tile_tab = h->dt_tile_tab.p; da.wave_tiles = h->dt_wave_tiles.p;
+    da.asm_q = h->dt_asm_q.p; da.diag_tile = h->dt_diag_tile.p; da.asm_qcol = h->dt_asm_qcol.p; da.src_tile = h->dt_src_tile.p;
+    da.Lblk = h->Lblk.p; da.Dl = h->Dl.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
+    HIPCHK(launch_tail(da, wtiles * kbt, h->dt_lds, h->stream));
   }
   HIPCHK(hipEventRecord(h->evf2, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
