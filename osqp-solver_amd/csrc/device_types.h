@@ -88,6 +88,7 @@ struct TailArgs {
   const double *Lblk, *Dl;
   double *Sd, *dt_val, *dinv;
   int *npos, *iscal;
+  unsigned long long *trace;    // null, or 4 clock sums per workgroup (MI_OSQP_TAIL_TRACE)
 };
 hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds, hipStream_t st);
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);

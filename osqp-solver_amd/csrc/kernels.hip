@@ -1448,6 +1448,12 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
   const double *Lb = a.Lblk + (size_t)wt * a.storage * kbt + wb;
   const double *Dl = a.Dl + (size_t)wt * a.N * kbt + wb;
   const int l15 = lane & 15, l4 = lane >> 4;
+  // timing stamps of wave 0 (MI_OSQP_TAIL_TRACE=1: a.trace != null; results are not affected): assembly, pivot blocks,
+  // panel + trailing updates, stream write - shader clocks summed over the passes
+  unsigned long long tr_t = a.trace ? __builtin_amdgcn_s_memtime() : 0ull, tr_acc[4] = {0ull, 0ull, 0ull, 0ull};
+  auto stamp = [&](int which) {
+    if (a.trace && wave == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[which] += t - tr_t; tr_t = t; }
+  };
   // ------------------------------------------------------------------ phase 0: assembly
   {
     double *La = smem, *Dc = smem + a.n_lt + 1;
@@ -1455,34 +1461,70 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
     if (tid == 0) La[a.n_lt] = 0.0;
     for (int c = tid; c < a.n_ltcol; c += nthr) Dc[c] = Dl[(size_t)a.ltcol_col[c] * kbt];
     __syncthreads();
-    for (uint32_t ti = a.wave_tiles[wave]; ti < a.wave_tiles[wave + 1]; ti++) {
-      const uint4 tt = reinterpret_cast<const uint4 *>(a.tile_tab)[ti];
-      const int I = (int)(tt.x >> 16), J = (int)(tt.x & 0xFFFFu);
-      mi_v4d acc;
+    // The quads of a wave's tiles are one linear stream of the two tables (tiles are laid out wave-major): the words of the
+    // next UQ quads are in flight while the current UQ are gathered from LDS and multiplied, across tile boundaries; the
+    // initial accumulator of the next tile is fetched one tile ahead.  (One 4-quad group at a time used to cost one L2
+    // round trip each: 0.9 M clocks per QP, 7 x the MFMA time.)
+    constexpr int UQ = 16;
+    const uint32_t t_begin = a.wave_tiles[wave], t_end = a.wave_tiles[wave + 1];
+    if (t_begin < t_end) {
+      const uint4 *ttab = reinterpret_cast<const uint4 *>(a.tile_tab);
+      auto load_init = [&](const uint4 &tt) {
+        const int I = (int)(tt.x >> 16), J = (int)(tt.x & 0xFFFFu);
+        mi_v4d v;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        int row = l4 + 4 * r, col = l15;
-        if (I == J && row < col) { const int t = row; row = col; col = t; }        // diagonal blocks hold their lower triangle
-        acc[r] = Lb[((size_t)tt.y + (size_t)col * 16 + row) * kbt];
-      }
-      constexpr int UQ = 4;          // quads in flight: table words, then LDS gathers, then the MFMAs
-      for (uint32_t q0 = tt.z; q0 < tt.w; q0 += UQ) {
-        uint32_t w[UQ], ci[UQ];
+        for (int r = 0; r < 4; r++) {
+          int row = l4 + 4 * r, col = l15;
+          if (I == J && row < col) { const int t = row; row = col; col = t; }        // diagonal blocks hold their lower triangle
+          v[r] = Lb[((size_t)tt.y + (size_t)col * 16 + row) * kbt];
+        }
+        return v;
+      };
+      const uint32_t q_begin = ttab[t_begin].z, q_end = ttab[t_end - 1].w;
+      uint32_t ti = t_begin;
+      uint4 tt = ttab[ti];
+      mi_v4d acc = load_init(tt), acc_next = acc;
+      uint4 tt_next = tt;
+      if (ti + 1 < t_end) { tt_next = ttab[ti + 1]; acc_next = load_init(tt_next); }
+      uint32_t wn[UQ], cn[UQ];
+      auto fetch = [&](uint32_t qb) {
 #pragma unroll
         for (int u = 0; u < UQ; u++) {
-          const uint32_t q = q0 + u < tt.w ? q0 + u : tt.w - 1;
-          w[u] = a.asm_q[(size_t)q * 64 + lane]; ci[u] = a.asm_qcol[(size_t)q * 4 + l4];
+          const uint32_t q = qb + u < q_end ? qb + u : (q_end ? q_end - 1 : 0u);
+          wn[u] = q_begin < q_end ? a.asm_q[(size_t)q * 64 + lane] : 0u; cn[u] = q_begin < q_end ? (uint32_t)a.asm_qcol[(size_t)q * 4 + l4] : 0u;
         }
+      };
+      fetch(q_begin);
+      auto next_tile = [&]() {          // the current tile is complete: store it, move on (its successor's accumulator is already here)
+        st_tile(A, tile_ix((int)(tt.x >> 16), (int)(tt.x & 0xFFFFu)), lane, acc);
+        ti++;
+        if (ti < t_end) {
+          tt = tt_next; acc = acc_next;
+          if (ti + 1 < t_end) { tt_next = ttab[ti + 1]; acc_next = load_init(tt_next); }
+        }
+      };
+      for (uint32_t qb = q_begin; qb < q_end; qb += UQ) {
+        uint32_t w[UQ], ci[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) { w[u] = wn[u]; ci[u] = cn[u]; }
+        if (qb + UQ < q_end) fetch(qb + UQ);
         double av[UQ], bv[UQ];
 #pragma unroll
         for (int u = 0; u < UQ; u++) { av[u] = -La[w[u] & 0xFFFFu]; bv[u] = La[w[u] >> 16] * Dc[ci[u]]; }
 #pragma unroll
-        for (int u = 0; u < UQ; u++) if (q0 + u < tt.w) acc = mfma_f64(av[u], bv[u], acc);
+        for (int u = 0; u < UQ; u++) {
+          const uint32_t q = qb + u;
+          if (q < q_end) {
+            while (q >= tt.w) next_tile();            // (tiles without sources are passed over)
+            acc = mfma_f64(av[u], bv[u], acc);
+          }
+        }
       }
-      st_tile(A, tile_ix(I, J), lane, acc);
+      while (ti < t_end) next_tile();
     }
   }
   __syncthreads();
+  stamp(0);
   // ------------------------------------------------------------------ phases 1 .. k/64: blocked sweep
   const int nrt = nt - 4;                                   // row tiles outside a pivot block
   const int nh = a.nh;                                      // row tiles of one staged half of the panel (host: <= 14)
@@ -1510,29 +1552,45 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
     __syncthreads();
     // ---- Ts <- -inv(Ts): four 16-wide sub-sweeps
     for (int q = 0; q < 4; q++) {
-      if (wave == 0) {                                      // the 16 x 16 diagonal tile, scalar: U <- -inv(U)
+      if (wave == 0) {
+        // The 16 x 16 diagonal tile, scalar: U <- -inv(U).  Lane (r = lane % 16, g = lane / 16) keeps U[r][4g .. 4g+3] in
+        // registers; per pivot only the pivot row travels (through 16 doubles of LDS: U is symmetric, so the row also
+        // serves as the pivot column).  The update is u - (ta tb) di: commutative in (ta, tb), i.e. U stays EXACTLY
+        // symmetric.  1/d by v_rcp_f64 + two Newton steps (full precision, not correctly rounded).
         double *U = Ts + (16 * q) * MI_TAIL_TS + 16 * q;
+        double *rowbuf = Ps;                                // (Ps is rewritten after the block is done)
         const int r = l15, c0 = l4 * 4;
+        double u[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) u[cc] = U[r * MI_TAIL_TS + c0 + cc];
         for (int kk = 0; kk < 16; kk++) {
-          const double d = U[kk * MI_TAIL_TS + kk], di = 1.0 / d, ta = U[r * MI_TAIL_TS + kk];
+          if (r == kk) {
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) rowbuf[c0 + cc] = u[cc];
+          }
+          wave_sync();
+          const double d = rowbuf[kk], ta = rowbuf[r];
+          double tb[4];
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) tb[cc] = rowbuf[c0 + cc];
+          wave_sync();
           if (lane == 0 && d > 0.0) npos++;
-          double nv[4];
+          double di = __builtin_amdgcn_rcp(d);
+          di = fma(fma(-d, di, 1.0), di, di);
+          di = fma(fma(-d, di, 1.0), di, di);
 #pragma unroll
           for (int cc = 0; cc < 4; cc++) {
             const int c = c0 + cc;
-            const double tb = U[kk * MI_TAIL_TS + c];
-            double v = U[r * MI_TAIL_TS + c];
-            if (r != kk && c != kk) v -= ta * di * tb;
+            double v;
+            if (r != kk && c != kk) v = fma(-(ta * tb[cc]), di, u[cc]);
             else if (r == kk && c == kk) v = -di;
             else if (c == kk) v = ta * di;
-            else v = tb * di;
-            nv[cc] = v;
+            else v = tb[cc] * di;
+            u[cc] = v;
           }
-          wave_sync();
-#pragma unroll
-          for (int cc = 0; cc < 4; cc++) U[r * MI_TAIL_TS + c0 + cc] = nv[cc];
-          wave_sync();
         }
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) U[r * MI_TAIL_TS + c0 + cc] = u[cc];
       }
       __syncthreads();
       // the other three tile rows a of the block: gn_a' = Un c_a' (accumulator registers = A-operand fragments of gn_a),
@@ -1580,20 +1638,34 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
       Ps[e] = Ts[(16 * kt + (l & 15)) * MI_TAIL_TS + 4 * sp + (l >> 4)];
     }
     __syncthreads();
+    stamp(1);
     if (nrt == 0) continue;
     // ---- panel staging: positions [x0, x1) of the non-pivot row tiles -> Cs (16 steps x 64 lanes per row tile)
     auto stage = [&](int x0, int x1) {
-      for (int e = wave; e < (x1 - x0) * 4; e += MI_TAIL_NW) {
-        const int x = x0 + (e >> 2), qq = e & 3, t = nonp(x);
-        double *dst = Cs + (size_t)(x - x0) * 1024;
-        if (t < P0) {                 // stored tile (P0 + qq, t): rows = pivot columns, cols = the rows of C: already operand order
-          const mi_v4d v = ld_tile(A, tile_ix(P0 + qq, t), lane);
+      constexpr int MAXE = 7;            // (x1 - x0) * 4 <= 56 pieces over 8 waves
+      mi_v4d v[MAXE];
+      const int ne = (x1 - x0) * 4;
 #pragma unroll
-          for (int r = 0; r < 4; r++) dst[(4 * qq + r) * 64 + lane] = v[r];
-        } else {                      // stored tile (t, P0 + qq): rows = the rows of C, cols = pivot columns: transpose on the way
-          const mi_v4d v = ld_tile(A, tile_ix(t, P0 + qq), lane);
+      for (int i = 0; i < MAXE; i++) {
+        const int e = wave + i * MI_TAIL_NW;
+        if (e < ne) {
+          const int t = nonp(x0 + (e >> 2)), qq = e & 3;
+          v[i] = ld_tile(A, t < P0 ? tile_ix(P0 + qq, t) : tile_ix(t, P0 + qq), lane);
+        }
+      }
 #pragma unroll
-          for (int r = 0; r < 4; r++) dst[(4 * qq + (l15 >> 2)) * 64 + ((l15 & 3) << 4) + l4 + 4 * r] = v[r];
+      for (int i = 0; i < MAXE; i++) {
+        const int e = wave + i * MI_TAIL_NW;
+        if (e < ne) {
+          const int x = x0 + (e >> 2), qq = e & 3, t = nonp(x);
+          double *dst = Cs + (size_t)(x - x0) * 1024;
+          if (t < P0) {               // stored tile (P0 + qq, t): rows = pivot columns, cols = the rows of C: already operand order
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * qq + r) * 64 + lane] = v[i][r];
+          } else {                    // stored tile (t, P0 + qq): rows = the rows of C, cols = pivot columns: transpose on the way
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(4 * qq + (l15 >> 2)) * 64 + ((l15 & 3) << 4) + l4 + 4 * r] = v[i][r];
+          }
         }
       }
     };
@@ -1631,19 +1703,17 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
           return c;
         };
         auto tix = [&](int y) { return tile_ix(I, nonp(y)); };
-        mi_v4d c0 = ld_tile(A, tix(y0), lane), c1 = c0, c2 = c0;
-        if (y0 + 1 <= yend) c1 = ld_tile(A, tix(y0 + 1), lane);
-        if (y0 + 2 <= yend) c2 = ld_tile(A, tix(y0 + 2), lane);
-        for (int y = y0; y <= yend; y += 3) {
-          c0 = upd(c0, y); st_tile(A, tix(y), lane, c0);
-          if (y + 3 <= yend) c0 = ld_tile(A, tix(y + 3), lane);
-          if (y + 1 <= yend) {
-            c1 = upd(c1, y + 1); st_tile(A, tix(y + 1), lane, c1);
-            if (y + 4 <= yend) c1 = ld_tile(A, tix(y + 4), lane);
-          }
-          if (y + 2 <= yend) {
-            c2 = upd(c2, y + 2); st_tile(A, tix(y + 2), lane, c2);
-            if (y + 5 <= yend) c2 = ld_tile(A, tix(y + 5), lane);
+        constexpr int PFT = 6;             // accumulator tiles in flight per wave (an HBM round trip is ~5 tile updates long)
+        mi_v4d c[PFT];
+#pragma unroll
+        for (int u = 0; u < PFT; u++) c[u] = ld_tile(A, tix(y0 + u <= yend ? y0 + u : yend), lane);
+        for (int y = y0; y <= yend; y += PFT) {
+#pragma unroll
+          for (int u = 0; u < PFT; u++) {
+            if (y + u <= yend) {
+              c[u] = upd(c[u], y + u); st_tile(A, tix(y + u), lane, c[u]);
+              if (y + u + PFT <= yend) c[u] = ld_tile(A, tix(y + u + PFT), lane);
+            }
           }
         }
       }
@@ -1682,17 +1752,33 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
       }
     }
     __syncthreads();
+    stamp(2);
   }
   // ---- M = -A into the QP's stream of the symmetric product, its diagonal into dinv
   {
     double *dv = a.dt_val + (size_t)slot * a.n_slots;
-    for (uint32_t e = tid; e < a.n_slots; e += nthr) { const int32_t sc = a.src_tile[e]; dv[e] = sc >= 0 ? -A[sc] : 0.0; }
+    constexpr int UW = 8;                // index reads, then the scattered value reads, then the stores: 8 independent chains per thread
+    for (uint32_t e0 = tid; e0 < a.n_slots; e0 += (uint32_t)nthr * UW) {
+      int32_t sc[UW];
+      double v[UW];
+#pragma unroll
+      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); sc[u] = e < a.n_slots ? a.src_tile[e] : MI_SRC_ZERO; }
+#pragma unroll
+      for (int u = 0; u < UW; u++) v[u] = sc[u] >= 0 ? -A[sc[u]] : 0.0;
+#pragma unroll
+      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); if (e < a.n_slots) dv[e] = v[u]; }
+    }
     for (int i = tid; i < k; i += nthr) a.dinv[H(a.N, (size_t)a.s + i)] = -A[a.diag_tile[i]];
   }
   if (tid == 0) {
     const int total = a.npos[slot] + npos;
     a.npos[slot] = total;
     if (total != a.n) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = -1;
+  }
+  if (a.trace) {
+    __syncthreads();
+    stamp(3);
+    if (tid == 0) for (int i = 0; i < 4; i++) a.trace[(size_t)g * 4 + i] = tr_acc[i];
   }
 }
 hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds, hipStream_t st) {

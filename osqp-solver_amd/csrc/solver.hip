@@ -738,7 +738,21 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
     da.lt_pos = h->dt_lt_pos.p; da.ltcol_col = h->dt_ltcol_col.p; da.tile_tab = h->dt_tile_tab.p; da.wave_tiles = h->dt_wave_tiles.p;
     da.asm_q = h->dt_asm_q.p; da.diag_tile = h->dt_diag_tile.p; da.asm_qcol = h->dt_asm_qcol.p; da.src_tile = h->dt_src_tile.p;
     da.Lblk = h->Lblk.p; da.Dl = h->Dl.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
+    unsigned long long *d_trace = nullptr;
+    const bool tracing = getenv("MI_OSQP_TAIL_TRACE") != nullptr;          // timing stamps only; results are unaffected
+    if (tracing) { HIPCHK(hipMalloc((void **)&d_trace, (size_t)wtiles * kbt * 4 * sizeof(unsigned long long))); HIPCHK(hipMemsetAsync(d_trace, 0, (size_t)wtiles * kbt * 32, h->stream)); }
+    da.trace = d_trace;
     HIPCHK(launch_tail(da, wtiles * kbt, h->dt_lds, h->stream));
+    if (tracing) {
+      std::vector<unsigned long long> tr((size_t)wtiles * kbt * 4);
+      HIPCHK(hipStreamSynchronize(h->stream));
+      HIPCHK(hipMemcpy(tr.data(), d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      (void)hipFree(d_trace);
+      double sum[4] = {0, 0, 0, 0};
+      for (size_t i = 0; i < tr.size(); i++) sum[i % 4] += (double)tr[i];
+      fprintf(stderr, "[mi_osqp] tail_kernel, %d QPs, mean shader clocks of wave 0 per QP: assembly %.0f, pivot blocks %.0f, panel + trailing %.0f, stream write %.0f\n",
+              wtiles * kbt, sum[0] / (wtiles * kbt), sum[1] / (wtiles * kbt), sum[2] / (wtiles * kbt), sum[3] / (wtiles * kbt));
+    }
   }
   HIPCHK(hipEventRecord(h->evf2, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
