@@ -79,6 +79,7 @@ struct TailArgs {
   int n, N, s, k, kbt, home_bt;
   uint32_t storage, n_slots;
   int n_lt, n_ltcol;
+  uint32_t n_quads;             // length of asm_q / 64
   int nh;                       // row tiles of one staged half of the panel
   uint32_t cs_doubles;          // LDS doubles reserved for the staged panel / the pivot block's image (Ps follows)
   const int *work;              // slot of every (work tile, lane class), -1 = none
@@ -88,9 +89,9 @@ struct TailArgs {
   const double *Lblk, *Dl;
   double *Sd, *dt_val, *dinv;
   int *npos, *iscal;
-  unsigned long long *trace;    // null, or 4 clock sums per workgroup (MI_OSQP_TAIL_TRACE)
+  unsigned long long *trace;    // null, or 8 clock sums per workgroup (MI_OSQP_TAIL_TRACE)
 };
-hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds, hipStream_t st);
+hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds_asm, size_t lds, hipStream_t st);
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
 

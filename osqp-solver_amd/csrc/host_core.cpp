@@ -843,7 +843,7 @@ static void build_block_factor(Analysis &an) {
         tiles.push_back(std::move(t));
       }
     // tiles to waves: longest first, dealt in snake order (balanced without a queue on the device)
-    const int nw = 8;
+    const int nw = 16;                    // waves of tail_assemble_kernel (one 1024-thread workgroup per QP)
     std::vector<int> order(tiles.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tiles[x].src.size() > tiles[y].src.size(); });
@@ -855,7 +855,9 @@ static void build_block_factor(Analysis &an) {
       for (int ti : mine[w]) {
         const TileRec &t = tiles[ti];
         const uint32_t q0 = (uint32_t)(dt.asm_q.size() / 64);
-        for (size_t s0 = 0; s0 < t.src.size(); s0 += 4) {
+        // (padded to whole blocks of 8 quads = 32 sources: tail_kernel walks the tables in straight-line blocks of 8)
+        const size_t padded = (t.src.size() + 31) / 32 * 32;
+        for (size_t s0 = 0; s0 < padded; s0 += 4) {
           for (int g = 0; g < 4; g++) {
             const bool real = s0 + g < t.src.size();
             const auto *fa = real ? &frag[t.I][t.src[s0 + g].first] : nullptr;

@@ -1432,40 +1432,35 @@ __device__ __forceinline__ void st_tile(double *A, uint32_t tix, int lane, mi_v4
 __device__ __forceinline__ uint32_t tile_ix(int I, int J) { return (uint32_t)(I * (I + 1) / 2 + J); }
 
 #define MI_TAIL_NW 8
-#define MI_TAIL_MAXSLOT 4          // row tiles a wave may own: ceil((512 / 16 - 4) / 8)
 #define MI_TAIL_TS 65              // row stride of the pivot block's LDS image
 
-__global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
+// Phase 0 of the dense tail as a kernel of its own: 16 waves per QP (1024 threads; the loop is a chain of L2 table reads,
+// LDS gathers and one MFMA per 4 sources - latency, not the matrix pipe, bounds it, so twice the waves of tail_kernel
+// halve it), 93 KB of LDS for the compact factor entries at config 3.
+__global__ __launch_bounds__(1024) void tail_assemble_kernel(TailArgs a) {
   extern __shared__ double smem[];
   const int g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = a.work[g];
   if (slot < 0) return;
-  const int k = a.k, kbt = a.kbt, wt = g / kbt, wb = g % kbt, nt = k / 16;
-  const size_t hbt = (size_t)a.home_bt, home = (size_t)slot / hbt, hb = (size_t)slot % hbt;
-  auto H = [&](size_t len, size_t i) { return (home * len + i) * hbt + hb; };
+  const int k = a.k, kbt = a.kbt, wt = g / kbt, wb = g % kbt;
   double *A = a.Sd + (size_t)g * k * k;
   const double *Lb = a.Lblk + (size_t)wt * a.storage * kbt + wb;
   const double *Dl = a.Dl + (size_t)wt * a.N * kbt + wb;
   const int l15 = lane & 15, l4 = lane >> 4;
-  // timing stamps of wave 0 (MI_OSQP_TAIL_TRACE=1: a.trace != null; results are not affected): assembly, pivot blocks,
-  // panel + trailing updates, stream write - shader clocks summed over the passes
-  unsigned long long tr_t = a.trace ? __builtin_amdgcn_s_memtime() : 0ull, tr_acc[4] = {0ull, 0ull, 0ull, 0ull};
-  auto stamp = [&](int which) {
-    if (a.trace && wave == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[which] += t - tr_t; tr_t = t; }
-  };
-  // ------------------------------------------------------------------ phase 0: assembly
   {
     double *La = smem, *Dc = smem + a.n_lt + 1;
     for (int e = tid; e < a.n_lt; e += nthr) La[e] = Lb[(size_t)a.lt_pos[e] * kbt];
     if (tid == 0) La[a.n_lt] = 0.0;
     for (int c = tid; c < a.n_ltcol; c += nthr) Dc[c] = Dl[(size_t)a.ltcol_col[c] * kbt];
     __syncthreads();
-    // The quads of a wave's tiles are one linear stream of the two tables (tiles are laid out wave-major): the words of the
-    // next UQ quads are in flight while the current UQ are gathered from LDS and multiplied, across tile boundaries; the
-    // initial accumulator of the next tile is fetched one tile ahead.  (One 4-quad group at a time used to cost one L2
-    // round trip each: 0.9 M clocks per QP, 7 x the MFMA time.)
-    constexpr int UQ = 16;
+    // The quads of a wave's tiles are one linear stream of the two tables (tiles are laid out wave-major, each padded to
+    // whole blocks of QB quads).  The stream runs NB blocks ahead of its use in a shift register of table words; every
+    // global load of the loop sits in straight-line code (clamped indices instead of branches), because the compiler can
+    // only keep its wait counts apart from vmcnt(0) when the number of loads in flight is the same on every path - with a
+    // conditional tile switch inside the loop each block of quads cost one L2 round trip (0.5 M clocks per QP, 4 x the
+    // MFMA time).  The initial accumulator (the KKT block) of the next tile is fetched one tile ahead.
+    constexpr int QB = 8, NB = 4;
     const uint32_t t_begin = a.wave_tiles[wave], t_end = a.wave_tiles[wave + 1];
     if (t_begin < t_end) {
       const uint4 *ttab = reinterpret_cast<const uint4 *>(a.tile_tab);
@@ -1480,50 +1475,67 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
         }
         return v;
       };
-      const uint32_t q_begin = ttab[t_begin].z, q_end = ttab[t_end - 1].w;
-      uint32_t ti = t_begin;
-      uint4 tt = ttab[ti];
-      mi_v4d acc = load_init(tt), acc_next = acc;
-      uint4 tt_next = tt;
-      if (ti + 1 < t_end) { tt_next = ttab[ti + 1]; acc_next = load_init(tt_next); }
-      uint32_t wn[UQ], cn[UQ];
-      auto fetch = [&](uint32_t qb) {
+      const uint32_t q_last = a.n_quads ? a.n_quads - 1 : 0u;
+      uint32_t rw[NB][QB], rc[NB][QB];
+      auto fetch = [&](uint32_t qb, uint32_t (&wd)[QB], uint32_t (&cd)[QB]) {
 #pragma unroll
-        for (int u = 0; u < UQ; u++) {
-          const uint32_t q = qb + u < q_end ? qb + u : (q_end ? q_end - 1 : 0u);
-          wn[u] = q_begin < q_end ? a.asm_q[(size_t)q * 64 + lane] : 0u; cn[u] = q_begin < q_end ? (uint32_t)a.asm_qcol[(size_t)q * 4 + l4] : 0u;
+        for (int u = 0; u < QB; u++) {
+          const uint32_t q = qb + u < q_last ? qb + u : q_last;
+          wd[u] = a.asm_q[(size_t)q * 64 + lane]; cd[u] = (uint32_t)a.asm_qcol[(size_t)q * 4 + l4];
         }
       };
-      fetch(q_begin);
-      auto next_tile = [&]() {          // the current tile is complete: store it, move on (its successor's accumulator is already here)
-        st_tile(A, tile_ix((int)(tt.x >> 16), (int)(tt.x & 0xFFFFu)), lane, acc);
-        ti++;
-        if (ti < t_end) {
-          tt = tt_next; acc = acc_next;
-          if (ti + 1 < t_end) { tt_next = ttab[ti + 1]; acc_next = load_init(tt_next); }
-        }
-      };
-      for (uint32_t qb = q_begin; qb < q_end; qb += UQ) {
-        uint32_t w[UQ], ci[UQ];
+      uint32_t qnext = ttab[t_begin].z;                      // first quad not yet requested
+      if (a.n_quads) {
 #pragma unroll
-        for (int u = 0; u < UQ; u++) { w[u] = wn[u]; ci[u] = cn[u]; }
-        if (qb + UQ < q_end) fetch(qb + UQ);
-        double av[UQ], bv[UQ];
-#pragma unroll
-        for (int u = 0; u < UQ; u++) { av[u] = -La[w[u] & 0xFFFFu]; bv[u] = La[w[u] >> 16] * Dc[ci[u]]; }
-#pragma unroll
-        for (int u = 0; u < UQ; u++) {
-          const uint32_t q = qb + u;
-          if (q < q_end) {
-            while (q >= tt.w) next_tile();            // (tiles without sources are passed over)
-            acc = mfma_f64(av[u], bv[u], acc);
-          }
-        }
+        for (int b = 0; b < NB; b++) { fetch(qnext, rw[b], rc[b]); qnext += QB; }
       }
-      while (ti < t_end) next_tile();
+      mi_v4d acc_next = load_init(ttab[t_begin]);
+      for (uint32_t ti = t_begin; ti < t_end; ti++) {
+        const uint4 tt = ttab[ti];
+        mi_v4d acc = acc_next;
+        acc_next = load_init(ttab[ti + 1 < t_end ? ti + 1 : ti]);
+        for (uint32_t q = tt.z; q < tt.w; q += QB) {
+          uint32_t w[QB], ci[QB];
+#pragma unroll
+          for (int u = 0; u < QB; u++) { w[u] = rw[0][u]; ci[u] = rc[0][u]; }
+#pragma unroll
+          for (int b = 0; b + 1 < NB; b++)
+#pragma unroll
+            for (int u = 0; u < QB; u++) { rw[b][u] = rw[b + 1][u]; rc[b][u] = rc[b + 1][u]; }
+          fetch(qnext, rw[NB - 1], rc[NB - 1]); qnext += QB;
+          double av[QB], bv[QB];
+#pragma unroll
+          for (int u = 0; u < QB; u++) { av[u] = -La[w[u] & 0xFFFFu]; bv[u] = La[w[u] >> 16] * Dc[ci[u]]; }
+#pragma unroll
+          for (int u = 0; u < QB; u++) acc = mfma_f64(av[u], bv[u], acc);
+        }
+        st_tile(A, tile_ix((int)(tt.x >> 16), (int)(tt.x & 0xFFFFu)), lane, acc);
+      }
     }
   }
-  __syncthreads();
+}
+
+// MAXSLOT = row tiles a wave may own = ceil((k / 16 - 4) / 8): 4 at k = 512, 3 up to 448, ...; every slot costs 32 VGPRs
+// (its Gn fragments), which the smaller instantiations spend on a deeper accumulator ring (PFT tiles in flight per wave)
+template <int MI_TAIL_MAXSLOT, int PFT>
+__global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
+  extern __shared__ double smem[];
+  const int g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = a.work[g];
+  if (slot < 0) return;
+  const int k = a.k, kbt = a.kbt, wt = g / kbt, wb = g % kbt, nt = k / 16;
+  const size_t hbt = (size_t)a.home_bt, home = (size_t)slot / hbt, hb = (size_t)slot % hbt;
+  auto H = [&](size_t len, size_t i) { return (home * len + i) * hbt + hb; };
+  double *A = a.Sd + (size_t)g * k * k;                     // the tiles tail_assemble_kernel left here
+  (void)wt; (void)wb;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // timing stamps of wave 0 (MI_OSQP_TAIL_TRACE=1: a.trace != null; results are not affected): assembly, pivot blocks,
+  // panel + trailing updates, stream write - shader clocks summed over the passes
+  unsigned long long tr_t = a.trace ? __builtin_amdgcn_s_memtime() : 0ull, tr_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  auto stamp = [&](int which) {
+    if (a.trace && wave == 0) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr_acc[which] += t - tr_t; tr_t = t; }
+  };
   stamp(0);
   // ------------------------------------------------------------------ phases 1 .. k/64: blocked sweep
   const int nrt = nt - 4;                                   // row tiles outside a pivot block
@@ -1646,12 +1658,10 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
       mi_v4d v[MAXE];
       const int ne = (x1 - x0) * 4;
 #pragma unroll
-      for (int i = 0; i < MAXE; i++) {
-        const int e = wave + i * MI_TAIL_NW;
-        if (e < ne) {
-          const int t = nonp(x0 + (e >> 2)), qq = e & 3;
-          v[i] = ld_tile(A, t < P0 ? tile_ix(P0 + qq, t) : tile_ix(t, P0 + qq), lane);
-        }
+      for (int i = 0; i < MAXE; i++) {          // (loads past the end re-read the last piece: no branch around a load)
+        const int e0 = wave + i * MI_TAIL_NW, e = e0 < ne ? e0 : ne - 1;
+        const int t = nonp(x0 + (e >> 2)), qq = e & 3;
+        v[i] = ld_tile(A, t < P0 ? tile_ix(P0 + qq, t) : tile_ix(t, P0 + qq), lane);
       }
 #pragma unroll
       for (int i = 0; i < MAXE; i++) {
@@ -1703,17 +1713,21 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
           return c;
         };
         auto tix = [&](int y) { return tile_ix(I, nonp(y)); };
-        constexpr int PFT = 6;             // accumulator tiles in flight per wave (an HBM round trip is ~5 tile updates long)
+        // PFT accumulator tiles in flight (an HBM round trip under load is several tile updates long).  Straight-line
+        // ring: every trip updates PFT tiles; positions past yend work on the wave's dummy tile behind the triangle
+        // (loaded, updated with the last column's operand, stored - never read by anyone), so that no load or store of
+        // the loop sits behind a branch and the wait counts stay exact.
+        const uint32_t dummy = (uint32_t)(nt * (nt + 1) / 2) + (uint32_t)wave;
+        auto tix_or_dummy = [&](int y) { return y <= yend ? tix(y) : dummy; };
         mi_v4d c[PFT];
 #pragma unroll
-        for (int u = 0; u < PFT; u++) c[u] = ld_tile(A, tix(y0 + u <= yend ? y0 + u : yend), lane);
+        for (int u = 0; u < PFT; u++) c[u] = ld_tile(A, tix_or_dummy(y0 + u), lane);
         for (int y = y0; y <= yend; y += PFT) {
 #pragma unroll
           for (int u = 0; u < PFT; u++) {
-            if (y + u <= yend) {
-              c[u] = upd(c[u], y + u); st_tile(A, tix(y + u), lane, c[u]);
-              if (y + u + PFT <= yend) c[u] = ld_tile(A, tix(y + u + PFT), lane);
-            }
+            c[u] = upd(c[u], y + u <= yend ? y + u : yend);
+            st_tile(A, tix_or_dummy(y + u), lane, c[u]);
+            c[u] = ld_tile(A, tix_or_dummy(y + u + PFT), lane);
           }
         }
       }
@@ -1729,10 +1743,15 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
       else if (stp == 1) { sx0 = 0; sx1 = h0; rx0 = 0; rx1 = nrt; gflag = 1; }
       else { sx0 = h0; sx1 = nrt; rx0 = h0; rx1 = nrt; gflag = 0; }
       if (stp) __syncthreads();         // everybody is done with the previous staging
+      stamp(7);
       stage(sx0, sx1);
+      stamp(4);
       __syncthreads();
+      stamp(7);
       if (gflag) compute_g(sx0, sx1);
+      stamp(5);
       trailing(rx0, rx1, sx0, sx1);
+      stamp(6);
     }
     // ---- the panel takes G = -Gn (nobody reads the old panel from the scratch any more: every staging is behind us)
 #pragma unroll
@@ -1751,22 +1770,33 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
         }
       }
     }
-    __syncthreads();
     stamp(2);
+    __syncthreads();
+    stamp(7);
   }
   // ---- M = -A into the QP's stream of the symmetric product, its diagonal into dinv
   {
     double *dv = a.dt_val + (size_t)slot * a.n_slots;
-    constexpr int UW = 8;                // index reads, then the scattered value reads, then the stores: 8 independent chains per thread
+    // 14 independent gathers per thread and trip, the index words one trip ahead; positions past the end repeat the last
+    // slot (same value written twice) instead of branching around the loads
+    constexpr int UW = 14;
+    const uint32_t last = a.n_slots - 1;
+    int32_t scn[UW];
+    auto fetch_idx = [&](uint32_t e0) {
+#pragma unroll
+      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); scn[u] = a.src_tile[e < last ? e : last]; }
+    };
+    fetch_idx((uint32_t)tid);
     for (uint32_t e0 = tid; e0 < a.n_slots; e0 += (uint32_t)nthr * UW) {
       int32_t sc[UW];
       double v[UW];
 #pragma unroll
-      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); sc[u] = e < a.n_slots ? a.src_tile[e] : MI_SRC_ZERO; }
+      for (int u = 0; u < UW; u++) sc[u] = scn[u];
+      fetch_idx(e0 + (uint32_t)nthr * UW);
 #pragma unroll
-      for (int u = 0; u < UW; u++) v[u] = sc[u] >= 0 ? -A[sc[u]] : 0.0;
+      for (int u = 0; u < UW; u++) { const double t = A[sc[u] >= 0 ? sc[u] : 0]; v[u] = sc[u] >= 0 ? -t : 0.0; }
 #pragma unroll
-      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); if (e < a.n_slots) dv[e] = v[u]; }
+      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); dv[e < last ? e : last] = v[u]; }
     }
     for (int i = tid; i < k; i += nthr) a.dinv[H(a.N, (size_t)a.s + i)] = -A[a.diag_tile[i]];
   }
@@ -1778,15 +1808,28 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
   if (a.trace) {
     __syncthreads();
     stamp(3);
-    if (tid == 0) for (int i = 0; i < 4; i++) a.trace[(size_t)g * 4 + i] = tr_acc[i];
+    if (tid == 0) for (int i = 0; i < 8; i++) a.trace[(size_t)g * 8 + i] = tr_acc[i];
   }
 }
-hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds, hipStream_t st) {
+hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds_asm, size_t lds, hipStream_t st) {
   if (a.k > 512 || (a.k & 63) || a.k < 64) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tail_kernel, dim3(nwork), dim3(512), lds, st, a);
-  return hipGetLastError();
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tail_assemble_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_asm);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tail_assemble_kernel, dim3(nwork), dim3(1024), lds_asm, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nwork), dim3(512), lds, st, a);
+    return hipGetLastError();
+  };
+  const int slots = (a.k / 16 - 4 + MI_TAIL_NW - 1) / MI_TAIL_NW;
+  if (slots <= 1) return go(&tail_kernel<1, 4>);
+  if (slots == 2) return go(&tail_kernel<2, 4>);
+  if (slots == 3) return go(&tail_kernel<3, 4>);
+  return go(&tail_kernel<4, 4>);
 }
 
 // ------------------------------------------------- layout / upload kernels

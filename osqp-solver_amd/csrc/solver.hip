@@ -18,6 +18,7 @@
 #include <string>
 #include <thread>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -170,7 +171,7 @@ struct SchedBufs {
 
 struct mi_osqp_batch {
   Settings st;
-  Analysis an;
+  std::shared_ptr<const Analysis> anp;        // pattern analysis: shared between the handles of one pattern (analysis cache below)
   int B = 0, BT = 1, ntiles = 0, threads = 512, device = 0, n_cus = 256;
   size_t lds = 0;
   std::vector<QPNumeric> qp;
@@ -193,7 +194,7 @@ struct mi_osqp_batch {
   DevBuf<uint32_t> dt_lt_pos, dt_ltcol_col, dt_tile_tab, dt_wave_tiles, dt_asm_q, dt_diag_tile;     // tail_kernel tables
   DevBuf<uint16_t> dt_asm_qcol;
   DevBuf<int32_t> dt_src_tile;
-  int dt_nh = 0; uint32_t dt_cs_doubles = 0; size_t dt_lds = 0;
+  int dt_nh = 0; uint32_t dt_cs_doubles = 0; size_t dt_lds = 0, dt_lds_asm = 0;
   DevBuf<int32_t> dt_src;
   DevBuf<double> dt_val, dt_val0, dt_Sd;
   DevBuf<uint32_t> sp_ptr, sp_ent;      // fused SpMV op (spmv_fused_kernel); empty when not eligible
@@ -260,8 +261,8 @@ static size_t lds_bytes(int N, int BT, int threads) {
 
 static KernelArgs make_args(mi_osqp_batch *h) {
   KernelArgs a{};
-  a.n = h->an.n; a.m = h->an.m; a.N = h->an.N; a.B = h->B;
-  a.fwd = h->fwd.view(h->an.fwd); a.bwd = h->bwd.view(h->an.bwd); a.chk = h->chk.view(h->an.chk);
+  a.n = (*h->anp).n; a.m = (*h->anp).m; a.N = (*h->anp).N; a.B = h->B;
+  a.fwd = h->fwd.view((*h->anp).fwd); a.bwd = h->bwd.view((*h->anp).bwd); a.chk = h->chk.view((*h->anp).chk);
   a.pinv = h->pinv.p; a.xloc = h->xloc.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.chk_val = h->chk_val.p; a.dinv = h->dinv.p;
   a.x = h->x.p; a.z = h->z.p; a.y = h->y.p; a.q = h->q.p; a.l = h->l.p; a.u = h->u.p;
@@ -269,9 +270,9 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
-  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = h->an.Next; a.wide = h->an.wide ? 1 : 0;
+  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = (*h->anp).Next; a.wide = (*h->anp).wide ? 1 : 0;
   {
-    const DenseTail &dt = h->an.dt;
+    const DenseTail &dt = (*h->anp).dt;
     a.dt.s = dt.s; a.dt.k = dt.k; a.dt.n_phases = dt.n_phases; a.dt.n_steps = dt.n_steps;
     a.dt.task = h->dt_task.p; a.dt.wave_task = h->dt_wave_task.p; a.dt.wave_step = h->dt_wave_step.p; a.dt.tail_bar = h->dt_tail_bar.p;
     a.dt_val = h->dt_val.p;
@@ -287,7 +288,7 @@ static KernelArgs make_args(mi_osqp_batch *h) {
 
 static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   FactorArgs a{};
-  const Analysis &an = h->an;
+  const Analysis &an = (*h->anp);
   a.n = an.n; a.m = an.m; a.N = an.N; a.B = h->B; a.nnzP = an.Pp[an.n]; a.nnzK = an.nnzK();
   a.pa_len = an.Pp[an.n] + an.Ap[an.n]; a.n_levels = an.bf.n_levels; a.force_all = force_all;
   a.storage = an.bf.storage; a.fwd = h->fwd.view(an.fwd); a.bwd = h->bwd.view(an.bwd);
@@ -332,7 +333,7 @@ static std::vector<double> gather_rows(const std::vector<int> &ids, int len, G &
 }
 
 static int upload_rho(mi_osqp_batch *h, const std::vector<int> &ids) {
-  int m = h->an.m, nq = (int)ids.size(), rc;
+  int m = (*h->anp).m, nq = (int)ids.size(), rc;
   if (!nq || !m) return 0;
   std::vector<double> r1 = gather_rows(ids, m, [&](int q) -> const std::vector<double> & { return h->qp[q].rho_vec; });
   if ((rc = upload_rows(h, r1, &ids, nq, m, h->rho_vec.p))) return rc;
@@ -342,7 +343,7 @@ static int upload_rho(mi_osqp_batch *h, const std::vector<int> &ids) {
 
 // scaled problem data, scalings, scalars of the listed QPs
 static int upload_problem(mi_osqp_batch *h, const std::vector<int> &ids, bool with_matrices) {
-  const Analysis &an = h->an;
+  const Analysis &an = (*h->anp);
   int n = an.n, m = an.m, nq = (int)ids.size(), rc;
   if (!nq) return 0;
   auto up = [&](int len, double *dst, auto get) -> int {
@@ -408,7 +409,7 @@ static int snapshot(mi_osqp_batch *h) {
 // download scaled l,u from the device into the host mirrors (after device-side bound updates)
 static int sync_bounds_to_host(mi_osqp_batch *h) {
   if (!h->host_bounds_stale) return 0;
-  int m = h->an.m, B = h->B, rc;
+  int m = (*h->anp).m, B = h->B, rc;
   if ((rc = ensure_stage(h, (size_t)B * m + 1, 0))) return rc;
   std::vector<double> tmp((size_t)B * m);
   for (int which = 0; which < 2; which++) {
@@ -433,7 +434,7 @@ static int sync_rho_to_host(mi_osqp_batch *h) {
   HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
   for (int q = 0; q < h->B; q++) {
     double r = h->h_dscal[(size_t)(q / h->BT) * DS_COUNT * h->BT + DS_RHO * h->BT + q % h->BT];
-    if (r != h->qp[q].rho) apply_rho(h->an, h->qp[q], r);
+    if (r != h->qp[q].rho) apply_rho((*h->anp), h->qp[q], r);
   }
   h->host_rho_stale = false;
   return 0;
@@ -461,6 +462,61 @@ static int reset_solve_state(mi_osqp_batch *h, bool cold) {
 }
 
 // ------------------------------------------------------------------- setup
+
+// Pattern analysis (ordering, symbolic factor, step streams, block-factor and dense-tail tables) depends only on the
+// sparsity pattern and the launch shape.  The GOMP drivers build one solver per horizon segment and the same ten
+// patterns come back on every run(): the last analyses are kept (process-wide, keyed by a hash of the pattern, verified
+// by a full comparison) and shared read-only between handles.  MI_OSQP_ANALYSIS_CACHE=0 switches the cache off.
+namespace ancache {
+struct Entry {
+  uint64_t hash; int64_t n, m; int nw, bt, max_extra, dt_max; std::string env;
+  std::vector<int64_t> Pp, Pi, Ap, Ai;
+  std::shared_ptr<const Analysis> an;
+};
+static std::mutex mu;
+static std::vector<Entry> entries;            // most recently used last
+constexpr size_t kMaxEntries = 24;
+static uint64_t fnv(uint64_t h, const void *p, size_t bytes) {
+  const unsigned char *c = (const unsigned char *)p;
+  for (size_t i = 0; i < bytes; i++) { h ^= c[i]; h *= 1099511628211ull; }
+  return h;
+}
+}  // namespace ancache
+
+static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap, const int64_t *Ai, int nw,
+                           int bt, int max_extra, int dt_max, std::shared_ptr<const Analysis> &out) {
+  const char *off = getenv("MI_OSQP_ANALYSIS_CACHE");
+  const bool use = !(off && atoi(off) == 0) && n > 0 && m >= 0 && Pp && Ap && Pp[0] == 0 && Ap[0] == 0 && Pp[n] >= 0 && Ap[n] >= 0 &&
+                   Pp[n] < ((int64_t)1 << 30) && Ap[n] < ((int64_t)1 << 30);
+  std::string env;                              // the knobs analyze() reads
+  for (const char *k : {"MI_OSQP_DENSE_TAIL", "MI_OSQP_ORDERING"}) { const char *v = getenv(k); env += v ? v : "-"; env += ';'; }
+  uint64_t hsh = 1469598103934665603ull;
+  if (use) {
+    hsh = ancache::fnv(hsh, Pp, (size_t)(n + 1) * 8); hsh = ancache::fnv(hsh, Pi, (size_t)Pp[n] * 8);
+    hsh = ancache::fnv(hsh, Ap, (size_t)(n + 1) * 8); hsh = ancache::fnv(hsh, Ai, (size_t)Ap[n] * 8);
+    std::lock_guard<std::mutex> lk(ancache::mu);
+    for (size_t i = 0; i < ancache::entries.size(); i++) {
+      ancache::Entry &e = ancache::entries[i];
+      if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.env != env) continue;
+      if ((int64_t)e.Pi.size() != Pp[n] || (int64_t)e.Ai.size() != Ap[n] || memcmp(e.Pp.data(), Pp, (size_t)(n + 1) * 8) ||
+          memcmp(e.Pi.data(), Pi, (size_t)Pp[n] * 8) || memcmp(e.Ap.data(), Ap, (size_t)(n + 1) * 8) || memcmp(e.Ai.data(), Ai, (size_t)Ap[n] * 8)) continue;
+      out = e.an;
+      std::rotate(ancache::entries.begin() + i, ancache::entries.begin() + i + 1, ancache::entries.end());
+      return MI_OSQP_OK;
+    }
+  }
+  auto an = std::make_shared<Analysis>();
+  const int rc = analyze(n, m, Pp, Pi, Ap, Ai, *an, nw, bt, max_extra, dt_max);
+  if (rc) return rc;
+  out = an;
+  if (use) {
+    ancache::Entry e{hsh, n, m, nw, bt, max_extra, dt_max, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, out};
+    std::lock_guard<std::mutex> lk(ancache::mu);
+    if (ancache::entries.size() >= ancache::kMaxEntries) ancache::entries.erase(ancache::entries.begin());
+    ancache::entries.push_back(std::move(e));
+  }
+  return MI_OSQP_OK;
+}
 
 static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
 
@@ -503,10 +559,10 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   const double ta0 = now_s();
   // dense tail (inverted Schur complement of the trailing rows): needs the LDS vector and <= 512 rows (one row per
   // thread of dense_inverse_kernel; k^3 flops per refactorisation)
-  int rc = analyze(n, m, Pp, Pi, Ap, Ai, h->an, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512);
+  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->anp);
   const double t_analysis = now_s() - ta0;
   if (rc) return rc;
-  const Analysis &an = h->an;
+  const Analysis &an = (*h->anp);
   h->B = (int)B;
   h->failed.assign((size_t)B, 0);
   // ---- device
@@ -550,8 +606,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const int nrt = dt.k / 16 - 4;
     h->dt_nh = nrt <= 14 ? std::max(nrt, 1) : (nrt + 1) / 2;
     h->dt_cs_doubles = (uint32_t)std::max(h->dt_nh * 1024, 64 * 65 + 63) / 64 * 64;
-    h->dt_lds = std::max(((size_t)h->dt_cs_doubles + 4096) * sizeof(double), (dt.asm_lds_bytes() + 255) & ~(size_t)255);
-    if (h->dt_lds > lds_cap) { g_last_error = "internal: LDS budget of tail_kernel exceeded"; return MI_OSQP_ERR_ALLOC; }
+    h->dt_lds = ((size_t)h->dt_cs_doubles + 4096) * sizeof(double);
+    h->dt_lds_asm = (dt.asm_lds_bytes() + 255) & ~(size_t)255;
+    if (h->dt_lds > lds_cap || h->dt_lds_asm > lds_cap) { g_last_error = "internal: LDS budget of tail_kernel exceeded"; return MI_OSQP_ERR_ALLOC; }
   }
 #undef ALLOC
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
@@ -729,29 +786,29 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipEventRecord(h->evf0, h->stream));
   HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
   HIPCHK(hipEventRecord(h->evf1, h->stream));
-  if (h->an.dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
-    const DenseTail &dt = h->an.dt;
+  if ((*h->anp).dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
+    const DenseTail &dt = (*h->anp).dt;
     TailArgs da{};
-    da.n = h->an.n; da.N = h->an.N; da.s = dt.s; da.k = dt.k; da.kbt = kbt; da.home_bt = BT;
-    da.storage = h->an.bf.storage; da.n_slots = dt.n_steps * 64u; da.n_lt = dt.n_lt; da.n_ltcol = dt.n_ltcol;
+    da.n = (*h->anp).n; da.N = (*h->anp).N; da.s = dt.s; da.k = dt.k; da.kbt = kbt; da.home_bt = BT;
+    da.storage = (*h->anp).bf.storage; da.n_slots = dt.n_steps * 64u; da.n_lt = dt.n_lt; da.n_ltcol = dt.n_ltcol; da.n_quads = (uint32_t)(dt.asm_q.size() / 64);
     da.nh = h->dt_nh; da.cs_doubles = h->dt_cs_doubles; da.work = h->work.p;
     da.lt_pos = h->dt_lt_pos.p; da.ltcol_col = h->dt_ltcol_col.p; da.tile_tab = h->dt_tile_tab.p; da.wave_tiles = h->dt_wave_tiles.p;
     da.asm_q = h->dt_asm_q.p; da.diag_tile = h->dt_diag_tile.p; da.asm_qcol = h->dt_asm_qcol.p; da.src_tile = h->dt_src_tile.p;
     da.Lblk = h->Lblk.p; da.Dl = h->Dl.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
     unsigned long long *d_trace = nullptr;
     const bool tracing = getenv("MI_OSQP_TAIL_TRACE") != nullptr;          // timing stamps only; results are unaffected
-    if (tracing) { HIPCHK(hipMalloc((void **)&d_trace, (size_t)wtiles * kbt * 4 * sizeof(unsigned long long))); HIPCHK(hipMemsetAsync(d_trace, 0, (size_t)wtiles * kbt * 32, h->stream)); }
+    if (tracing) { HIPCHK(hipMalloc((void **)&d_trace, (size_t)wtiles * kbt * 8 * sizeof(unsigned long long))); HIPCHK(hipMemsetAsync(d_trace, 0, (size_t)wtiles * kbt * 64, h->stream)); }
     da.trace = d_trace;
-    HIPCHK(launch_tail(da, wtiles * kbt, h->dt_lds, h->stream));
+    HIPCHK(launch_tail(da, wtiles * kbt, h->dt_lds_asm, h->dt_lds, h->stream));
     if (tracing) {
-      std::vector<unsigned long long> tr((size_t)wtiles * kbt * 4);
+      std::vector<unsigned long long> tr((size_t)wtiles * kbt * 8);
       HIPCHK(hipStreamSynchronize(h->stream));
       HIPCHK(hipMemcpy(tr.data(), d_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       (void)hipFree(d_trace);
-      double sum[4] = {0, 0, 0, 0};
-      for (size_t i = 0; i < tr.size(); i++) sum[i % 4] += (double)tr[i];
-      fprintf(stderr, "[mi_osqp] tail_kernel, %d QPs, mean shader clocks of wave 0 per QP: assembly %.0f, pivot blocks %.0f, panel + trailing %.0f, stream write %.0f\n",
-              wtiles * kbt, sum[0] / (wtiles * kbt), sum[1] / (wtiles * kbt), sum[2] / (wtiles * kbt), sum[3] / (wtiles * kbt));
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (size_t i = 0; i < tr.size(); i++) sum[i % 8] += (double)tr[i] / (wtiles * kbt);
+      fprintf(stderr, "[mi_osqp] tail_kernel, %d QPs, mean shader clocks of wave 0 per QP: assembly %.0f, pivot blocks %.0f, panel stores %.0f, stream write %.0f; "
+              "staging %.0f, Gn %.0f, trailing %.0f, barrier waits of the panel phase %.0f\n", wtiles * kbt, sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[6], sum[7]);
     }
   }
   HIPCHK(hipEventRecord(h->evf2, h->stream));
@@ -760,13 +817,13 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   {
     float f = 0.f, d = 0.f;
     HIPCHK(hipEventElapsedTime(&f, h->evf0, h->evf1)); HIPCHK(hipEventElapsedTime(&d, h->evf1, h->evf2));
-    h->factor_ms_sum += f; h->dense_ms_sum += h->an.dt.k ? d : 0.0; h->refactor_launches++; h->refactor_qps += nq;
+    h->factor_ms_sum += f; h->dense_ms_sum += (*h->anp).dt.k ? d : 0.0; h->refactor_launches++; h->refactor_qps += nq;
   }
   for (int s : work)            // (only the listed slots: at setup the flags of padding slots are not initialised yet)
     if (s >= 0 && h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
       if (getenv("MI_OSQP_DEBUG_TIMING")) {
         (void)hipMemcpy(h->h_npos, h->npos.p, (size_t)h->ntiles * BT * sizeof(int), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[mi_osqp] slot %d: %d positive pivots, expected %d\n", s, h->h_npos[s], h->an.n);
+        fprintf(stderr, "[mi_osqp] slot %d: %d positive pivots, expected %d\n", s, h->h_npos[s], (*h->anp).n);
       }
       if (bad) bad->push_back(s);
     }
@@ -791,7 +848,7 @@ static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps) {
 // exchange the complete device state of slot pairs (slot = tile*BT + b)
 static int apply_swaps(mi_osqp_batch *h, const std::vector<int2> &pairs) {
   if (pairs.empty()) return 0;
-  const Analysis &an = h->an;
+  const Analysis &an = (*h->anp);
   int np = (int)pairs.size(), BT = h->BT, n = an.n, m = an.m, rc;
   if (h->pairs.n < pairs.size() && (rc = h->pairs.alloc(std::max<size_t>(pairs.size(), (size_t)h->ntiles * BT)))) return rc;
   HIPCHK(hipMemcpyAsync(h->pairs.p, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
@@ -837,7 +894,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
   std::vector<std::vector<int2>> rounds;
   // compaction (re-pairing the QPs still iterating into fewer tiles) is implemented and tested but OFF by default:
   // since the value streams are per QP, a finished QP costs no bytes anyway, and moving data only breaks even
-  const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr || h->an.dt.k != 0;      // (and not combined with the dense tail)
+  const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr || (*h->anp).dt.k != 0;      // (and not combined with the dense tail)
   auto loop = [&]() -> int {
     int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
     while (true) {
@@ -1016,7 +1073,7 @@ int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_sta
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   if (d_x_out) {   // keep the internal copy coherent for get_primal()
-    HIPCHK(hipMemcpyAsync(h->x_out.p, d_x_out, (size_t)h->B * h->an.n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->x_out.p, d_x_out, (size_t)h->B * (*h->anp).n * sizeof(double), hipMemcpyDeviceToDevice, s));
   }
   if (d_status || d_iters) HIPCHK(launch_gather_status(h->iscal.p, d_status, d_iters, h->B, h->BT, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1026,13 +1083,13 @@ int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_sta
 int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x) {
   if (!h || !x) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
-  HIPCHK(hipMemcpy(x, h->x_out.p, (size_t)h->B * h->an.n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(x, h->x_out.p, (size_t)h->B * (*h->anp).n * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OSQP_OK;
 }
 int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y) {
   if (!h || !y) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
-  if (h->an.m) HIPCHK(hipMemcpy(y, h->y_out.p, (size_t)h->B * h->an.m * sizeof(double), hipMemcpyDeviceToHost));
+  if ((*h->anp).m) HIPCHK(hipMemcpy(y, h->y_out.p, (size_t)h->B * (*h->anp).m * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OSQP_OK;
 }
 
@@ -1114,7 +1171,7 @@ int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
   if (!h || !x) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   h->st.warm_start = 1;
-  size_t cnt = (size_t)h->B * h->an.n;
+  size_t cnt = (size_t)h->B * (*h->anp).n;
   int rc = ensure_stage(h, cnt, 0);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(h->stage.p, x, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1128,7 +1185,7 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
   if (!h || !l || !u) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   h->clear_rho_updates = true;
-  const Analysis &an = h->an;
+  const Analysis &an = (*h->anp);
   int m = an.m, B = h->B, rc;
   for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
   if ((rc = sync_rho_to_host(h))) return rc;
@@ -1155,7 +1212,7 @@ int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, cons
   DevGuard guard(h->device);
   h->clear_rho_updates = true;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-  int m = h->an.m, B = h->B;
+  int m = (*h->anp).m, B = h->B;
   if (!m) return MI_OSQP_OK;
   // pass 1: validate + detect constraint-type changes without writing
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), s));
@@ -1182,7 +1239,7 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   h->clear_rho_updates = true;
-  const Analysis &an = h->an;
+  const Analysis &an = (*h->anp);
   int n = an.n, B = h->B, nnzA = an.Ap[n], rc;
   for (int j = 0; j <= n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
   for (int k = 0; k < nnzA; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
@@ -1223,7 +1280,7 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
   KernelArgs a = make_args(h);
   if (h->sp_ptr.n && !getenv("MI_OSQP_SPMV_STREAM")) {      // one read of P and A for all three products
     SpmvFused t{};
-    t.ptr = h->sp_ptr.p; t.ent = h->sp_ent.p; t.pa_val = h->pa_val.p; t.pa_len = h->an.Pp[h->an.n] + h->an.Ap[h->an.n];
+    t.ptr = h->sp_ptr.p; t.ent = h->sp_ent.p; t.pa_val = h->pa_val.p; t.pa_len = (*h->anp).Pp[(*h->anp).n] + (*h->anp).Ap[(*h->anp).n];
     if (h->sp_npass && !getenv("MI_OSQP_SPMV_NO_PREFETCH")) {
       t.ell = h->sp_ell.p; t.rowid = h->sp_rowid.p; t.n_pass = h->sp_npass;
       for (int p = 0; p < 4; p++) { t.ell_off[p] = h->sp_ell_off[p]; t.ell_k[p] = h->sp_ell_k[p]; }
@@ -1232,7 +1289,7 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
     HIPCHK(hipStreamSynchronize(s));
     return MI_OSQP_OK;
   }
-  size_t lds = (size_t)(h->an.Next + 2 * h->an.n + h->an.m) * h->BT * sizeof(double);
+  size_t lds = (size_t)((*h->anp).Next + 2 * (*h->anp).n + (*h->anp).m) * h->BT * sizeof(double);
   a.op_out_lds = !h->global_xs && lds <= 160 * 1024;
   if (!a.op_out_lds) lds = h->lds;
   HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
@@ -1255,11 +1312,11 @@ int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double 
   if (!h || !dims) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   const int nw = h->threads / 64;
-  const int64_t fp = h->an.fwd.n_phases, bp = h->an.bwd.n_phases, words = 8 + 4 * nw + (fp + bp) * nw * 2;
+  const int64_t fp = (*h->anp).fwd.n_phases, bp = (*h->anp).bwd.n_phases, words = 8 + 4 * nw + (fp + bp) * nw * 2;
   dims[0] = fp; dims[1] = bp; dims[2] = nw; dims[3] = words;
   if (!out) return MI_OSQP_OK;
   if (which == 1 || which == 2) {
-    const Schedule &sc = which == 1 ? h->an.fwd : h->an.bwd;
+    const Schedule &sc = which == 1 ? (*h->anp).fwd : (*h->anp).bwd;
     if ((int64_t)sc.phase.size() > cap) { g_last_error = "trace: output too small"; return MI_OSQP_ERR_INVALID_DATA; }
     std::copy(sc.phase.begin(), sc.phase.end(), out);
     return MI_OSQP_OK;

@@ -9,7 +9,7 @@ python3 - <<PY
 import csv, glob
 f = sorted(glob.glob("$OUT/**/*kernel_trace.csv", recursive=True))[-1]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("miosqp::", "")[:44]) for r in csv.DictReader(open(f)))
-big = [e for e in ev if ("iterate" in e[2] or "factor" in e[2] or "check" in e[2] or "dense" in e[2])]
+big = [e for e in ev if ("iterate" in e[2] or "factor" in e[2] or "check" in e[2] or "tail" in e[2])]
 last = big[-24:]
 for s, e, n in last:
     print(f"{n:46s} {(e - s) / 1e3:9.1f} us")
