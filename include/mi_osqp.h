@@ -227,7 +227,10 @@ int mi_osqp_batch_refactor_device(mi_osqp_batch *h);
 int mi_osqp_batch_kernel_time(mi_osqp_batch *h, double *avg_ms, int64_t *launches);
 /* the same for the refactorisation kernels (row E13) since the last call: summed durations (ms, HIP events on the
  * launch stream) of factor_kernel and of dense_inverse_kernel, their launches and the QPs they refactored. */
-int mi_osqp_batch_refactor_time(mi_osqp_batch *h, double *factor_ms, double *dense_inverse_ms, int64_t *launches, int64_t *qps);
+int mi_osqp_batch_refactor_time(mi_osqp_batch *h, double *factor_ms, double *tail_ms, int64_t *launches, int64_t *qps);
+/* the largest of those refactorisations (most QPs; a solve also holds small ones for stragglers): its QPs and the
+ * durations of factor_kernel and of the dense-tail kernels (tail_assemble_kernel + tail_kernel). Reset by refactor_time. */
+int mi_osqp_batch_refactor_peak(mi_osqp_batch *h, int64_t *qps, double *factor_ms, double *tail_ms);
 
 /* --------------------------------------------------- host-only diagnostics
  * No GPU needed: analyse a pattern + one value set and replay the DEVICE

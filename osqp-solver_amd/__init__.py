@@ -103,6 +103,7 @@ def lib():
         L.mi_osqp_batch_kkt_solve.argtypes = [vp, vp, vp, vp]
         L.mi_osqp_batch_kernel_time.argtypes = [vp, dp, ip]
         L.mi_osqp_batch_refactor_time.argtypes = [vp, dp, dp, ip, ip]
+        L.mi_osqp_batch_refactor_peak.argtypes = [vp, ip, dp, dp]
         L.mi_osqp_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, ip, ip, dp, dp, ip, ip, dp, dp, dp, C.POINTER(Settings)]
         L.mi_osqp_update_A.argtypes = [vp, ip, ip, dp]
         L.mi_osqp_update_bounds.argtypes = [vp, dp, dp]
@@ -293,6 +294,12 @@ class BatchSolver:
         f, d, ln, nq = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
         _chk(lib().mi_osqp_batch_refactor_time(self._h, C.byref(f), C.byref(d), C.byref(ln), C.byref(nq)), "refactor_time")
         return f.value, d.value, ln.value, nq.value
+
+    def refactor_peak(self):
+        """(QPs, factor_kernel ms, dense-tail kernels ms) of the largest refactorisation since the last refactor_time()."""
+        nq, f, d = C.c_int64(), C.c_double(), C.c_double()
+        _chk(lib().mi_osqp_batch_refactor_peak(self._h, C.byref(nq), C.byref(f), C.byref(d)), "refactor_peak")
+        return nq.value, f.value, d.value
 
     # ---- device-resident variants (torch tensors on the solver's GPU)
     def solve_device(self, x_out=None, status=None, iters=None, stream=None):

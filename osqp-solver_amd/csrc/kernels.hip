@@ -393,6 +393,7 @@ struct TilePtrs {
   int *iscal;
   ValSrc<BT> vfwd, vbwd, vchk;
   mi_rsrc vdt[BT];                 // dense tail: the stream of the inverted Schur complement, one per QP
+  int act;                         // bit b: QP b of the tile streams (is not finished / skipped); wave-uniform
 };
 
 template <int BT>
@@ -413,10 +414,12 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile,
   p.vfwd.idx = idx_rsrc(a.fwd); p.vfwd.step = make_rsrc(a.fwd.step, a.fwd.n_steps * 4u);
   p.vbwd.idx = idx_rsrc(a.bwd); p.vbwd.step = make_rsrc(a.bwd.step, a.bwd.n_steps * 4u);
   p.vchk.idx = idx_rsrc(a.chk); p.vchk.step = make_rsrc(a.chk.step, a.chk.n_steps * 4u);
+  p.act = 0;
 #pragma unroll
   for (int bb = 0; bb < BT; bb++) {
     const size_t slot = t * BT + bb;
     const bool off = skip_done && p.iscal[IS_DONE * BT + bb] != 0;     // wave-uniform: inside a solve, finished QPs (and padding slots) stream nothing
+    if (!off) p.act |= 1 << bb;
     p.vfwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.fwd_val + slot * a.fwd.n_steps * 64, a.fwd.n_steps * 512u);
     p.vbwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.bwd_val + slot * a.bwd.n_steps * 64, a.bwd.n_steps * 512u);
     p.vchk.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.chk_val + slot * a.chk.n_steps * 64, a.chk.n_steps * 512u);
@@ -446,19 +449,26 @@ __device__ __forceinline__ double rol1_d(double v) {
   return __hiloint2double(hi, lo);
 }
 #define MI_DT_PF 16
-// Every wave walks its tasks (64 x 64 blocks of M, 64 or 32 steps each) through a 16-step register ring of the
+// Every wave walks its tasks (64 x 64 blocks of M, 64 or 32 steps each) through a PF-step register ring of the
 // value stream; per step and QP: two fmas (column sum stays in the lane, row sum travels) and two rotations.
 // xt = the tail of the solve vector (t, read only), yr / yc = the two accumulation vectors (LDS, [k][BT]).
-template <int BT>
-__device__ __forceinline__ void dense_tail_apply(const DenseTailDev &dt, const mi_rsrc (&vals)[BT], const double *xt,
+// NQ = QP streams served: all BT of the tile, or ONE (slot b0 of the tile: the other QPs of the tile have finished, or
+// BT = 1) with a ring twice as deep - a lone stream is bound by the loads it keeps in flight (one memory latency per
+// ring revolution), and the registers the finished QP's ring held are free.
+template <int BT, int NQ, int PF>
+__device__ __forceinline__ void dense_tail_apply(const DenseTailDev &dt, const mi_rsrc (&vals)[NQ], int b0, const double *xt,
                                                  double *yr, double *yc, int wave, int lane) {
-  constexpr int PF = MI_DT_PF;
+  static_assert(NQ == BT || NQ == 1, "all QPs of the tile or one");
+  static_assert(32 % PF == 0, "task lengths (32 / 64 steps) must be multiples of the ring depth");
+  auto ldv = [&](const double *p, double (&o)[NQ]) {
+    if constexpr (NQ == BT) load_bt<BT>(p, o); else o[0] = p[b0];
+  };
   mi_cptr tk = as_const(dt.task);
   uint32_t t = as_const(dt.wave_task)[wave];
   const uint32_t begin = as_const(dt.wave_step)[wave], end = as_const(dt.wave_step)[wave + 1];
-  double rv[PF][BT], tj[BT], ti[BT], accr[BT], accc[BT];
+  double rv[PF][NQ], tj[NQ], ti[NQ], accr[NQ], accc[NQ];
 #pragma unroll
-  for (int b = 0; b < BT; b++) {
+  for (int b = 0; b < NQ; b++) {
     tj[b] = 0.0; ti[b] = 0.0; accr[b] = 0.0; accc[b] = 0.0;
 #pragma unroll
     for (int st = 0; st < PF; st++) rv[st][b] = 0.0;
@@ -471,22 +481,22 @@ __device__ __forceinline__ void dense_tail_apply(const DenseTailDev &dt, const m
       for (uint32_t nb = fl >> 8; nb; nb--) lds_barrier();
       flags = fl & 255u; left = nst;
       const uint32_t s0 = flags & 1u;
-      load_bt<BT>(xt + (size_t)(J0 + (uint32_t)lane) * BT, tj);
-      load_bt<BT>(xt + (size_t)(I0 + (((uint32_t)lane + s0) & 63u)) * BT, ti);
+      ldv(xt + (size_t)(J0 + (uint32_t)lane) * BT, tj);
+      ldv(xt + (size_t)(I0 + (((uint32_t)lane + s0) & 63u)) * BT, ti);
 #pragma unroll
-      for (int b = 0; b < BT; b++) { accr[b] = 0.0; accc[b] = 0.0; }
+      for (int b = 0; b < NQ; b++) { accr[b] = 0.0; accc[b] = 0.0; }
     }
 #pragma unroll
     for (int st = 0; st < PF; st++) {
 #pragma unroll
-      for (int b = 0; b < BT; b++) {
+      for (int b = 0; b < NQ; b++) {
         accc[b] = fma(rv[st][b], ti[b], accc[b]);
         accr[b] = fma(rv[st][b], tj[b], accr[b]);
       }
 #pragma unroll
-      for (int b = 0; b < BT; b++) { ti[b] = rol1_d(ti[b]); accr[b] = rol1_d(accr[b]); }
+      for (int b = 0; b < NQ; b++) { ti[b] = rol1_d(ti[b]); accr[b] = rol1_d(accr[b]); }
 #pragma unroll
-      for (int b = 0; b < BT; b++) {
+      for (int b = 0; b < NQ; b++) {
         const mi_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(vals[b], (uint32_t)lane * 8u, (pos + (uint32_t)st) * 512u, 0);
         rv[st][b] = __hiloint2double((int)w.y, (int)w.x);
       }
@@ -497,9 +507,10 @@ __device__ __forceinline__ void dense_tail_apply(const DenseTailDev &dt, const m
         const uint32_t il = ((uint32_t)lane + (flags & 1u) + nst) & 63u;      // the row this lane's travelling sum belongs to
         double *rvec = (flags & 2u) ? yc : yr, *cvec = (flags & 2u) ? yr : yc;
 #pragma unroll
-        for (int b = 0; b < BT; b++) {
-          rvec[(size_t)(I0 + il) * BT + b] += accr[b];
-          cvec[(size_t)(J0 + (uint32_t)lane) * BT + b] += accc[b];
+        for (int b = 0; b < NQ; b++) {
+          const int bb = NQ == BT ? b : b0;
+          rvec[(size_t)(I0 + il) * BT + bb] += accr[b];
+          cvec[(size_t)(J0 + (uint32_t)lane) * BT + bb] += accc[b];
         }
         t++;
       }
@@ -510,7 +521,7 @@ __device__ __forceinline__ void dense_tail_apply(const DenseTailDev &dt, const m
 
 // what happens between the forward and the backward sweep: D^-1 on the rows before the dense tail, S^-1 on the tail
 template <int BT, bool GX>
-__device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *dinv, const mi_rsrc (&vdt)[BT], double *xs,
+__device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *dinv, const mi_rsrc (&vdt)[BT], int act, double *xs,
                                            int tid, int nthr, int wave, int lane) {
   if (!a.dt.k) {
     for (int e = tid; e < a.N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= dinv[e];
@@ -526,7 +537,18 @@ __device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *di
       else { yr[e - s * BT] = dinv[e] * xs[e]; yc[e - s * BT] = 0.0; }          // dinv of a tail row = diagonal of S^-1
     }
     __syncthreads();
-    dense_tail_apply<BT>(a.dt, vdt, xs + (size_t)s * BT, yr, yc, wave, lane);
+    if constexpr (BT == 1) {
+      dense_tail_apply<1, 1, 2 * MI_DT_PF>(a.dt, vdt, 0, xs + (size_t)s * BT, yr, yc, wave, lane);
+    } else {
+      // exactly one QP of the tile still streams (the others have finished): serve it alone, with the deeper ring
+      const int act_u = __builtin_amdgcn_readfirstlane(act);
+      if (BT == 2 && (act_u == 1 || act_u == 2)) {
+        const mi_rsrc one[1] = {act_u == 2 ? vdt[BT - 1] : vdt[0]};
+        dense_tail_apply<BT, 1, 2 * MI_DT_PF>(a.dt, one, act_u == 2 ? 1 : 0, xs + (size_t)s * BT, yr, yc, wave, lane);
+      } else {
+        dense_tail_apply<BT, BT, MI_DT_PF>(a.dt, vdt, 0, xs + (size_t)s * BT, yr, yc, wave, lane);
+      }
+    }
     for (int e = tid; e < k * BT; e += nthr) xs[(size_t)s * BT + e] = yr[e] + yc[e];
     __syncthreads();
   }
@@ -537,7 +559,7 @@ template <int BT, int PF, bool GX, bool WIDE = false>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
                                               int tid, int nthr, int wave, int nw, int lane) {
   run_tri<BT, PF, GX, 0, WIDE>(a.fwd, p.vfwd, xs, wave, lane);
-  kkt_middle<BT, GX>(a, p.dinv, p.vdt, xs, tid, nthr, wave, lane);
+  kkt_middle<BT, GX>(a, p.dinv, p.vdt, p.act, xs, tid, nthr, wave, lane);
   run_tri<BT, PF, GX, 0, WIDE>(a.bwd, p.vbwd, xs, wave, lane);
 }
 
@@ -1031,7 +1053,7 @@ __global__ __launch_bounds__(512) void kkt_trace_kernel(KernelArgs a, const doub
   uint32_t *trf = twb + 2 * nw, *trb = trf + (size_t)a.fwd.n_phases * nw * 2;
   run_tri<BT, MI_PFV, false, TRL>(a.fwd, p.vfwd, xs, wave, lane, trf, twf);
   if (tid == 0) tr[4] = (uint32_t)__builtin_amdgcn_s_memtime();
-  kkt_middle<BT, false>(a, p.dinv, p.vdt, xs, tid, nthr, wave, lane);
+  kkt_middle<BT, false>(a, p.dinv, p.vdt, p.act, xs, tid, nthr, wave, lane);
   if (tid == 0) tr[5] = (uint32_t)__builtin_amdgcn_s_memtime();
   run_tri<BT, MI_PFV, false, TRL>(a.bwd, p.vbwd, xs, wave, lane, trb, twb);
   if (tid == 0) { tr[2] = (uint32_t)__builtin_amdgcn_s_memtime(); tr[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); }

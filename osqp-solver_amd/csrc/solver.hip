@@ -209,7 +209,8 @@ struct mi_osqp_batch {
   double *h_dscal = nullptr;  // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evf0 = nullptr, evf1 = nullptr, evf2 = nullptr;
   double factor_ms_sum = 0.0, dense_ms_sum = 0.0;
-  int64_t refactor_launches = 0, refactor_qps = 0;
+  int64_t refactor_launches = 0, refactor_qps = 0, peak_qps = 0;
+  double peak_factor_ms = 0.0, peak_tail_ms = 0.0;
   mi_osqp_stats stats{};
   // last-solve accounting
   int64_t last_total_iters = 0, last_launches = 0, last_refactors = 0;
@@ -818,6 +819,7 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
     float f = 0.f, d = 0.f;
     HIPCHK(hipEventElapsedTime(&f, h->evf0, h->evf1)); HIPCHK(hipEventElapsedTime(&d, h->evf1, h->evf2));
     h->factor_ms_sum += f; h->dense_ms_sum += (*h->anp).dt.k ? d : 0.0; h->refactor_launches++; h->refactor_qps += nq;
+    if (nq >= h->peak_qps) { h->peak_qps = nq; h->peak_factor_ms = f; h->peak_tail_ms = (*h->anp).dt.k ? d : 0.0; }
   }
   for (int s : work)            // (only the listed slots: at setup the flags of padding slots are not initialised yet)
     if (s >= 0 && h->h_iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] < 0) {
@@ -1145,6 +1147,15 @@ int mi_osqp_batch_refactor_time(mi_osqp_batch *h, double *factor_ms, double *den
   if (launches) *launches = h->refactor_launches;
   if (qps) *qps = h->refactor_qps;
   h->factor_ms_sum = h->dense_ms_sum = 0.0; h->refactor_launches = h->refactor_qps = 0;
+  h->peak_qps = 0; h->peak_factor_ms = h->peak_tail_ms = 0.0;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_refactor_peak(mi_osqp_batch *h, int64_t *qps, double *factor_ms, double *tail_ms) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (qps) *qps = h->peak_qps;
+  if (factor_ms) *factor_ms = h->peak_factor_ms;
+  if (tail_ms) *tail_ms = h->peak_tail_ms;
   return MI_OSQP_OK;
 }
 
