@@ -173,8 +173,11 @@ void mi_osqp_release_device_cache(void);
 int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream);
 /* Solve and leave x[B][n] (and optionally status[B]/iters[B], int32) in HBM. */
 int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream);
-/* Benchmark helper: cold-start every QP and restore rho and the factor that
- * setup produced, so that repeated solves do identical work. */
+/* Back to the state right after setup (or after the last update that refactored): cold-start every QP, restore rho,
+ * the rho vectors and the factor of that moment, forget the count of rho updates.  A planner that builds the same
+ * solver again and again (one per horizon segment and run, [REF] src/gomp-solver.h:61) may keep the handle instead:
+ * reset + update_bounds + warm_start gives bitwise the results of a fresh setup with the same P and A.  The bench uses it
+ * so that repeated steps do identical work. */
 int mi_osqp_batch_reset(mi_osqp_batch *h);
 /* Totals of the last solve: ADMM iterations summed over QPs, iterate launches (= segments),
  * seconds in iterate_kernel (HIP events), in device refactorisations and in the

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <array>
+#include <memory>
 #include <cassert>
 #include <cmath>
 #include <cstdio>
@@ -469,7 +470,15 @@ class BatchGOMPSolver {
       });
       seconds_build += since_(tb_);
       auto ts_ = clk_::now();
-      BatchSolverT qp{cons, triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * waypoints), (int)(waypoints * N_DIM), (int)N_DIM), verbose};
+      // One solver per horizon segment, as the reference builds them ([REF] src/gomp-solver.h:61) - but kept across run()
+      // calls: when this segment's P and A are those of the solver built for it earlier (joint-space rows: only the bounds
+      // depend on the trajectory), the handle is put back into its post-construction state and given the new bounds
+      // (BatchQPSolver::reinit: bitwise a fresh construction) instead of being analysed, uploaded and factored again.
+      const QPMatrixSparse Pseg = triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * waypoints), (int)(waypoints * N_DIM), (int)N_DIM);
+      std::unique_ptr<BatchSolverT> &slot = solver_cache_[(size_t)(SEGMENTS - i)];
+      if (reuse_solvers && slot && reinit_(*slot, cons, Pseg)) ++solver_reuses;
+      else slot = std::make_unique<BatchSolverT>(cons, Pseg, verbose);
+      BatchSolverT &qp = *slot;
       qp.setWarmStart(warm);
       seconds_setup += since_(ts_);
       std::vector<char> running(K, 1);
@@ -514,6 +523,8 @@ class BatchGOMPSolver {
   // per-trajectory counters (comparable with GOMPSolver's) and the number of batched solves
   std::vector<int> segments_run, qp_solves, qp_updates;
   int batch_solves = 0;
+  bool reuse_solvers = true;      // keep the per-segment solvers across run() calls (see run())
+  int solver_reuses = 0;          // how often a kept solver was re-initialised instead of a new one being built
   // where the wall time of the last run() went: building constraints, QP setup (analysis + upload + factorisation),
   // batched solves, feasibility checks + re-linearisation + update
   double seconds_build = 0.0, seconds_setup = 0.0, seconds_solve = 0.0, seconds_update = 0.0;
@@ -526,6 +537,12 @@ class BatchGOMPSolver {
   const std::vector<HorizontalLine> obstacles;
   const std::vector<RobotBall> mappers;
   const bool verbose;
+
+  std::array<std::unique_ptr<BatchSolverT>, SEGMENTS> solver_cache_;
+  // (a batch solver type without reinit(), e.g. a test double, is always rebuilt)
+  template <class S>
+  static auto reinit_(S &s, const std::vector<QPConstraints> &cons, const QPMatrixSparse &P) -> decltype(s.reinit(cons, P)) { return s.reinit(cons, P); }
+  static bool reinit_(...) { return false; }
 
   // body(k) for k in [0, count) on up to 16 host threads (the FK / Jacobian callbacks of the balls must be re-entrant,
   // which the reference's are: pure functions of the joint vector)

@@ -15,6 +15,7 @@
 // objects without copying their layout assumptions.
 #pragma once
 
+#include <algorithm>
 #include <cassert>
 #include <iostream>
 #include <stdexcept>
@@ -143,6 +144,8 @@ class BatchQPSolver {
     if (custom) s = *custom;
     s.verbose = verbose;
     std::vector<double> Pv, Av, l, u;
+    Pv.reserve(P.values.size() * cs.size()); Av.reserve(A0.values.size() * cs.size());
+    l.reserve((size_t)m_ * cs.size()); u.reserve((size_t)m_ * cs.size());
     bool ok = P.rows == n_ && P.cols == n_;
     for (const QPConstraints &c : cs) {
       const auto &[lo, A, up] = c;
@@ -154,6 +157,7 @@ class BatchQPSolver {
       l.insert(l.end(), lo.begin(), lo.end());
       u.insert(u.end(), up.begin(), up.end());
     }
+    if (ok) { P_ = P; A_outer_ = A0.outer; A_inner_ = A0.inner; Av_ = Av; }          // what reinit() compares against
     int rc = MI_OSQP_ERR_INVALID_DATA;
     if (ok)
       rc = mi_osqp_batch_setup(&h_, K_, n_, m_, reinterpret_cast<const int64_t *>(P.outer.data()),
@@ -168,6 +172,7 @@ class BatchQPSolver {
   BatchQPSolver &operator=(const BatchQPSolver &) = delete;
 
   void update(const std::vector<QPConstraints> &cs) {
+    pristine_ = false;                       // (new A values / a snapshot taken with adapted rho: reinit() no longer applies)
     if ((long long)cs.size() != K_) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_INVALID_DATA));
     const QPMatrixSparse &A0 = std::get<1>(cs[0]);
     std::vector<double> Av, l, u;
@@ -186,6 +191,7 @@ class BatchQPSolver {
   }
   // bounds only (the joint-space GOMP rows never change A)
   void updateBounds(const std::vector<QPConstraints> &cs) {
+    pristine_ = false;
     std::vector<double> l, u;
     for (const QPConstraints &c : cs) {
       l.insert(l.end(), std::get<0>(c).begin(), std::get<0>(c).end());
@@ -217,6 +223,26 @@ class BatchQPSolver {
     return out;
   }
 
+  // A planner builds the same solver again on every run ([REF] src/gomp-solver.h:61: one QPSolver per horizon segment).
+  // When P, the pattern of A and the values of A are the ones this solver was built with, the handle is simply put back
+  // into its state after construction (mi_osqp_batch_reset) and given the new bounds: bitwise the results of a fresh
+  // construction, without analysis, equilibration, upload and factorisation.  false: not applicable, build a new one.
+  bool reinit(const std::vector<QPConstraints> &cs, const QPMatrixSparse &P) {
+    if (status_ != MI_OSQP_OK || !pristine_ || (long long)cs.size() != K_ || P.outer != P_.outer || P.inner != P_.inner || P.values != P_.values) return false;
+    const size_t nnzA = A_inner_.size();
+    std::vector<double> l, u;
+    l.reserve((size_t)m_ * cs.size()); u.reserve((size_t)m_ * cs.size());
+    for (size_t k = 0; k < cs.size(); k++) {
+      const auto &[lo, A, up] = cs[k];
+      if (A.rows != m_ || A.cols != n_ || A.outer != A_outer_ || A.inner != A_inner_ || (long long)lo.size() != m_ || (long long)up.size() != m_) return false;
+      if (!std::equal(A.values.begin(), A.values.end(), Av_.begin() + k * nnzA)) return false;
+      l.insert(l.end(), lo.begin(), lo.end());
+      u.insert(u.end(), up.begin(), up.end());
+    }
+    if (mi_osqp_batch_reset(h_) != MI_OSQP_OK) return false;
+    return mi_osqp_batch_update_bounds(h_, l.data(), u.data()) == MI_OSQP_OK;
+  }
+
   int setup_status() const { return status_; }
   const std::vector<mi_osqp_info> &last_infos() const { return infos_; }
   long long size() const { return K_; }
@@ -226,6 +252,10 @@ class BatchQPSolver {
   long long K_ = 0, n_ = 0, m_ = 0;
   int status_ = 0;
   std::vector<mi_osqp_info> infos_;
+  QPMatrixSparse P_;
+  std::vector<long long> A_outer_, A_inner_;
+  std::vector<double> Av_;
+  bool pristine_ = true;            // no update() since construction: the handle's setup snapshot is the post-construction state
 };
 
 }  // namespace miosqp_ref

@@ -219,6 +219,15 @@ static int run_batch(int seed = 0) {
   }
   BatchGOMPSolver<3> bg(40, 0.1, pos, vel, acc, c3d, lines, balls);
   auto rb = bg.run(starts, ends);
+  {     // a second run() keeps the segment solvers that saw no update() (re-initialised, not rebuilt): bitwise the same plan
+    const std::vector<int> solves1 = bg.qp_solves, updates1 = bg.qp_updates;
+    auto rb2 = bg.run(starts, ends);
+    CHECK(bg.solver_reuses > 0);
+    CHECK(bg.qp_solves == solves1 && bg.qp_updates == updates1);
+    for (size_t b = 0; b < starts.size(); ++b) { CHECK(rb2[b].first == rb[b].first); CHECK(rb2[b].second == rb[b].second); }
+    std::printf("second run(): %d of %d segment solvers re-initialised instead of rebuilt, results bitwise equal: %s\n", bg.solver_reuses, SEGMENTS,
+                fails ? "NO" : "yes");
+  }
   int total_updates = 0;
   for (size_t b = 0; b < starts.size(); ++b) {
     GOMPSolver<3, QPSolver> g(40, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
@@ -278,6 +287,8 @@ static int run_bench(int B, int W, int sample) {
   auto rb2 = bg.run(starts, ends);
   tg = std::chrono::duration<double>(clk::now() - t0).count();
   for (int b = 0; b < B; ++b) { CHECK(rb2[b].first == rb[b].first); CHECK(rb2[b].second == rb[b].second); }
+  std::printf("second run(): %d of %d segment solvers re-initialised (reset + new bounds) instead of rebuilt; results bitwise equal to the first run\n",
+              bg.solver_reuses, SEGMENTS);
   int ok = 0, solves = 0;
   for (int b = 0; b < B; ++b) { ok += rb[b].first == ExitCode::kOptimal; solves += bg.qp_solves[b]; }
   std::printf("batched driver: %d trajectories (D=7, W=%d): %.3f s = %.1f trajectories/s, %d QP solves in %d batched solves, %d optimal\n",
