@@ -216,6 +216,9 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 #ifndef MI_PFV
 #define MI_PFV 15
 #endif
+// A QP whose solve vector lives in global memory (GX: the large single QPs, one workgroup for the whole problem) is
+// bound by the loads its 8 waves keep in flight, not by registers per CU: its ring is twice as deep.
+#define MI_PFV_OF(BT, GX) (((BT) == 1 && (GX)) ? 2 * MI_PFV : MI_PFV)
 template <int BT, int PF>
 struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t gr[PF]; uint32_t desc; };     // gr: target rows of the wide index words (unused otherwise)
 // The value streams of a tile: ONE stream per QP ([slot][step][64] doubles, 8 B per lane and load) plus the shared
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   for (int iter = a.iter_begin + 1; iter <= a.iter_end; iter++) {
     const bool do_info = a.info_at_end && iter == a.iter_end;     // delta_x / delta_y are only needed by check_kernel
     // ---- E7
-    kkt_solve_lds<BT, MI_PFV, GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
+    kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
     // ---- E8-E10 fused with E6 of the next iteration (run_tri ends with a barrier): every thread replaces the
     // solution entry it has just consumed by the next right-hand side entry - same position, no other reader
     for (int e = tid; e < n * BT; e += nthr) {
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
     for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
   }
   __syncthreads();
-  kkt_solve_lds<BT, MI_PFV, GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
+  kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
     if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
