@@ -216,9 +216,10 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 #ifndef MI_PFV
 #define MI_PFV 15
 #endif
-// A QP whose solve vector lives in global memory (GX: the large single QPs, one workgroup for the whole problem) is
-// bound by the loads its 8 waves keep in flight, not by registers per CU: its ring is twice as deep.
-#define MI_PFV_OF(BT, GX) (((BT) == 1 && (GX)) ? 2 * MI_PFV : MI_PFV)
+// (a ring twice as deep for the global-vector mode of the large single QPs was measured in round 2: no change - 8.97 ms
+// per iteration at config 5 either way; that mode is bound by the global gathers / read-modify-writes of the solve vector
+// and the full drains at its phase barriers, not by the value stream)
+#define MI_PFV_OF(BT, GX) MI_PFV
 template <int BT, int PF>
 struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t gr[PF]; uint32_t desc; };     // gr: target rows of the wide index words (unused otherwise)
 // The value streams of a tile: ONE stream per QP ([slot][step][64] doubles, 8 B per lane and load) plus the shared
