@@ -213,8 +213,12 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 // straight-line site: reads past the end of a stream hit the next wave's steps or the
 // buffer bound (which returns 0) and are never consumed, so there is no branch around a
 // load and the compiler keeps ONE copy of the ring.
+// Ring depth of the sweeps (steps in flight per wave; a multiple of MI_D_LOOKAHEAD + 1).  Round 2 sweep on the 1024-QP
+// headline batch (scripts/tune_rings.sh, ms per step): 15 / 16 (sweeps / dense-tail product): 38.8; 9 / 8: 37.2; 6 / 8: 37.3;
+// 9 / 16: 37.8 - a many-stream read kernel reaches the full 6.1-6.4 TB/s with 64 KB in flight per CU
+// (scripts/probes/stream_probe.hip), the shallower rings cost 88 instead of 119 VGPRs and start up faster after a barrier.
 #ifndef MI_PFV
-#define MI_PFV 15
+#define MI_PFV 9
 #endif
 // (a ring twice as deep for the global-vector mode of the large single QPs was measured in round 2: no change - 8.97 ms
 // per iteration at config 5 either way; that mode is bound by the global gathers / read-modify-writes of the solve vector
@@ -452,7 +456,9 @@ __device__ __forceinline__ double rol1_d(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-#define MI_DT_PF 16
+#ifndef MI_DT_PF
+#define MI_DT_PF 8
+#endif
 // Every wave walks its tasks (64 x 64 blocks of M, 64 or 32 steps each) through a PF-step register ring of the
 // value stream; per step and QP: two fmas (column sum stays in the lane, row sum travels) and two rotations.
 // xt = the tail of the solve vector (t, read only), yr / yc = the two accumulation vectors (LDS, [k][BT]).
