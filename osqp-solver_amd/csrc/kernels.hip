@@ -1466,9 +1466,12 @@ __device__ __forceinline__ uint32_t tile_ix(int I, int J) { return (uint32_t)(I 
 #define MI_TAIL_NW 8
 #define MI_TAIL_TS 65              // row stride of the pivot block's LDS image
 
-// Phase 0 of the dense tail as a kernel of its own: 16 waves per QP (1024 threads; the loop is a chain of L2 table reads,
-// LDS gathers and one MFMA per 4 sources - latency, not the matrix pipe, bounds it, so twice the waves of tail_kernel
-// halve it), 93 KB of LDS for the compact factor entries at config 3.
+// Phase 0 of the dense tail as a kernel of its own: 16 waves per QP (1024 threads), 93 KB of LDS for the compact factor
+// entries at config 3.  What bounds it (timing experiments of round 2, 1024 QPs: 0.89 ms; without the staging gather
+// 0.78; with the MFMA replaced by one scalar fma 0.75; with random instead of table indices 1.05): vector-ALU issue -
+// ~40 instructions of index unpacking, address arithmetic and operand scaling around every MFMA - and the LDS gathers,
+// not the matrix pipe and not memory latency.  Next step if it matters: byte offsets and the column index packed into one
+// 64-bit table word read through a buffer descriptor (no address arithmetic), D pre-negated.
 __global__ __launch_bounds__(1024) void tail_assemble_kernel(TailArgs a) {
   extern __shared__ double smem[];
   const int g = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
