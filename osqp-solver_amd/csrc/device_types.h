@@ -83,9 +83,11 @@ struct TailArgs {
   int nh;                       // row tiles of one staged half of the panel
   uint32_t cs_doubles;          // LDS doubles reserved for the staged panel / the pivot block's image (Ps follows)
   const int *work;              // slot of every (work tile, lane class), -1 = none
-  const uint32_t *lt_pos, *ltcol_col, *tile_tab, *wave_tiles, *asm_q, *diag_tile;
-  const uint16_t *asm_qcol;
-  const int32_t *src_tile;      // per stream slot: tile-order offset in the scratch, MI_SRC_ZERO = 0
+  const uint32_t *lt_pos, *ltcol_col, *tile_tab, *wave_tiles, *diag_tile;
+  const uint64_t *asm_q64;
+  const int32_t *src_tile;      // per stream slot: tile-order offset in the scratch, MI_SRC_ZERO = 0 (host replay; unused by the kernel)
+  const uint32_t *dt_task, *dt_task_step;       // the product's tasks (DenseTail::task) in stream order and the first stream step of each
+  uint32_t n_tasks;
   const double *Lblk, *Dl;
   double *Sd, *dt_val, *dinv;
   int *npos, *iscal;

@@ -871,6 +871,11 @@ static void build_block_factor(Analysis &an) {
       }
     }
     dt.wave_tiles[nw] = (uint32_t)(dt.tile_tab.size() / 4);
+    dt.asm_q64.resize(dt.asm_q.size());
+    for (size_t e = 0; e < dt.asm_q.size(); e++) {
+      const uint64_t w = dt.asm_q[e], ci = dt.asm_qcol[e / 16];               // (lane / 16 = source of the quad)
+      dt.asm_q64[e] = ((w & 0xFFFFu) * 8u) | ((((w >> 16) * 8u) | ((ci * 8u) << 17)) << 32);
+    }
     // asm_q is [quad][lane]: lane = source * 16 + tile row -- the loops above emitted exactly that order
     dt.src_tile.resize(dt.src.size());
     for (size_t e = 0; e < dt.src.size(); e++) {
@@ -879,6 +884,8 @@ static void build_block_factor(Analysis &an) {
     }
     dt.diag_tile.resize(k);
     for (int i = 0; i < k; i++) dt.diag_tile[i] = dt_tile_offset(i, i);
+    dt.task_step.clear();
+    { uint32_t pos = 0; for (size_t t = 0; t < dt.task.size() / 4; t++) { dt.task_step.push_back(pos); pos += dt.task[4 * t + 3]; } }
   }
 }
 
@@ -993,7 +1000,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
           const auto lo = std::lower_bound(cols[c].begin(), cols[c].end(), N - best_k);
           n_lt += cols[c].end() - lo; n_ltcol += lo != cols[c].end();
         }
-        if (n_lt <= 65534 && 8 * (n_lt + 1 + n_ltcol) <= 144 * 1024) { an.dt.k = best_k; an.dt.s = N - best_k; }
+        if (n_lt <= 16382 && n_ltcol <= 4095 && 8 * (n_lt + 1 + n_ltcol) <= 144 * 1024) { an.dt.k = best_k; an.dt.s = N - best_k; }     // (17- / 15-bit byte offsets in asm_q64)
         else tail_nnz_used = 0;
       } else tail_nnz_used = 0;
     }

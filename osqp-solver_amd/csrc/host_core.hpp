@@ -137,8 +137,11 @@ struct DenseTail {
   std::vector<uint32_t> wave_tiles;  // nw + 1: range of tile_tab entries of every wave
   std::vector<uint32_t> asm_q;       // [quads][64]
   std::vector<uint16_t> asm_qcol;    // [quads][4]: compact source column of the quad's 4 sources
+  std::vector<uint64_t> asm_q64;     // DEVICE form of the two, [quads][64]: low word = byte offset of operand A's compact entry in LDS;
+                                     // high word = byte offset of operand B's entry | (8 * compact source column) << 17
   std::vector<int32_t> src_tile;     // per stream slot: tile-order offset of its element (src translated) or MI_SRC_ZERO
   std::vector<uint32_t> diag_tile;   // [k]: tile-order offset of S[i, i]
+  std::vector<uint32_t> task_step;   // per task (in stream order = the order of `task`): its first step in the value stream
   size_t asm_lds_bytes() const { return ((size_t)n_lt + 1 + (size_t)n_ltcol) * sizeof(double); }
 };
 // tile-order offset of element (i, j), i >= j (tail-local), of the lower-triangular tile array

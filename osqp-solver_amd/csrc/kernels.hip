@@ -1487,15 +1487,17 @@ __global__ __launch_bounds__(1024) void tail_assemble_kernel(TailArgs a) {
     double *La = smem, *Dc = smem + a.n_lt + 1;
     for (int e = tid; e < a.n_lt; e += nthr) La[e] = Lb[(size_t)a.lt_pos[e] * kbt];
     if (tid == 0) La[a.n_lt] = 0.0;
-    for (int c = tid; c < a.n_ltcol; c += nthr) Dc[c] = Dl[(size_t)a.ltcol_col[c] * kbt];
+    for (int c = tid; c < a.n_ltcol; c += nthr) Dc[c] = -Dl[(size_t)a.ltcol_col[c] * kbt];       // (negated: S = KKT block MINUS L d L')
     __syncthreads();
-    // The quads of a wave's tiles are one linear stream of the two tables (tiles are laid out wave-major, each padded to
-    // whole blocks of QB quads).  The stream runs NB blocks ahead of its use in a shift register of table words; every
-    // global load of the loop sits in straight-line code (clamped indices instead of branches), because the compiler can
-    // only keep its wait counts apart from vmcnt(0) when the number of loads in flight is the same on every path - with a
-    // conditional tile switch inside the loop each block of quads cost one L2 round trip (0.5 M clocks per QP, 4 x the
-    // MFMA time).  The initial accumulator (the KKT block) of the next tile is fetched one tile ahead.
-    constexpr int QB = 8, NB = 4;
+    // The quads of a wave's tiles are one linear stream of 64-bit table words (tiles are laid out wave-major, each padded
+    // to whole blocks of QB quads): low word = LDS byte offset of operand A's entry, high word = offset of operand B's
+    // entry | offset of the source column's -d << 17.  Read through a buffer descriptor with a scalar offset (no address
+    // arithmetic), one block ahead of its use; every load of the loop sits in straight-line code (clamped indices instead
+    // of branches: a branch around a load makes the compiler collapse its wait counts).  The kernel is bound by vector-ALU
+    // issue around its MFMAs, so the loop body is kept to ~8 vector instructions per step (the first version spent ~40 on
+    // index unpacking, 64-bit addresses and operand scaling: 0.63 ms for 605 QPs).  The initial accumulator (the KKT
+    // block) of the next tile is fetched one tile ahead.
+    constexpr int QB = 8;
     const uint32_t t_begin = a.wave_tiles[wave], t_end = a.wave_tiles[wave + 1];
     if (t_begin < t_end) {
       const uint4 *ttab = reinterpret_cast<const uint4 *>(a.tile_tab);
@@ -1510,37 +1512,38 @@ __global__ __launch_bounds__(1024) void tail_assemble_kernel(TailArgs a) {
         }
         return v;
       };
+      const mi_rsrc tab = make_rsrc(a.asm_q64, a.n_quads * 512u);
       const uint32_t q_last = a.n_quads ? a.n_quads - 1 : 0u;
-      uint32_t rw[NB][QB], rc[NB][QB];
-      auto fetch = [&](uint32_t qb, uint32_t (&wd)[QB], uint32_t (&cd)[QB]) {
+      mi_u32x2 nxt[QB];
+      auto fetch = [&](uint32_t qb) {
 #pragma unroll
         for (int u = 0; u < QB; u++) {
           const uint32_t q = qb + u < q_last ? qb + u : q_last;
-          wd[u] = a.asm_q[(size_t)q * 64 + lane]; cd[u] = (uint32_t)a.asm_qcol[(size_t)q * 4 + l4];
+          nxt[u] = __builtin_amdgcn_raw_buffer_load_b64(tab, (uint32_t)lane * 8u, q * 512u, 0);
         }
       };
-      uint32_t qnext = ttab[t_begin].z;                      // first quad not yet requested
-      if (a.n_quads) {
 #pragma unroll
-        for (int b = 0; b < NB; b++) { fetch(qnext, rw[b], rc[b]); qnext += QB; }
-      }
+      for (int u = 0; u < QB; u++) nxt[u] = mi_u32x2{0u, 0u};
+      uint32_t qnext = ttab[t_begin].z;                      // first quad not yet requested
+      if (a.n_quads) { fetch(qnext); qnext += QB; }
+      const char *lds = reinterpret_cast<const char *>(smem);
+      const uint32_t dc_off = (uint32_t)(a.n_lt + 1) * 8u;
       mi_v4d acc_next = load_init(ttab[t_begin]);
       for (uint32_t ti = t_begin; ti < t_end; ti++) {
         const uint4 tt = ttab[ti];
         mi_v4d acc = acc_next;
         acc_next = load_init(ttab[ti + 1 < t_end ? ti + 1 : ti]);
         for (uint32_t q = tt.z; q < tt.w; q += QB) {
-          uint32_t w[QB], ci[QB];
+          mi_u32x2 cur[QB];
 #pragma unroll
-          for (int u = 0; u < QB; u++) { w[u] = rw[0][u]; ci[u] = rc[0][u]; }
-#pragma unroll
-          for (int b = 0; b + 1 < NB; b++)
-#pragma unroll
-            for (int u = 0; u < QB; u++) { rw[b][u] = rw[b + 1][u]; rc[b][u] = rc[b + 1][u]; }
-          fetch(qnext, rw[NB - 1], rc[NB - 1]); qnext += QB;
+          for (int u = 0; u < QB; u++) cur[u] = nxt[u];
+          fetch(qnext); qnext += QB;
           double av[QB], bv[QB];
 #pragma unroll
-          for (int u = 0; u < QB; u++) { av[u] = -La[w[u] & 0xFFFFu]; bv[u] = La[w[u] >> 16] * Dc[ci[u]]; }
+          for (int u = 0; u < QB; u++) {
+            av[u] = *reinterpret_cast<const double *>(lds + cur[u].x);
+            bv[u] = *reinterpret_cast<const double *>(lds + (cur[u].y & 0x1FFFFu)) * *reinterpret_cast<const double *>(lds + dc_off + (cur[u].y >> 17));
+          }
 #pragma unroll
           for (int u = 0; u < QB; u++) acc = mfma_f64(av[u], bv[u], acc);
         }
@@ -1811,27 +1814,34 @@ __global__ __launch_bounds__(512) void tail_kernel(TailArgs a) {
   }
   // ---- M = -A into the QP's stream of the symmetric product, its diagonal into dinv
   {
+    // The stream is the sequence of the product's tasks: per task one 64 x 64 block of M in "circulant" order (step q, lane
+    // l: M[I0 + (l + s0 + q) % 64, J0 + l]).  The block's 16 tiles are read coalesced into an LDS image (two images: the
+    // tiles of the next block load while this one is written) and written out step by step as contiguous 512-byte rows -
+    // a transposition through LDS instead of 100 k scattered 8-byte reads of the scratch (0.27 M clocks per QP).
     double *dv = a.dt_val + (size_t)slot * a.n_slots;
-    // 14 independent gathers per thread and trip, the index words one trip ahead; positions past the end repeat the last
-    // slot (same value written twice) instead of branching around the loads
-    constexpr int UW = 14;
-    const uint32_t last = a.n_slots - 1;
-    int32_t scn[UW];
-    auto fetch_idx = [&](uint32_t e0) {
+    for (uint32_t t = 0; t < a.n_tasks; t++) {
+      double *Tb = smem + (size_t)(t & 1u) * (64 * MI_TAIL_TS);
+      const uint32_t I0 = a.dt_task[4 * t], J0 = a.dt_task[4 * t + 1], fl = a.dt_task[4 * t + 2] & 255u, nsteps = a.dt_task[4 * t + 3];
+      const bool diag = fl & 1u;
+      for (int idx = wave; idx < 16; idx += MI_TAIL_NW) {
+        const int ta = idx >> 2, tb = idx & 3;
+        if (diag && ta < tb) continue;
+        const mi_v4d v = ld_tile(A, tile_ix((int)I0 / 16 + ta, (int)J0 / 16 + tb), lane);
 #pragma unroll
-      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); scn[u] = a.src_tile[e < last ? e : last]; }
-    };
-    fetch_idx((uint32_t)tid);
-    for (uint32_t e0 = tid; e0 < a.n_slots; e0 += (uint32_t)nthr * UW) {
-      int32_t sc[UW];
-      double v[UW];
-#pragma unroll
-      for (int u = 0; u < UW; u++) sc[u] = scn[u];
-      fetch_idx(e0 + (uint32_t)nthr * UW);
-#pragma unroll
-      for (int u = 0; u < UW; u++) { const double t = A[sc[u] >= 0 ? sc[u] : 0]; v[u] = sc[u] >= 0 ? -t : 0.0; }
-#pragma unroll
-      for (int u = 0; u < UW; u++) { const uint32_t e = e0 + (uint32_t)(u * nthr); dv[e < last ? e : last] = v[u]; }
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * ta + l4 + 4 * r, col = 16 * tb + l15;
+          if (!diag) Tb[row * MI_TAIL_TS + col] = v[r];
+          else if (ta != tb || row >= col) { Tb[row * MI_TAIL_TS + col] = v[r]; Tb[col * MI_TAIL_TS + row] = v[r]; }
+        }
+      }
+      __syncthreads();
+      const uint32_t s0 = diag ? 1u : 0u, step0 = a.dt_task_step[t];
+      for (uint32_t q = wave; q < nsteps; q += MI_TAIL_NW) {
+        const uint32_t sh = s0 + q, i = ((uint32_t)lane + sh) & 63u;
+        double val = -Tb[i * MI_TAIL_TS + lane];
+        if (diag && sh == 32u && lane >= 32) val = 0.0;          // the pairs at distance 32 appear twice in a diagonal block
+        dv[(size_t)(step0 + q) * 64 + lane] = val;
+      }
     }
     for (int i = tid; i < k; i += nthr) a.dinv[H(a.N, (size_t)a.s + i)] = -A[a.diag_tile[i]];
   }

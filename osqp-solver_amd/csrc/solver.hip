@@ -191,8 +191,8 @@ struct mi_osqp_batch {
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
   // dense tail (host_core.hpp DenseTail): task tables, the per-QP stream of S^-1 (+ setup snapshot), dense scratch
   DevBuf<uint32_t> dt_task, dt_wave_task, dt_wave_step, dt_tail_bar;
-  DevBuf<uint32_t> dt_lt_pos, dt_ltcol_col, dt_tile_tab, dt_wave_tiles, dt_asm_q, dt_diag_tile;     // tail_kernel tables
-  DevBuf<uint16_t> dt_asm_qcol;
+  DevBuf<uint32_t> dt_lt_pos, dt_ltcol_col, dt_tile_tab, dt_wave_tiles, dt_diag_tile, dt_task_step;     // tail_kernel tables
+  DevBuf<uint64_t> dt_asm_q64;
   DevBuf<int32_t> dt_src_tile;
   int dt_nh = 0; uint32_t dt_cs_doubles = 0; size_t dt_lds = 0, dt_lds_asm = 0;
   DevBuf<int32_t> dt_src;
@@ -599,15 +599,15 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     if ((rc = h->dt_task.upload(dt.task)) || (rc = h->dt_wave_task.upload(dt.wave_task)) || (rc = h->dt_wave_step.upload(dt.wave_step)) ||
         (rc = h->dt_tail_bar.upload(dt.tail_bar)) || (rc = h->dt_src.upload(dt.src)) ||
         (rc = h->dt_lt_pos.upload(dt.lt_pos)) || (rc = h->dt_ltcol_col.upload(dt.ltcol_col)) || (rc = h->dt_tile_tab.upload(dt.tile_tab)) ||
-        (rc = h->dt_wave_tiles.upload(dt.wave_tiles)) || (rc = h->dt_asm_q.upload(dt.asm_q)) || (rc = h->dt_asm_qcol.upload(dt.asm_qcol)) ||
-        (rc = h->dt_src_tile.upload(dt.src_tile)) || (rc = h->dt_diag_tile.upload(dt.diag_tile)) ||
+        (rc = h->dt_wave_tiles.upload(dt.wave_tiles)) || (rc = h->dt_asm_q64.upload(dt.asm_q64)) ||
+        (rc = h->dt_src_tile.upload(dt.src_tile)) || (rc = h->dt_diag_tile.upload(dt.diag_tile)) || (rc = h->dt_task_step.upload(dt.task_step)) ||
         (rc = h->dt_Sd.alloc((size_t)dt.k * dt.k * (T + 4)))) return rc;
     // LDS plan of tail_kernel: the staged half of the panel (<= 14 row tiles of 8 KiB; at least the 64 x 65 image of a pivot
     // block) + Pn in operand order (32 KiB), or the compact factor entries of the assembly phase, whichever is larger
     const int nrt = dt.k / 16 - 4;
     h->dt_nh = nrt <= 14 ? std::max(nrt, 1) : (nrt + 1) / 2;
     h->dt_cs_doubles = (uint32_t)std::max(h->dt_nh * 1024, 64 * 65 + 63) / 64 * 64;
-    h->dt_lds = ((size_t)h->dt_cs_doubles + 4096) * sizeof(double);
+    h->dt_lds = std::max<size_t>((size_t)h->dt_cs_doubles + 4096, 2 * 64 * 65) * sizeof(double);       // (the stream write keeps two 64 x 65 images)
     h->dt_lds_asm = (dt.asm_lds_bytes() + 255) & ~(size_t)255;
     if (h->dt_lds > lds_cap || h->dt_lds_asm > lds_cap) { g_last_error = "internal: LDS budget of tail_kernel exceeded"; return MI_OSQP_ERR_ALLOC; }
   }
@@ -791,10 +791,11 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
     const DenseTail &dt = (*h->anp).dt;
     TailArgs da{};
     da.n = (*h->anp).n; da.N = (*h->anp).N; da.s = dt.s; da.k = dt.k; da.kbt = kbt; da.home_bt = BT;
-    da.storage = (*h->anp).bf.storage; da.n_slots = dt.n_steps * 64u; da.n_lt = dt.n_lt; da.n_ltcol = dt.n_ltcol; da.n_quads = (uint32_t)(dt.asm_q.size() / 64);
+    da.storage = (*h->anp).bf.storage; da.n_slots = dt.n_steps * 64u; da.n_lt = dt.n_lt; da.n_ltcol = dt.n_ltcol; da.n_quads = (uint32_t)(dt.asm_q64.size() / 64);
     da.nh = h->dt_nh; da.cs_doubles = h->dt_cs_doubles; da.work = h->work.p;
     da.lt_pos = h->dt_lt_pos.p; da.ltcol_col = h->dt_ltcol_col.p; da.tile_tab = h->dt_tile_tab.p; da.wave_tiles = h->dt_wave_tiles.p;
-    da.asm_q = h->dt_asm_q.p; da.diag_tile = h->dt_diag_tile.p; da.asm_qcol = h->dt_asm_qcol.p; da.src_tile = h->dt_src_tile.p;
+    da.dt_task = h->dt_task.p; da.dt_task_step = h->dt_task_step.p; da.n_tasks = (uint32_t)(dt.task.size() / 4);
+    da.asm_q64 = h->dt_asm_q64.p; da.diag_tile = h->dt_diag_tile.p; da.src_tile = h->dt_src_tile.p;
     da.Lblk = h->Lblk.p; da.Dl = h->Dl.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
     unsigned long long *d_trace = nullptr;
     const bool tracing = getenv("MI_OSQP_TAIL_TRACE") != nullptr;          // timing stamps only; results are unaffected
