@@ -315,7 +315,8 @@ def secondary(M, PR, torch, with_cpu):
         from oracle import oracle as O
     # ---- config 2: single GOMP 6-DOF trajectory QP, 50 waypoints; config 4: 256 x 7-DOF x 100 waypoints
     for name, Bq, D, W in (("config 2: single GOMP 6-DOF trajectory QP, 50 waypoints", 1, 6, 50),
-                           ("config 4: batch of 256 GOMP 7-DOF trajectories, 100 waypoints", 256, 7, 100)):
+                           ("config 4: batch of 256 GOMP 7-DOF trajectories, 100 waypoints", 256, 7, 100),
+                           ("reference example size (examples/solver-example.cpp): single GOMP 6-DOF trajectory QP, 802 waypoints", 1, 6, 802)):
         pr = PR.gomp_batch(Bq, D, W)
         t = time.time()
         s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])

@@ -53,6 +53,15 @@ struct KernelArgs {
   int iter_begin, iter_end;             // this launch runs iterations (iter_begin, iter_end]
   int op_out_lds;                       // spmv op: results staged in LDS (the launcher sized it)
   int info_at_end;                      // a check_kernel follows: store delta_x / delta_y of the last iteration
+  // multi-workgroup mode (one large QP, global solve vector): mw_groups workgroups share the QP's triangular solves and
+  // vector steps; mw_bar = {arrival count, generation, error flag} of their grid barrier (zero between launches)
+  int mw_groups;
+  unsigned *mw_bar;
+  // dataflow form of the triangular solves (Analysis::df; always with the wide index words and one QP): shadow offset of the
+  // in-place results, flags per permuted row (bit 0 forward A step, bit 1 backward A step, bit 2 multi-row chunk)
+  int df;
+  unsigned df_shadow;
+  const unsigned char *rflag;
 };
 
 // device block refactorisation (row E13); tables are host_core.hpp BlockFactor

@@ -270,10 +270,12 @@ int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 // spread over the waves); the steps are then numbered WAVE-MAJOR: wave w's steps of all phases are contiguous
 // in memory and form the linear stream the device walks (sched_format.h); phase boundaries survive only as
 // barrier counts in the descriptors.
-void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers, bool wide) {
+void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers, bool wide,
+                   bool dataflow = false, uint32_t shadow = 0, uint32_t pad = 0) {
   sch = Schedule();
   sch.n_levels = (int)levels.size();
   sch.nw = nw; sch.bt = bt; sch.barriers = barriers;
+  sch.dataflow = dataflow; sch.shadow = shadow; sch.pad = pad;
   // a unit = work that must stay on one wave, in order
   struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; };
   struct Unit { std::vector<StepSpec> steps; };
@@ -366,7 +368,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       for (size_t k = 0; k < recs.size(); k++) {
         const StepSpec &st = recs[k];
         const uint32_t stepno = sch.n_steps++;
-        sch.idx.resize((size_t)sch.n_steps * 64, 0u);
+        sch.idx.resize((size_t)sch.n_steps * 64, pad);
         sch.src.resize((size_t)sch.n_steps * 64, MI_SRC_ZERO);
         uint32_t nbar = 0;
         if (barriers && k == 0) { nbar = (uint32_t)(p - last_phase); last_phase = p; }
@@ -425,6 +427,16 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
   if (getenv("MI_OSQP_DEBUG_ORDER")) {
     fprintf(stderr, "[mi_osqp] schedule: levels %zu phases %zu steps %u outA %zu\n", levels.size(), phases.size(), sch.n_steps,
             sch.outA.size());
+    {   // critical path: the longest wave of every phase
+      uint64_t crit = 0; uint32_t worst = 0; int over8 = 0;
+      for (int p = 0; p < sch.n_phases; p++) {
+        uint32_t mx = 0;
+        for (int w = 0; w < nw; w++) { const uint32_t *e = &sch.phase[(size_t)p * sch.phase_stride() + 1 + 4 * w]; mx = std::max(mx, e[1] - e[0]); }
+        crit += mx; worst = std::max(worst, mx); over8 += mx > 8;
+      }
+      fprintf(stderr, "[mi_osqp]   critical path %llu steps over %d phases (longest phase %u steps, %d phases above 8 steps), %d waves\n",
+              (unsigned long long)crit, sch.n_phases, worst, over8, nw);
+    }
     uint32_t cnt[7][2] = {};
     for (uint32_t st = 0; st < sch.n_steps; st++) cnt[MI_D_LT(sch.step[st])][(sch.step[st] & MI_D_FLUSH) ? 1 : 0]++;
     for (int lt = 0; lt < 7; lt++) fprintf(stderr, "[mi_osqp]   lane groups of %2d: %u flush steps, %u other steps\n", 1 << lt, cnt[lt][1], cnt[lt][0]);
@@ -432,7 +444,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
 }
 }  // namespace
 
-static void build_tri_schedules(Analysis &an, int nw, int bt) {
+static void build_tri_schedules(Analysis &an, int nw, int bt, bool df) {
   int N = an.N;
   int nch = (int)an.chunk_start.size() - 1;
   std::vector<int> chunk_of(N);
@@ -450,6 +462,26 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
     if (multi) { an.inv_off[c] = an.n_inv; an.n_inv += r * (r - 1) / 2; }
     for (int i = 0; i < r; i++) an.xloc[c0 + i] = multi ? an.Next++ : c0 + i;
   }
+  an.df = df;
+  an.xs_total = df ? 2 * an.Next + 8 : an.Next;
+  an.rflag.assign(df ? N : 0, 0);
+  if (df) {
+    for (int c = 0; c < nch; c++) {
+      const int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1];
+      for (int i = c0; i < c1; i++) {
+        uint8_t f = (c1 - c0 >= 2 && c0 < ts) ? 4 : 0;
+        for (int t = an.Rp[i]; t < an.Rp[i + 1] && !(f & 1); t++) if (an.Rj[t] < c0 && an.Rj[t] < ts) f |= 1;
+        for (int q = an.Lp[i]; q < an.Lp[i + 1] && !(f & 2); q++) if (an.Li[q] >= c1) f |= 2;
+        an.rflag[i] = f;
+      }
+    }
+  }
+  const uint32_t SH = (uint32_t)an.Next, PAD = df ? 2u * (uint32_t)an.Next : 0u;
+  // (dataflow form: where a gather finds the FINAL value of the sweep's intermediate results)
+  auto f_t = [&](int k) { return (uint32_t)(df && (an.rflag[k] & 1) ? k + (int)SH : k); };                      // forward: t_k
+  auto f_x = [&](int j) { return (uint32_t)(df ? an.df_floc(j) : an.xloc[j]); };                                // forward: result of row j
+  auto b_t = [&](int k) { return (uint32_t)(df && (an.rflag[k] & 2) ? an.xloc[k] + (int)SH : an.xloc[k]); };    // backward: t_k
+  auto b_x = [&](int j) { return (uint32_t)(df ? an.df_bloc(j) : j); };                                         // backward: result of row j
   // ---- forward: rows ascending, sources are columns j < row.  Row i of a chunk: phase A subtracts the
   // couplings to earlier chunks in place (position i); phase B stores inv(L_cc) t at position xloc[i],
   // which is where every later row gathers it.
@@ -470,18 +502,18 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
         RowWork rw; rw.row = (uint32_t)i;
         for (int t = an.Rp[i]; t < an.Rp[i + 1]; t++) {
           int j = an.Rj[t];
-          if (j < c0 && j < ts) rw.ent.push_back({(uint32_t)an.xloc[j], an.Rpos[t]});
+          if (j < c0 && j < ts) rw.ent.push_back({f_x(j), an.Rpos[t]});
         }
         if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
         if (r >= 2 && c0 < ts) {
           RowWork rb; rb.row = (uint32_t)an.xloc[i];
-          for (int k = c0; k < i; k++) rb.ent.push_back({(uint32_t)k, an.inv_index(c, i - c0, k - c0)});
-          rb.ent.push_back({(uint32_t)i, MI_SRC_ONE});
+          for (int k = c0; k < i; k++) rb.ent.push_back({f_t(k), an.inv_index(c, i - c0, k - c0)});
+          rb.ent.push_back({f_t(i), MI_SRC_ONE});
           lw[lev[c]].rowsB.push_back(std::move(rb));
         }
       }
     }
-    pack_schedule(lw, an.fwd, nw, bt, true, an.wide);
+    pack_schedule(lw, an.fwd, nw, bt, !df, an.wide, df, SH, PAD);
   }
   // ---- backward: columns descending, sources are rows j > column.  Column k of a chunk: phase A works in
   // place at xloc[k] (where the scaled forward result lives), phase B stores inv(L_cc)' t at position k.
@@ -503,18 +535,18 @@ static void build_tri_schedules(Analysis &an, int nw, int bt) {
         RowWork rw; rw.row = (uint32_t)an.xloc[col];
         for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
           int j = an.Li[p];
-          if (j >= c1) rw.ent.push_back({(uint32_t)j, p});
+          if (j >= c1) rw.ent.push_back({b_x(j), p});
         }
         if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
         if (r >= 2) {
           RowWork rb; rb.row = (uint32_t)col;
-          rb.ent.push_back({(uint32_t)an.xloc[col], MI_SRC_ONE});
-          for (int i = col + 1; i < c1; i++) rb.ent.push_back({(uint32_t)an.xloc[i], an.inv_index(c, i - c0, col - c0)});
+          rb.ent.push_back({b_t(col), MI_SRC_ONE});
+          for (int i = col + 1; i < c1; i++) rb.ent.push_back({b_t(i), an.inv_index(c, i - c0, col - c0)});
           lw[lev[c]].rowsB.push_back(std::move(rb));
         }
       }
     }
-    pack_schedule(lw, an.bwd, nw, bt, true, an.wide);
+    pack_schedule(lw, an.bwd, nw, bt, !df, an.wide, df, SH, PAD);
   }
 }
 
@@ -892,8 +924,8 @@ static void build_block_factor(Analysis &an) {
 // --------------------------------------------------------------------- analyze
 
 int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows, int dense_tail_max) {
-  if (nwaves < 1 || nwaves > 16 || (bt != 1 && bt != 2 && bt != 4)) return MI_OSQP_ERR_INVALID_SETTINGS;
+            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows, int dense_tail_max, int tri_waves) {
+  if (nwaves < 1 || nwaves > 16 || (bt != 1 && bt != 2 && bt != 4) || tri_waves < 0 || tri_waves > 2048) return MI_OSQP_ERR_INVALID_SETTINGS;
   if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
   int n = (int)n64, m = (int)m64, N = n + m;
   an = Analysis();
@@ -940,7 +972,8 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   // ---- ordering: two candidates, chosen by the modelled time of one KKT solve on the device
   // (latency-bound regime of one tile, measured with scripts/trace_phases.py: ~0.4 us per phase, ~40 GB/s of factor stream)
   // 16-bit index words while every vector the streams address stays below 65 535 entries (0xFFFF = "no row")
-  an.wide = N >= 65535 || 2 * n + m >= 65535;
+  an.tri_waves = tri_waves;
+  an.wide = N >= 65535 || 2 * n + m >= 65535 || tri_waves > 0;        // (the dataflow form doubles the index range)
   if (max_extra_rows < 0) max_extra_rows = 1 << 30;       // (also the budget of the dense tail's two accumulation vectors)
   if (!an.wide && max_extra_rows > 65534 - N) max_extra_rows = 65534 - N;
   auto finalize = [&](const std::vector<int> &perm0, double &cost) {
@@ -1073,7 +1106,8 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     }
     an.ordering = use_nd ? 1 : 0;
   }
-  build_tri_schedules(an, nwaves, bt);
+  if (tri_waves > 0 && (bt != 1 || an.dt.k)) return MI_OSQP_ERR_INVALID_SETTINGS;
+  build_tri_schedules(an, tri_waves > 0 ? tri_waves : nwaves, bt, tri_waves > 0);
   build_chk_schedule(an, nwaves, bt);
   build_dense_tail(an, nwaves);
   build_block_factor(an);
@@ -1366,7 +1400,86 @@ static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs
   return ok;
 }
 
+// Dataflow form (Schedule::dataflow): the waves advance round robin, one step at a time; a step whose gathers meet a
+// "not yet" entry waits.  False when the streams deadlock, when an entry is written twice in one sweep or when a subtracting
+// flush reads an entry the sweep itself writes (its old value must be there before the sweep starts).
+static bool replay_dataflow(const Schedule &s, const double *canon, double *xs, size_t xs_len, const std::vector<char> &pending) {
+  const int nw = s.nw;
+  std::vector<uint32_t> pos(nw);
+  for (int w = 0; w < nw; w++) pos[w] = s.wave_range[2 * w];
+  std::vector<char> wait(pending), written(xs_len, 0);      // wait[e]: the sweep has yet to write e
+  std::vector<std::vector<double>> acc(nw, std::vector<double>(64, 0.0));
+  bool ok = true;
+  for (;;) {
+    bool done = true, progress = false;
+    for (int w = 0; w < nw; w++) {
+      if (pos[w] >= s.wave_range[2 * w + 1]) continue;
+      done = false;
+      const uint32_t st = pos[w], d = s.step[st];
+      if (MI_D_NBAR(d)) return false;
+      if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
+        bool ready = true;
+        for (uint32_t ln = 0; ln < 64 && ready; ln++) {
+          const uint32_t slot = st * 64 + ln;
+          if (s.src[slot] != MI_SRC_ZERO && wait[s.idx[slot]]) ready = false;
+          if (s.src[slot] == MI_SRC_ZERO && s.idx[slot] != s.pad) ok = false;
+        }
+        if (!ready) continue;
+        const uint32_t lt = MI_D_LT(d), T = 1u << lt;
+        for (uint32_t ln = 0; ln < 64; ln++) {
+          const uint32_t slot = st * 64 + ln;
+          if (s.src[slot] != MI_SRC_ZERO) acc[w][ln] += (s.src[slot] == MI_SRC_ONE ? 1.0 : canon[s.src[slot]]) * xs[s.idx[slot]];
+        }
+        if (d & MI_D_FLUSH) {
+          for (uint32_t g = 0; g < 64 / T; g++) {
+            double sum = 0.0;
+            for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[w][ln];
+            const uint32_t row = s.outA[s.step_ob[st] + g];
+            if (row == kNoRow) continue;
+            const bool sub = !(d & MI_D_STORE);
+            const uint32_t dst = sub ? row + s.shadow : row;
+            if (dst >= xs_len || written[dst] || !pending[dst] || (sub && (pending[row] || written[row]))) { ok = false; continue; }
+            xs[dst] = sub ? xs[row] - sum : sum;
+            written[dst] = 1; wait[dst] = 0;
+          }
+          std::fill(acc[w].begin(), acc[w].end(), 0.0);
+        }
+      }
+      pos[w]++; progress = true;
+    }
+    if (done) break;
+    if (!progress) return false;                              // every unfinished wave waits: deadlock
+  }
+  for (size_t e = 0; e < xs_len; e++) if (pending[e] && !written[e]) ok = false;     // a reset entry nobody writes would stall its readers
+  return ok;
+}
+
+static bool replay_kkt_solve_df(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
+  const int N = an.N, SH = an.Next;
+  std::vector<double> xs(an.xs_total, 0.0);
+  std::vector<char> pend(an.xs_total, 0);
+  // E6 as the device does it: right-hand side at p, "not yet" at every entry the forward sweep writes
+  for (int k = 0; k < N; k++) {
+    xs[k] = rhs[an.perm[k]];
+    if (an.rflag[k] & 1) pend[k + SH] = 1;
+    if (an.rflag[k] & 4) pend[an.xloc[k]] = 1;
+  }
+  bool ok = replay_dataflow(an.fwd, qp.Lx.data(), xs.data(), xs.size(), pend);
+  // the middle: D^-1, results to xloc; "not yet" at every entry the backward sweep writes
+  std::fill(pend.begin(), pend.end(), 0);
+  for (int k = 0; k < N; k++) {
+    const double v = xs[an.df_floc(k)] * qp.Dlinv[k];
+    xs[an.xloc[k]] = v;
+    if (an.rflag[k] & 2) pend[an.xloc[k] + SH] = 1;
+    if (an.rflag[k] & 4) pend[k] = 1;
+  }
+  ok = replay_dataflow(an.bwd, qp.Lx.data(), xs.data(), xs.size(), pend) && ok;
+  for (int k = 0; k < N; k++) sol[an.perm[k]] = xs[an.df_bloc(k)];
+  return ok;
+}
+
 bool replay_kkt_solve(const Analysis &an, const QPNumeric &qp, const double *rhs, double *sol) {
+  if (an.df) return replay_kkt_solve_df(an, qp, rhs, sol);
   int N = an.N;
   std::vector<double> xs(an.Next, 0.0);
   for (int k = 0; k < N; k++) xs[k] = rhs[an.perm[k]];

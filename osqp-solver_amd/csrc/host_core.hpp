@@ -68,6 +68,12 @@ struct Schedule {
   std::vector<uint32_t> wave_range;      // 2 per wave: [begin, end) of its stream
   std::vector<uint32_t> lvl_pos;         // (n_levels+1) x nw: stream position of wave w at the start of level L
   std::vector<uint32_t> tail_bar;        // per wave: barriers still owed after its last step (all waves pass n_phases)
+  // dataflow form (Analysis::df): no barriers; a subtracting flush reads the old value at `row` and writes the result at
+  // `row + shadow`, every entry of the solve vector a step gathers is either written before the sweep starts or written
+  // exactly ONCE during the sweep (the gatherer waits until it no longer holds the "not yet" pattern); padding slots
+  // gather entry `pad` (always 0.0)
+  bool dataflow = false;
+  uint32_t shadow = 0, pad = 0;
   uint32_t phys_steps() const { return n_steps; }
   size_t phase_stride() const { return 4 * (size_t)nw + 1; }
   int n_levels = 0;
@@ -178,6 +184,21 @@ struct Analysis {
   // one-row chunks, N + (running index) for the rows of multi-row chunks (Next = vector length)
   std::vector<int> xloc;
   int Next = 0;
+  // Dataflow form of the triangular solves (tri_waves > 0 of analyze(): ONE QP shared by that many waves, solve
+  // vector in global memory).  The waves do not meet at barriers between the levels: a value that a sweep produces is
+  // written once, to an entry that holds the "not yet" bit pattern until then, and its consumers poll for it.  For that
+  // the in-place results get a second home: entry e + Next ("shadow") for a row whose sweep step subtracts in place.
+  //   forward : A rows read the right-hand side at i and write t_i at i + Next; B rows write at xloc[i]
+  //   backward: A rows read xloc[k] and write at xloc[k] + Next; B rows write at k
+  // rflag[e]: bit 0 = row e has a forward A step, bit 1 = a backward A step, bit 2 = row of a multi-row chunk.
+  // Entry 2 * Next is the padding entry (0.0); the vector has xs_total entries.
+  bool df = false;
+  int tri_waves = 0;
+  int xs_total = 0;
+  std::vector<uint8_t> rflag;
+  // where the forward / backward sweep leaves the final value of row e
+  int df_floc(int e) const { return (rflag[e] & 4) ? xloc[e] : ((rflag[e] & 1) ? e + Next : e); }
+  int df_bloc(int e) const { return (rflag[e] & 4) ? e : ((rflag[e] & 2) ? e + Next : e); }
   Schedule fwd, bwd, chk;
   BlockFactor bf;
   DenseTail dt;                    // dt.k == 0: none
@@ -199,9 +220,12 @@ struct Analysis {
 // LDS capacity; negative = no limit of the caller's.  With 16-bit index words (Analysis::wide == false) the count
 // is also limited by the index range.
 // `dense_tail_max` = largest dense tail (rows) the caller can serve, 0 = never use one.
+// `tri_waves` > 0 = the dataflow form of the triangular solves (Analysis::df: ONE QP, solve vector in global memory, no
+// dense tail): the forward / backward step streams are laid out for that many waves (of any number of workgroups); the
+// check schedule stays at nwaves.  0 = the barrier form (one workgroup of nwaves waves per tile).
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
             const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1,
-            int dense_tail_max = 512);
+            int dense_tail_max = 512, int tri_waves = 0);
 // physical position (in doubles, inside one tile) of QP b's value of a logical slot
 size_t phys_index(const Schedule &s, uint32_t slot, int b);
 

@@ -338,13 +338,207 @@ __device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin,
   if constexpr (TR >= 2) { if (lane == 0) { tw[2 * wave] = wait_cycles; tw[2 * wave + 1] = real_steps; } }
 }
 
+// Triangular solve with the solve vector in GLOBAL memory (GX: KKT systems that do not fit LDS - the large single QPs).
+// Same streams, same arithmetic and order as run_stream; what differs is when the vector is touched.  There, gathers run
+// 2 steps ahead and a flush step reads the old value of its target row right before the read-modify-write: with LDS
+// that costs nothing, with global memory every gather exposes most of an L2 round trip (VMEM returns in order, behind
+// the value ring) and every flush step - half of the steps - drains the whole queue (`vmcnt(0)`): 0.55 us per step at
+// config 5.  Here BOTH the gathered values and the old values of the flush targets are requested LA = 8 steps ahead
+// (index words and descriptors of those steps are in the ring already: PF = 18 > LA), and whatever was requested across
+// a phase barrier is requested again right after it in one burst (another wave may have written those entries before
+// the barrier; within a phase no step reads what another one writes - host replay).
+#define MI_GX_PF 18
+#define MI_GX_LA 8
+// Barrier of the multi-workgroup mode: G workgroups (one per CU, all resident: G <= 64 on 256 CUs) share one QP.  The
+// recipe of MI355X_MICROARCH.md (inter-workgroup visibility): every storing wave has drained its stores (__syncthreads
+// waits vmcnt(0)), lane 0 releases at agent scope (writes the XCD's dirty L2 lines back), arrives on a monotonic counter,
+// polls the generation word with relaxed loads + s_sleep, acquires at agent scope (invalidates this CU's L1) and lets its
+// workgroup go.  A wait of more than ~2 s raises the error word instead of hanging the GPU (every workgroup then runs out
+// the same way; the host reports a device error).
+struct Mw { unsigned *bar; unsigned G; };
+__device__ __forceinline__ void grid_barrier(const Mw &mw) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned gen = __hip_atomic_load(&mw.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned arrived = __hip_atomic_fetch_add(&mw.bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (arrived == mw.G) {
+      __hip_atomic_store(&mw.bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&mw.bar[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+      while (__hip_atomic_load(&mw.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(&mw.bar[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (__hip_atomic_load(&mw.bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void wg_or_grid_barrier(const Mw &mw) { if (mw.G > 1) grid_barrier(mw); else __syncthreads(); }
+template <int BT, int PF, int LA, bool WIDE>
+__device__ __forceinline__ void run_stream_gx(const ValSrc<BT> &vs, uint32_t begin, uint32_t end, uint32_t tail, double *xs, int lane) {
+  constexpr int G = LA + 1;                   // slots of requested values: step q uses slot q % G (G divides PF)
+  static_assert(PF % G == 0 && PF > LA + 4, "slots must line up across ring revolutions; the ring must hold the steps looked ahead at");
+  constexpr uint32_t NONE = WIDE ? 0xFFFFFFFFu : 0xFFFFu;
+  Ring<BT, PF> r;
+  r.desc = MI_D_NOOP;
+#pragma unroll
+  for (int st = 0; st < PF; st++) {
+    r.gi[st] = 0u; r.gr[st] = 0u;
+#pragma unroll
+    for (int b = 0; b < BT; b++) r.v[st][b] = 0.0;
+  }
+  double acc[BT], xq[G][BT], oq[G][BT];
+#pragma unroll
+  for (int b = 0; b < BT; b++) {
+    acc[b] = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; g++) { xq[g][b] = 0.0; oq[g][b] = 0.0; }
+  }
+  for (uint32_t npos = begin; npos < end + PF; npos += PF) {   // this revolution runs steps npos - PF + st, loads npos + st
+    const uint32_t dnext = load_desc(vs, npos, end, lane);
+    // request the vector entries step (st + j) of this revolution needs: its gather operand and, for a subtracting flush
+    // step, the old value of its target row (no-op steps request entry 0: no branch around a load)
+    auto request = [&](int sj, uint32_t dj) {                   // sj: position in the ring (static), dj: its descriptor
+      const bool row_step = MI_D_TYPE(dj) == MI_D_TYPE_ROW;
+      const uint32_t w = r.gi[sj % PF];
+      const uint32_t gidx = row_step ? (WIDE ? w : (w & 0xFFFFu)) : 0u;
+      load_bt<BT>(xs + (size_t)gidx * BT, xq[sj % G]);
+      const bool rmw = row_step && (dj & MI_D_FLUSH) && !(dj & MI_D_STORE);
+      const uint32_t row = WIDE ? r.gr[sj % PF] : (w >> 16);
+      flush_prefetch<BT, NONE>(rmw ? MI_D_LT(dj) : 0u, rmw ? row : 0u, xs, lane, oq[sj % G]);      // (not a flush: entry 0, unused)
+    };
+#pragma unroll
+    for (int st = 0; st < PF; st++) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st);
+      const uint32_t nb0 = MI_D_NBAR(d);
+      if (nb0) {
+        for (uint32_t nb = nb0; nb; nb--) __syncthreads();
+        // everything requested before the barrier may be stale: request the next LA steps again, in one burst
+#pragma unroll
+        for (int j = 0; j < LA; j++) {
+          const uint32_t dj = st + j < PF ? (uint32_t)__builtin_amdgcn_readlane((int)r.desc, (st + j) % PF)
+                                          : (uint32_t)__builtin_amdgcn_readlane((int)dnext, (st + j) % PF);
+          request(st + j, dj);
+        }
+      }
+      // look-ahead: step st + LA (its ring slot and descriptor arrived long ago); its slot (st + LA) % G is the one step
+      // st - 1 used
+      {
+        const uint32_t dl = st + LA < PF ? (uint32_t)__builtin_amdgcn_readlane((int)r.desc, (st + LA) % PF)
+                                         : (uint32_t)__builtin_amdgcn_readlane((int)dnext, (st + LA) % PF);
+        request(st + LA, dl);
+        if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
+#pragma unroll
+          for (int b = 0; b < BT; b++) acc[b] = fma(r.v[st][b], xq[st % G][b], acc[b]);
+          if (d & MI_D_FLUSH) {
+            const uint32_t w = r.gi[st];
+            const uint32_t lt = MI_D_LT(d), row = WIDE ? r.gr[st] : (w >> 16);
+            reduce_write<BT, NONE>(acc, lt, row, xs, lane, !(d & MI_D_STORE), oq[st % G]);
+#pragma unroll
+            for (int b = 0; b < BT; b++) acc[b] = 0.0;
+          }
+        }
+      }
+      load_step<BT, WIDE>(vs, npos + (uint32_t)st, lane, r.v[st], r.gi[st], r.gr[st]);
+    }
+    r.desc = dnext;
+  }
+  for (uint32_t nb = tail; nb; nb--) __syncthreads();
+}
+
+// ---- dataflow form of a sweep (host_core.hpp Analysis::df): ONE QP, the vector in global memory, any number of workgroups.
+// No barriers between the levels: every entry a sweep produces is written exactly once (a subtracting flush reads the old
+// value at `row` and writes at `row + shadow`) and holds the bit pattern MI_DF_NOTYET until then; a step whose gather meets
+// that pattern loads again until the value is there.  All accesses of the vector are agent-scope relaxed atomics, i.e.
+// sc1 loads / stores (past the CU's L1, written through: the 8-byte "granule" hand-off of MI355X_MICROARCH.md, one hop
+// ~1 us instead of a grid barrier of ~6 us per level).  Gathers and old values are requested LA steps ahead like in
+// run_stream_gx; a request that came back too early just costs the re-load.  Every wave of the grid is resident (<= 64
+// workgroups of 8 waves) and the streams are ordered by level, so the waits cannot form a cycle; a wait of more than ~2 s
+// (a lost store would be a bug) raises the error word instead of hanging the GPU, and every later wait gives up at once.
+#define MI_DF_NOTYET 0x7FF8D0F1A5B4C3D2ll          // a quiet NaN with a payload no arithmetic produces
+__device__ __forceinline__ double ld_sc1(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double df_notyet() { return __longlong_as_double(MI_DF_NOTYET); }
+template <int PF, int LA>
+__device__ __forceinline__ void run_stream_df(const ValSrc<1> &vs, uint32_t begin, uint32_t end, double *xs, uint32_t shadow, int lane,
+                                              unsigned *err) {
+  constexpr int G = LA + 1;
+  static_assert(PF % G == 0 && PF > LA + 4, "slots must line up across ring revolutions; the ring must hold the steps looked ahead at");
+  Ring<1, PF> r;
+  r.desc = MI_D_NOOP;
+#pragma unroll
+  for (int st = 0; st < PF; st++) { r.gi[st] = 0u; r.gr[st] = 0u; r.v[st][0] = 0.0; }
+  double acc = 0.0, xq[G], oq[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) { xq[g] = 0.0; oq[g] = 0.0; }
+  bool dead = false;                                                       // a wait has timed out: results are garbage, do not wait again
+  for (uint32_t npos = begin; npos < end + PF; npos += PF) {
+    const uint32_t dnext = load_desc(vs, npos, end, lane);
+    auto request = [&](int sj, uint32_t dj) {
+      const bool row_step = MI_D_TYPE(dj) == MI_D_TYPE_ROW;
+      xq[sj % G] = ld_sc1(xs + (row_step ? r.gi[sj % PF] : 0u));
+      const bool rmw = row_step && (dj & MI_D_FLUSH) && !(dj & MI_D_STORE);
+      const uint32_t row = r.gr[sj % PF];
+      const bool mine = rmw && row != 0xFFFFFFFFu && ((uint32_t)lane & ((1u << MI_D_LT(dj)) - 1u)) == 0u;
+      oq[sj % G] = ld_sc1(xs + (mine ? row : 0u));                         // (not needed: entry 0, unused - no branch around a load)
+    };
+#pragma unroll
+    for (int st = 0; st < PF; st++) {
+      const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)r.desc, st);
+      const uint32_t dl = st + LA < PF ? (uint32_t)__builtin_amdgcn_readlane((int)r.desc, (st + LA) % PF)
+                                       : (uint32_t)__builtin_amdgcn_readlane((int)dnext, (st + LA) % PF);
+      request(st + LA, dl);
+      if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
+        double xv = xq[st % G];
+        if (__builtin_amdgcn_ballot_w64(__double_as_longlong(xv) == MI_DF_NOTYET) && !dead) {
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+          uint32_t spins = 0;
+          do {
+            xv = ld_sc1(xs + r.gi[st]);
+            if ((++spins & 63u) == 0u &&
+                (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+              __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              dead = true;
+              break;
+            }
+          } while (__builtin_amdgcn_ballot_w64(__double_as_longlong(xv) == MI_DF_NOTYET));
+        }
+        acc = fma(r.v[st][0], xv, acc);
+        if (d & MI_D_FLUSH) {
+          const uint32_t lt = MI_D_LT(d), row = r.gr[st];
+          const bool sub = !(d & MI_D_STORE);
+          double kp = acc;
+          if (lt > 0) kp += dpp_d<DPP_SHL(1)>(kp);
+          if (lt > 1) kp += dpp_d<DPP_SHL(2)>(kp);
+          if (lt > 2) kp += dpp_d<DPP_SHL(4)>(kp);
+          if (lt > 3) kp += dpp_d<DPP_SHL(8)>(kp);
+          if (lt > 4) kp += down16_d(kp);
+          if (lt > 5) kp += down32_d(kp);
+          if (row != 0xFFFFFFFFu && ((uint32_t)lane & ((1u << lt) - 1u)) == 0u)
+            st_sc1(xs + (size_t)row + (sub ? shadow : 0u), sub ? oq[st % G] - kp : kp);
+          acc = 0.0;
+        }
+      }
+      load_step<1, true>(vs, npos + (uint32_t)st, lane, r.v[st], r.gi[st], r.gr[st]);
+    }
+    r.desc = dnext;
+  }
+}
+
 // One triangular solve: this wave's whole stream of the schedule.
 template <int BT, int PF, bool GX, int TR = 0, bool WIDE = false>
 __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc<BT> &vals, double *xs, int wave, int lane,
                                         uint32_t *tr = nullptr, uint32_t *tw = nullptr) {
   mi_cptr lp = as_const(s.lvl_pos);
   const uint32_t begin = lp[wave], end = lp[(size_t)s.n_levels * s.nw + wave], tail = as_const(s.tail_bar)[wave];
-  run_stream<BT, PF, true, true, GX, TR, WIDE>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw, tw);
+  if constexpr (GX && TR == 0 && BT <= 2) run_stream_gx<BT, MI_GX_PF, MI_GX_LA, WIDE>(vals, begin, end, tail, xs, lane);     // (BT = 4: registers)
+  else run_stream<BT, PF, true, true, GX, TR, WIDE>(vals, begin, end, tail, xs, nullptr, lane, tr, wave, s.nw, tw);
 }
 
 // SpMV with the same streams: levels [l0, l1) of the check schedule (independent rows, no barriers)
@@ -534,7 +728,17 @@ template <int BT, bool GX>
 __device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *dinv, const mi_rsrc (&vdt)[BT], int act, double *xs,
                                            int tid, int nthr, int wave, int lane) {
   if (!a.dt.k) {
-    for (int e = tid; e < a.N * BT; e += nthr) xs[(size_t)a.xloc[e / BT] * BT + e % BT] *= dinv[e];
+    constexpr int U = GX ? 8 : 1;               // (global vector: U dependent xloc -> xs gathers in flight per thread)
+    const int tot = a.N * BT;
+    for (int e0 = tid; e0 < tot; e0 += nthr * U) {
+      size_t pos[U]; double v[U], dv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int e = e0 + u * nthr < tot ? e0 + u * nthr : e0; pos[u] = (size_t)a.xloc[e / BT] * BT + e % BT; dv[u] = dinv[e]; }
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = xs[pos[u]];
+#pragma unroll
+      for (int u = 0; u < U; u++) if (e0 + u * nthr < tot) xs[pos[u]] = v[u] * dv[u];
+    }
     __syncthreads();
     return;
   }
@@ -565,9 +769,50 @@ __device__ __forceinline__ void kkt_middle(const KernelArgs &a, const double *di
 }
 
 // K solve on the LDS vector: fwd levels, D^-1, bwd levels (row E7)
+// Dataflow form: where the sweeps leave the final value of permuted row e (host_core.hpp Analysis::df_floc / df_bloc)
+__device__ __forceinline__ uint32_t df_floc(uint32_t e, uint32_t f, uint32_t xl, uint32_t sh) { return (f & 4u) ? xl : ((f & 1u) ? e + sh : e); }
+__device__ __forceinline__ uint32_t df_bloc(uint32_t e, uint32_t f, uint32_t sh) { return (f & 4u) ? e : ((f & 2u) ? e + sh : e); }
+// entries the forward sweep is going to write: "not yet" (by whoever stores the right-hand side entry of row e)
+__device__ __forceinline__ void df_arm_fwd(double *xs, uint32_t e, uint32_t f, uint32_t xl, uint32_t sh) {
+  if (f & 1u) st_sc1(xs + e + sh, df_notyet());
+  if (f & 4u) st_sc1(xs + xl, df_notyet());
+}
+
+// (tid / nthr / wave: of the workgroup, or - one QP shared by mw.G workgroups - of the whole grid)
 template <int BT, int PF, bool GX, bool WIDE = false>
 __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtrs<BT> &p, double *xs,
-                                              int tid, int nthr, int wave, int nw, int lane) {
+                                              int tid, int nthr, int wave, int nw, int lane, const Mw &mw = Mw{nullptr, 1u}) {
+  if constexpr (GX && BT == 1 && WIDE) {
+    if (a.df) {
+      // the caller has stored the right-hand side, armed the forward entries and passed a barrier
+      mi_cptr lpf = as_const(a.fwd.lvl_pos), lpb = as_const(a.bwd.lvl_pos);
+      run_stream_df<MI_GX_PF, MI_GX_LA>(p.vfwd, lpf[wave], lpf[(size_t)a.fwd.n_levels * a.fwd.nw + wave], xs, a.df_shadow, lane, mw.bar + 2);
+      wg_or_grid_barrier(mw);
+      // D^-1, results to xloc; arm the entries the backward sweep writes
+      const uint32_t sh = a.df_shadow;
+      constexpr int U = 8;
+      for (int e0 = tid; e0 < a.N; e0 += nthr * U) {
+        uint32_t xl[U], f[U]; double v[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int e = e0 + u * nthr < a.N ? e0 + u * nthr : e0; xl[u] = a.xloc[e]; f[u] = a.rflag[e]; dv[u] = p.dinv[e]; }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int e = e0 + u * nthr < a.N ? e0 + u * nthr : e0; v[u] = ld_sc1(xs + df_floc((uint32_t)e, f[u], xl[u], sh)); }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int e = e0 + u * nthr;
+          if (e < a.N) {
+            st_sc1(xs + xl[u], v[u] * dv[u]);
+            if (f[u] & 2u) st_sc1(xs + xl[u] + sh, df_notyet());
+            if (f[u] & 4u) st_sc1(xs + e, df_notyet());
+          }
+        }
+      }
+      wg_or_grid_barrier(mw);
+      run_stream_df<MI_GX_PF, MI_GX_LA>(p.vbwd, lpb[wave], lpb[(size_t)a.bwd.n_levels * a.bwd.nw + wave], xs, a.df_shadow, lane, mw.bar + 2);
+      wg_or_grid_barrier(mw);
+      return;
+    }
+  }
   run_tri<BT, PF, GX, 0, WIDE>(a.fwd, p.vfwd, xs, wave, lane);
   kkt_middle<BT, GX>(a, p.dinv, p.vdt, p.act, xs, tid, nthr, wave, lane);
   run_tri<BT, PF, GX, 0, WIDE>(a.bwd, p.vbwd, xs, wave, lane);
@@ -579,7 +824,12 @@ __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtr
 template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   extern __shared__ double smem[];
-  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  // multi-workgroup mode (global vector, one QP): the grid is ONE tile; thread / wave numbers run over the grid and the
+  // barriers between phases are grid barriers
+  const Mw mw{a.mw_bar, GX && BT == 1 && a.mw_groups > 1 ? (unsigned)a.mw_groups : 1u};
+  const bool multi = GX && BT == 1 && mw.G > 1;
+  const int tile = multi ? 0 : blockIdx.x;
+  const int tid = multi ? blockIdx.x * blockDim.x + threadIdx.x : threadIdx.x, nthr = multi ? blockDim.x * mw.G : blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
   const int n = a.n, m = a.m, N = a.N;
@@ -589,44 +839,88 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   const int done = p.iscal[IS_DONE * BT + b];
   if (__syncthreads_and(done)) return;
   const double alpha = a.alpha, sigma = a.sigma;
+  bool df = false;
+  if constexpr (GX && BT == 1 && WIDE) df = a.df != 0;
+  const uint32_t sh = a.df_shadow;
   // ---- E6 of the first iteration: rhs into the permuted solve vector
   for (int e = tid; e < N * BT; e += nthr) {
     const int i = e / BT;
     double v;
     if (i < n) v = sigma * p.x[e] - p.q[e];
     else { const int ez = e - n * BT; v = p.z[ez] - p.rho_inv[ez] * p.y[ez]; }
-    xs[(size_t)a.pinv[i] * BT + b] = v;
+    const uint32_t pe = a.pinv[i];
+    if (df) { st_sc1(xs + pe, v); df_arm_fwd(xs, pe, a.rflag[pe], a.xloc[pe], sh); }
+    else xs[(size_t)pe * BT + b] = v;
   }
-  __syncthreads();
+  if (df && tid == 0) st_sc1(xs + 2 * (size_t)sh, 0.0);            // the entry padding slots gather
+  if constexpr (GX) wg_or_grid_barrier(mw); else __syncthreads();
   for (int iter = a.iter_begin + 1; iter <= a.iter_end; iter++) {
     const bool do_info = a.info_at_end && iter == a.iter_end;     // delta_x / delta_y are only needed by check_kernel
     // ---- E7
-    kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
+    kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
     // ---- E8-E10 fused with E6 of the next iteration (run_tri ends with a barrier): every thread replaces the
     // solution entry it has just consumed by the next right-hand side entry - same position, no other reader
-    for (int e = tid; e < n * BT; e += nthr) {
-      const int i = e / BT;
-      const size_t pos = (size_t)a.pinv[i] * BT + b;
-      const double xt = xs[pos], xp = p.x[e];
-      double xn = alpha * xt + (1.0 - alpha) * xp;
-      if (!done) { p.x[e] = xn; if (do_info) p.dx[e] = xn - xp; } else xn = xp;
-      xs[pos] = sigma * xn - p.q[e];
+    // (global-vector mode: one workgroup walks 4 x 10^5 entries, each a dependent pinv -> xs gather: U entries per thread
+    //  are loaded before any of them is stored, else every trip costs a full memory round trip - 1.5 ms per iteration at
+    //  config 5; U = 1 with the vector in LDS: same code as before)
+    constexpr int U = GX ? 4 : 1;
+    // (dataflow form: the solution of row pe sits at df_bloc(pe); the new right-hand side goes to pe and the entries the
+    //  forward sweep writes are armed - same thread, loads before stores, so an entry that is both is read first)
+    uint32_t fl[U], xl[U];
+    for (int e0 = tid; e0 < n * BT; e0 += nthr * U) {
+      size_t pos[U]; double xt[U], xp[U], qv[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int e = e0 + u * nthr < n * BT ? e0 + u * nthr : e0; pos[u] = (size_t)a.pinv[e / BT] * BT + b; }
+      if (df) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { fl[u] = a.rflag[pos[u]]; xl[u] = a.xloc[pos[u]]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * nthr < n * BT ? e0 + u * nthr : e0;
+        xt[u] = df ? ld_sc1(xs + df_bloc((uint32_t)pos[u], fl[u], sh)) : xs[pos[u]]; xp[u] = p.x[e]; qv[u] = p.q[e];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * nthr;
+        if (e < n * BT) {
+          double xn = alpha * xt[u] + (1.0 - alpha) * xp[u];
+          if (!done) { p.x[e] = xn; if (do_info) p.dx[e] = xn - xp[u]; } else xn = xp[u];
+          if (df) { st_sc1(xs + pos[u], sigma * xn - qv[u]); df_arm_fwd(xs, (uint32_t)pos[u], fl[u], xl[u], sh); }
+          else xs[pos[u]] = sigma * xn - qv[u];
+        }
+      }
     }
-    for (int e = tid; e < m * BT; e += nthr) {
-      const int j = e / BT;
-      const size_t pos = (size_t)a.pinv[n + j] * BT + b;
-      const double nu = xs[pos];
-      const double zp = p.z[e], yv = p.y[e], ri = p.rho_inv[e], rv = p.rho_vec[e];
-      double zt = zp - ri * yv;
-      zt += ri * nu;
-      const double zr = alpha * zt + (1.0 - alpha) * zp;
-      double zn = fmin(fmax(zr + ri * yv, p.l[e]), p.u[e]);
-      const double dyv = rv * (zr - zn);
-      double yn = yv + dyv;
-      if (!done) { p.z[e] = zn; p.y[e] = yn; if (do_info) p.dy[e] = dyv; } else { zn = zp; yn = yv; }
-      xs[pos] = zn - ri * yn;
+    for (int e0 = tid; e0 < m * BT; e0 += nthr * U) {
+      size_t pos[U]; double nu[U], zp[U], yv[U], ri[U], rv[U], lo[U], up[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) { const int e = e0 + u * nthr < m * BT ? e0 + u * nthr : e0; pos[u] = (size_t)a.pinv[n + e / BT] * BT + b; }
+      if (df) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { fl[u] = a.rflag[pos[u]]; xl[u] = a.xloc[pos[u]]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * nthr < m * BT ? e0 + u * nthr : e0;
+        nu[u] = df ? ld_sc1(xs + df_bloc((uint32_t)pos[u], fl[u], sh)) : xs[pos[u]]; zp[u] = p.z[e]; yv[u] = p.y[e]; ri[u] = p.rho_inv[e]; rv[u] = p.rho_vec[e]; lo[u] = p.l[e]; up[u] = p.u[e];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = e0 + u * nthr;
+        if (e < m * BT) {
+          double zt = zp[u] - ri[u] * yv[u];
+          zt += ri[u] * nu[u];
+          const double zr = alpha * zt + (1.0 - alpha) * zp[u];
+          double zn = fmin(fmax(zr + ri[u] * yv[u], lo[u]), up[u]);
+          const double dyv = rv[u] * (zr - zn);
+          double yn = yv[u] + dyv;
+          if (!done) { p.z[e] = zn; p.y[e] = yn; if (do_info) p.dy[e] = dyv; } else { zn = zp[u]; yn = yv[u]; }
+          if (df) { st_sc1(xs + pos[u], zn - ri[u] * yn); df_arm_fwd(xs, (uint32_t)pos[u], fl[u], xl[u], sh); }
+          else xs[pos[u]] = zn - ri[u] * yn;
+        }
+      }
     }
-    __syncthreads();
+    if constexpr (GX) wg_or_grid_barrier(mw); else __syncthreads();
   }
 }
 
@@ -1017,18 +1311,38 @@ hipError_t launch_spmv_fused(const KernelArgs &a, const SpmvFused &t, int BT, in
 template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const double *__restrict__ rhs, double *sol) {
   extern __shared__ double smem[];
-  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const Mw mw{a.mw_bar, GX && BT == 1 && a.mw_groups > 1 ? (unsigned)a.mw_groups : 1u};      // (multi-workgroup mode: see iterate_kernel)
+  const bool multi = GX && BT == 1 && mw.G > 1;
+  const int tile = multi ? 0 : blockIdx.x;
+  const int tid = multi ? blockIdx.x * blockDim.x + threadIdx.x : threadIdx.x, nthr = multi ? blockDim.x * mw.G : blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int N = a.N;
   double *lds_rest;
   double *xs = solve_vector<BT, GX>(a, smem, tile, lds_rest);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
+  bool df = false;
+  if constexpr (GX && BT == 1 && WIDE) df = a.df != 0;
+  if (df) {
+    if constexpr (GX && BT == 1 && WIDE) {
+      const uint32_t sh = a.df_shadow;
+      for (int i = tid; i < N; i += nthr) {
+        const uint32_t pe = a.pinv[i];
+        st_sc1(xs + pe, rhs[i]);
+        df_arm_fwd(xs, pe, a.rflag[pe], a.xloc[pe], sh);
+      }
+      if (tid == 0) st_sc1(xs + 2 * (size_t)sh, 0.0);
+      wg_or_grid_barrier(mw);
+      kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
+      for (int i = tid; i < N; i += nthr) { const uint32_t pe = a.pinv[i]; sol[i] = ld_sc1(xs + df_bloc(pe, a.rflag[pe], sh)); }
+    }
+    return;
+  }
   for (int bb = 0; bb < BT; bb++) {           // coalesced QP-major I/O
     const int q = tile * BT + bb;
     for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
   }
   __syncthreads();
-  kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane);
+  kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
     if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
@@ -2030,6 +2344,7 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
   } while (0)
 
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
+  if (a.df) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || a.mw_groups < 1) return hipErrorInvalidValue; tiles = a.mw_groups; }
   MI_DISPATCH(iterate_kernel, a);
 }
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
@@ -2041,6 +2356,7 @@ hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size
 }
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                             const double *rhs, double *sol) {
+  if (a.df) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || a.mw_groups < 1) return hipErrorInvalidValue; tiles = a.mw_groups; }
   MI_DISPATCH(kkt_solve_kernel, a, rhs, sol);
 }
 hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,

@@ -182,6 +182,9 @@ struct mi_osqp_batch {
   DevBuf<double> fwd_val, bwd_val, chk_val, dinv, x, z, y, q, l, u, rho_vec, rho_inv, Dsc, Dsc_inv, Esc, Esc_inv;
   DevBuf<double> dx, dy, out1, out2, dscal, x_out, y_out, xs_global;
   bool global_xs = false;
+  int mw_groups = 0, mw_threads = 0;    // > 0: dataflow form of the solves (Analysis::df): mw_groups workgroups of mw_threads threads share the ONE QP of the handle
+  DevBuf<uint32_t> mw_bar;              // their grid barrier: arrival count, generation, error word
+  DevBuf<unsigned char> rflag;
   DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
   DevBuf<int> iscal, qp_of_slot, flag, npos;
   DevBuf<int2> pairs;
@@ -271,7 +274,9 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
-  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = (*h->anp).Next; a.wide = (*h->anp).wide ? 1 : 0;
+  a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = (*h->anp).xs_total; a.wide = (*h->anp).wide ? 1 : 0;
+  a.mw_groups = h->mw_groups; a.mw_bar = h->mw_bar.p;
+  a.df = (*h->anp).df ? 1 : 0; a.df_shadow = (unsigned)(*h->anp).Next; a.rflag = h->rflag.p;
   {
     const DenseTail &dt = (*h->anp).dt;
     a.dt.s = dt.s; a.dt.k = dt.k; a.dt.n_phases = dt.n_phases; a.dt.n_steps = dt.n_steps;
@@ -470,7 +475,7 @@ static int reset_solve_state(mi_osqp_batch *h, bool cold) {
 // by a full comparison) and shared read-only between handles.  MI_OSQP_ANALYSIS_CACHE=0 switches the cache off.
 namespace ancache {
 struct Entry {
-  uint64_t hash; int64_t n, m; int nw, bt, max_extra, dt_max; std::string env;
+  uint64_t hash; int64_t n, m; int nw, bt, max_extra, dt_max, tri_waves; std::string env;
   std::vector<int64_t> Pp, Pi, Ap, Ai;
   std::shared_ptr<const Analysis> an;
 };
@@ -485,7 +490,7 @@ static uint64_t fnv(uint64_t h, const void *p, size_t bytes) {
 }  // namespace ancache
 
 static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap, const int64_t *Ai, int nw,
-                           int bt, int max_extra, int dt_max, std::shared_ptr<const Analysis> &out) {
+                           int bt, int max_extra, int dt_max, int tri_waves, std::shared_ptr<const Analysis> &out) {
   const char *off = getenv("MI_OSQP_ANALYSIS_CACHE");
   const bool use = !(off && atoi(off) == 0) && n > 0 && m >= 0 && Pp && Ap && Pp[0] == 0 && Ap[0] == 0 && Pp[n] >= 0 && Ap[n] >= 0 &&
                    Pp[n] < ((int64_t)1 << 30) && Ap[n] < ((int64_t)1 << 30);
@@ -498,7 +503,7 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
     std::lock_guard<std::mutex> lk(ancache::mu);
     for (size_t i = 0; i < ancache::entries.size(); i++) {
       ancache::Entry &e = ancache::entries[i];
-      if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.env != env) continue;
+      if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.tri_waves != tri_waves || e.env != env) continue;
       if ((int64_t)e.Pi.size() != Pp[n] || (int64_t)e.Ai.size() != Ap[n] || memcmp(e.Pp.data(), Pp, (size_t)(n + 1) * 8) ||
           memcmp(e.Pi.data(), Pi, (size_t)Pp[n] * 8) || memcmp(e.Ap.data(), Ap, (size_t)(n + 1) * 8) || memcmp(e.Ai.data(), Ai, (size_t)Ap[n] * 8)) continue;
       out = e.an;
@@ -507,11 +512,11 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
     }
   }
   auto an = std::make_shared<Analysis>();
-  const int rc = analyze(n, m, Pp, Pi, Ap, Ai, *an, nw, bt, max_extra, dt_max);
+  const int rc = analyze(n, m, Pp, Pi, Ap, Ai, *an, nw, bt, max_extra, dt_max, tri_waves);
   if (rc) return rc;
   out = an;
   if (use) {
-    ancache::Entry e{hsh, n, m, nw, bt, max_extra, dt_max, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, out};
+    ancache::Entry e{hsh, n, m, nw, bt, max_extra, dt_max, tri_waves, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, out};
     std::lock_guard<std::mutex> lk(ancache::mu);
     if (ancache::entries.size() >= ancache::kMaxEntries) ancache::entries.erase(ancache::entries.begin());
     ancache::entries.push_back(std::move(e));
@@ -520,6 +525,16 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
 }
 
 static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
+
+// multi-workgroup mode: a grid barrier that gave up waiting (a workgroup of the grid was not resident) leaves its error
+// word set; the results of that launch are garbage
+static int mw_barrier_ok(mi_osqp_batch *h) {
+  if (h->mw_groups <= 0) return MI_OSQP_OK;
+  uint32_t w[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(w, h->mw_bar.p, sizeof(w), hipMemcpyDeviceToHost));
+  if (w[2]) { g_last_error = "dataflow solve: a wait for a vector entry or a grid barrier timed out"; return MI_OSQP_ERR_DEVICE; }
+  return MI_OSQP_OK;
+}
 
 static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
                             const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai,
@@ -560,7 +575,19 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   const double ta0 = now_s();
   // dense tail (inverted Schur complement of the trailing rows): needs the LDS vector and <= 512 rows (one row per
   // thread of dense_inverse_kernel; k^3 flops per refactorisation)
-  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->anp);
+  // one QP whose vector lives in global memory: the dataflow form of the solves, shared by several workgroups (one CU
+  // cannot issue the scattered 8-byte gathers / read-modify-writes of a 10^5-row factor fast enough, and a barrier per
+  // level costs more than the level: DESIGN.md 7.4).  MI_OSQP_GROUPS = 0: the barrier form, one workgroup.
+  h->mw_groups = 0; h->mw_threads = 0;
+  if (h->global_xs && BT == 1 && B == 1 && h->threads <= 512) {
+    const char *eg = getenv("MI_OSQP_GROUPS"), *ew = getenv("MI_OSQP_GROUP_THREADS");
+    // measured on the 316 x 316 grid of config 5 (scripts/mw_probe.py, ms per iteration): 16 x 512 threads 1.56, 32 x 512 1.23,
+    // 64 x 256 1.06, 128 x 128 1.01, 256 x 128 0.97 (the barrier form in one workgroup: 6.5); 150 x 150 grid: 128 x 128 0.40
+    h->mw_groups = eg ? std::max(0, std::min(256, atoi(eg))) : 128;
+    h->mw_threads = ew ? std::max(64, std::min(512, atoi(ew) / 64 * 64)) : 128;
+    if (h->mw_groups * (h->mw_threads / 64) > 2048) h->mw_groups = 2048 / (h->mw_threads / 64);
+  }
+  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), h->anp);
   const double t_analysis = now_s() - ta0;
   if (rc) return rc;
   const Analysis &an = (*h->anp);
@@ -592,7 +619,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
-  if (h->global_xs) { ALLOC(xs_global, an.Next); }
+  if (h->global_xs) { ALLOC(xs_global, an.xs_total); }
+  if (an.df && ((rc = h->mw_bar.alloc(4)) || (rc = h->mw_bar.zero(h->stream)) || (rc = h->rflag.upload(an.rflag)))) return rc;
   if (an.dt.k) {
     const DenseTail &dt = an.dt;
     ALLOC(dt_val, (size_t)dt.n_steps * 64);
@@ -907,11 +935,13 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
         seg_end = std::min<int64_t>(seg_end, (iter / S.adaptive_rho_interval + 1) * S.adaptive_rho_interval);
       a.iter_begin = iter; a.iter_end = seg_end; a.info_at_end = 1;
       HIPCHK(hipEventRecord(h->ev0, h->stream));
-      HIPCHK(launch_iterate(a, BT, ntl, h->threads, h->lds, h->stream));
+      if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
+      HIPCHK(launch_iterate(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
       HIPCHK(hipEventRecord(h->ev1, h->stream));
       HIPCHK(launch_check(a, BT, ntl, h->threads, h->lds, h->stream));
       HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
+      if ((rc = mw_barrier_ok(h))) return rc;
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
       h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
@@ -1314,9 +1344,10 @@ int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol
   DevGuard guard(h->device);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
-  HIPCHK(launch_kkt_solve(a, h->BT, h->ntiles, h->threads, h->lds, s, d_rhs, d_sol));
+  if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), s));
+  HIPCHK(launch_kkt_solve(a, h->BT, h->ntiles, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, s, d_rhs, d_sol));
   HIPCHK(hipStreamSynchronize(s));
-  return MI_OSQP_OK;
+  return mw_barrier_ok(h);
 }
 
 int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double *d_rhs, double *d_sol, uint32_t *out,
@@ -1488,11 +1519,11 @@ int mi_osqp_debug_host_kkt_solve(int64_t n, int64_t m, const int64_t *Pp, const 
                                  const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l,
                                  const double *u, const mi_osqp_settings *settings, int64_t tile, const double *rhs,
                                  double *sol_schedule, double *sol_direct, mi_osqp_stats *st) {
-  (void)tile;
   Settings s = to_settings(settings);
   if (validate_settings(s)) return MI_OSQP_ERR_INVALID_SETTINGS;
   Analysis an;
-  int rc = analyze(n, m, Pp, Pi, Ap, Ai, an);
+  // tile > 1: the dataflow form for tile - 1 workgroups per QP (global solve vector, no dense tail)
+  int rc = tile > 1 ? analyze(n, m, Pp, Pi, Ap, Ai, an, 8, 1, -1, 0, (int)tile - 1) : analyze(n, m, Pp, Pi, Ap, Ai, an);
   if (rc) return rc;
   QPNumeric Q;
   load_qp(an, s, Pv, nullptr, Av, l, u, Q);
