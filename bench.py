@@ -334,6 +334,14 @@ def secondary(M, PR, torch, with_cpu):
              "N": st["N"], "nnz_L": st["nnz_L"], "phases": [st["fwd_levels"], st["bwd_levels"]], "tile": st["tile"]}
         if O is not None:
             nb = min(Bq, 4 * cores)
+            if Bq == 1:                       # like for like: the same warm start, one thread
+                Pm, Am = PR.qp_matrices(pr, 0)
+                o = O.OracleQPSolver(Pm, None, Am, pr["l"][0], pr["u"][0]); o.set_warm_start(pr["warm"][0])
+                t = time.perf_counter(); o.solve(); t2 = time.perf_counter() - t
+                e["cpu_baseline"] = {"value": 1.0 / t2, "unit": "QPs/s", "cores": 1, "kind": "port", "ms": 1e3 * t2, "iterations": int(o.info().iter),
+                                     "sample": "the same QP, same warm start, oracle solve phase on one thread"}
+                res.append(e); s.close()
+                continue
             rc = O.batch_solve(pr["P"], pr["Px"][:nb], None, pr["A"], pr["Ax"][:nb], pr["l"][:nb], pr["u"][:nb],
                                threads=min(cores, nb), native=True)
             e["cpu_baseline"] = {"value": nb / rc["solve_s"], "unit": "QPs/s", "cores": min(cores, nb), "kind": "port",

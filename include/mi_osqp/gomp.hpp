@@ -167,6 +167,8 @@ class ConstraintBuilder {
  public:
   ConstraintBuilder(size_t waypoints, std::vector<RobotBall> m, std::vector<HorizontalLine> obstacles)
       : W_(waypoints), balls_(std::move(m)), lines_(std::move(obstacles)) {
+    cells_.reserve(N_DIM * W_ * (10 + 3 * balls_.size() * (1 + lines_.size())));
+    lo_.reserve(N_DIM * W_ * (7 + lines_.size() * balls_.size())); up_.reserve(lo_.capacity());
     for (size_t t = 0; t + 1 < W_; ++t)                      // v_t - q_{t+1} + q_t = 0
       for (size_t j = 0; j < N_DIM; ++j) {
         lo_.push_back(-INF); up_.push_back(INF);
@@ -230,6 +232,9 @@ class ConstraintBuilder {
     return *this;
   }
 
+  // sort and de-duplicate the write log now (build() does it on demand): a builder that serves as a template for copies
+  ConstraintBuilder &normalised() { normalise(); return *this; }
+
   QPConstraints build() const {
     QPMatrixSparse A;
     A.rows = (long long)lo_.size(); A.cols = (long long)(2 * N_DIM * W_);
@@ -255,14 +260,42 @@ class ConstraintBuilder {
   struct Cell { size_t col, row; double v; };
   mutable std::vector<Cell> cells_;
   mutable bool sorted_ = true;
-  void set(size_t col, size_t row, double v) { cells_.push_back({col, row, v}); sorted_ = false; }
+  void set(size_t col, size_t row, double v) {
+    if (sorted_ && !cells_.empty()) {          // a write to an existing cell of a normalised builder (a copied template): in place
+      auto it = std::lower_bound(cells_.begin(), cells_.end(), Cell{col, row, 0.0},
+                                 [](const Cell &a, const Cell &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+      if (it != cells_.end() && it->col == col && it->row == row) { it->v = v; return; }
+    }
+    cells_.push_back({col, row, v}); sorted_ = false;
+  }
   void normalise() const {
     if (sorted_) return;
-    std::stable_sort(cells_.begin(), cells_.end(), [](const Cell &a, const Cell &b) { return a.col != b.col ? a.col < b.col : a.row < b.row; });
+    // stable order by (col, row): a counting pass over the columns (2 N_DIM W of them, a handful of cells each), then an
+    // insertion sort inside every column - the write order among equal (col, row) survives both
+    // (scratch kept per thread: the builder runs thousands of times per second in the batched driver, and fresh
+    //  buffers of this size come straight from mmap every time)
+    const size_t ncol = 2 * N_DIM * W_;
+    static thread_local std::vector<size_t> start, at;
+    static thread_local std::vector<Cell> by_col;
+    start.assign(ncol + 1, 0);
+    for (const Cell &c : cells_) { assert(c.col < ncol); start[c.col + 1]++; }
+    for (size_t j = 0; j < ncol; ++j) start[j + 1] += start[j];
+    if (by_col.size() < cells_.size()) by_col.resize(cells_.size());
+    at.assign(start.begin(), start.end() - 1);
+    for (const Cell &c : cells_) by_col[at[c.col]++] = c;
     size_t o = 0;
-    for (size_t k = 0; k < cells_.size(); ++k) {
-      if (k + 1 < cells_.size() && cells_[k + 1].col == cells_[k].col && cells_[k + 1].row == cells_[k].row) continue;   // a later write wins
-      cells_[o++] = cells_[k];
+    for (size_t j = 0; j < ncol; ++j) {
+      Cell *b = by_col.data() + start[j], *e = by_col.data() + start[j + 1];
+      for (Cell *p = b + 1; p < e; ++p) {
+        const Cell c = *p;
+        Cell *q = p;
+        while (q > b && (q - 1)->row > c.row) { *q = *(q - 1); --q; }
+        *q = c;
+      }
+      for (Cell *p = b; p < e; ++p) {
+        if (p + 1 < e && (p + 1)->row == p->row) continue;    // a later write wins
+        cells_[o++] = *p;
+      }
     }
     cells_.resize(o);
     sorted_ = true;
@@ -455,7 +488,12 @@ class BatchGOMPSolver {
       std::vector<ConstraintBuilder<N_DIM>> builders;
       std::vector<QPConstraints> cons(K);
       auto tb_ = clk_::now();
-      builders.assign(K, ConstraintBuilder<N_DIM>{waypoints, mappers, obstacles});
+      // The joint-space rows of a segment differ between the trajectories only in the bounds of the first and the third-last
+      // waypoint: they are laid down once (same calls, same order as initConstraints) and copied; each trajectory then
+      // repeats its two position() calls - in the sequential order they are the last writes to those rows as well - and
+      // adds its own obstacle rows.  Same QPConstraints as initConstraints(), a third of the time.
+      const ConstraintBuilder<N_DIM> tmpl = jointSpaceTemplate(starts[ids[0]], ends[ids[0]], waypoints);
+      builders.assign(K, ConstraintBuilder<N_DIM>{4, {}, {}});
       // the K trajectories are independent: their constraints are built by a few host threads
       parallel_for_(K, [&](size_t k) {
         const QPVector &prev = last_solution[ids[k]];
@@ -464,7 +502,10 @@ class BatchGOMPSolver {
           warm[k][t] = prev[t];
           warm[k][waypoints * N_DIM + t] = prev[waypoints * N_DIM + t];
         }
-        builders[k] = initConstraints(starts[ids[k]], ends[ids[k]], warm[k], waypoints);
+        builders[k] = tmpl;
+        builders[k].position(0, constraints::equal<N_DIM>(starts[ids[k]]))
+            .position(waypoints - 3, constraints::equal<N_DIM>(ends[ids[k]]))
+            .withObstacles(con_3d, warm[k]);
         cons[k] = builders[k].build();
         seg_solution[k] = warm[k];
       });
@@ -555,8 +596,8 @@ class BatchGOMPSolver {
     for (auto &x : th) x.join();
   }
 
-  ConstraintBuilder<N_DIM> initConstraints(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, const QPVector &warm_start,
-                                           size_t waypoints) const {
+  // initConstraints of GOMPSolver ([REF] src/gomp-solver.h:98-110) without its last call (the obstacle rows), normalised
+  ConstraintBuilder<N_DIM> jointSpaceTemplate(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, size_t waypoints) const {
     ConstraintBuilder<N_DIM> b{waypoints, mappers, obstacles};
     b.position(0, constraints::equal<N_DIM>(start_pos))
         .positions(1, waypoints - 2, pos_con)
@@ -565,7 +606,7 @@ class BatchGOMPSolver {
         .velocity(waypoints - 3, constraints::eqZero<N_DIM>())
         .accelerations(0, waypoints - 4, acc_con)
         .acceleration(waypoints - 3, constraints::eqZero<N_DIM>())
-        .withObstacles(con_3d, warm_start);
+        .normalised();
     return b;
   }
 

@@ -16,10 +16,12 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -202,7 +204,8 @@ class BatchQPSolver {
   }
 
   void setWarmStart(const std::vector<QPVector> &xs) {
-    std::vector<double> x;
+    std::vector<double> &x = xbuf_;               // (kept across calls: no fresh pages to fault in on every call)
+    x.clear();
     for (const QPVector &v : xs) x.insert(x.end(), v.begin(), v.end());
     int rc = (long long)x.size() == K_ * n_ ? mi_osqp_batch_warm_start_x(h_, x.data()) : (int)MI_OSQP_ERR_INVALID_DATA;
     assert(rc == MI_OSQP_OK);
@@ -229,18 +232,27 @@ class BatchQPSolver {
   // construction, without analysis, equilibration, upload and factorisation.  false: not applicable, build a new one.
   bool reinit(const std::vector<QPConstraints> &cs, const QPMatrixSparse &P) {
     if (status_ != MI_OSQP_OK || !pristine_ || (long long)cs.size() != K_ || P.outer != P_.outer || P.inner != P_.inner || P.values != P_.values) return false;
-    const size_t nnzA = A_inner_.size();
-    std::vector<double> l, u;
-    l.reserve((size_t)m_ * cs.size()); u.reserve((size_t)m_ * cs.size());
-    for (size_t k = 0; k < cs.size(); k++) {
+    const size_t nnzA = A_inner_.size(), K = cs.size(), m = (size_t)m_;
+    lbuf_.resize(m * K); ubuf_.resize(m * K);     // (kept across calls)
+    // the K comparisons (pattern and values of A: ~20 MB for 256 trajectories) and copies are independent: a few host threads
+    std::atomic<bool> same{true};
+    auto body = [&](size_t k) {
       const auto &[lo, A, up] = cs[k];
-      if (A.rows != m_ || A.cols != n_ || A.outer != A_outer_ || A.inner != A_inner_ || (long long)lo.size() != m_ || (long long)up.size() != m_) return false;
-      if (!std::equal(A.values.begin(), A.values.end(), Av_.begin() + k * nnzA)) return false;
-      l.insert(l.end(), lo.begin(), lo.end());
-      u.insert(u.end(), up.begin(), up.end());
+      if (A.rows != m_ || A.cols != n_ || A.outer != A_outer_ || A.inner != A_inner_ || lo.size() != m || up.size() != m ||
+          A.values.size() != nnzA || !std::equal(A.values.begin(), A.values.end(), Av_.begin() + k * nnzA)) { same = false; return; }
+      std::copy(lo.begin(), lo.end(), lbuf_.begin() + k * m);
+      std::copy(up.begin(), up.end(), ubuf_.begin() + k * m);
+    };
+    const size_t nt = std::min<size_t>({K, 16, std::max(1u, std::thread::hardware_concurrency())});
+    if (nt <= 1) { for (size_t k = 0; k < K; k++) body(k); }
+    else {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < nt; t++) th.emplace_back([&, t] { for (size_t k = t; k < K; k += nt) body(k); });
+      for (auto &x : th) x.join();
     }
+    if (!same) return false;
     if (mi_osqp_batch_reset(h_) != MI_OSQP_OK) return false;
-    return mi_osqp_batch_update_bounds(h_, l.data(), u.data()) == MI_OSQP_OK;
+    return mi_osqp_batch_update_bounds(h_, lbuf_.data(), ubuf_.data()) == MI_OSQP_OK;
   }
 
   int setup_status() const { return status_; }
@@ -255,6 +267,7 @@ class BatchQPSolver {
   QPMatrixSparse P_;
   std::vector<long long> A_outer_, A_inner_;
   std::vector<double> Av_;
+  std::vector<double> lbuf_, ubuf_, xbuf_;
   bool pristine_ = true;            // no update() since construction: the handle's setup snapshot is the post-construction state
 };
 

@@ -446,9 +446,10 @@ class QPSolver:
         return self._b.stats()
 
 
-def debug_host_kkt_solve(P, A, l, u, rhs, **settings):
+def debug_host_kkt_solve(P, A, l, u, rhs, tri_waves=0, **settings):
     """Host-only: factor one QP's KKT and solve K sol = rhs twice -- by replaying
-    the DEVICE schedules sequentially and by a plain CSC solve.  (No GPU.)"""
+    the DEVICE schedules sequentially and by a plain CSC solve.  (No GPU.)
+    tri_waves > 0: the dataflow form of the sweeps for that many waves (large single QPs)."""
     L = lib()
     P, A = _csc(P), _csc(A)
     n, m = A.shape[1], A.shape[0]
@@ -460,7 +461,7 @@ def debug_host_kkt_solve(P, A, l, u, rhs, **settings):
     Ap, Ai, Ax = _i64(A.indptr), _i64(A.indices), _f64(A.data)
     l, u = _f64(l), _f64(u)
     rc = L.mi_osqp_debug_host_kkt_solve(n, m, _ip(Pp), _ip(Pi), _dp(Px), _ip(Ap), _ip(Ai), _dp(Ax), _dp(l), _dp(u),
-                                        C.byref(s), 1, _dp(rhs), _dp(sol_s), _dp(sol_d), C.byref(st))
+                                        C.byref(s), 1 + int(tri_waves), _dp(rhs), _dp(sol_s), _dp(sol_d), C.byref(st))
     _chk(rc, "debug_host_kkt_solve")
     return sol_s, sol_d, st.as_dict()
 

@@ -55,6 +55,29 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// MI_OSQP_DEBUG_TIMING: wall time of the C-ABI calls that sit in the GOMP drivers' loops, summed per entry point and
+// printed when the process exits
+struct CallTimer {
+  struct Slot { const char *name; double s; long calls; };
+  static Slot *slots() { static Slot t[16] = {}; return t; }
+  static bool on() { static const bool v = getenv("MI_OSQP_DEBUG_TIMING") != nullptr; return v; }
+  static void report() {
+    for (Slot *t = slots(); t->name; t++) fprintf(stderr, "[mi_osqp] %-28s %6ld calls %9.3f ms\n", t->name, t->calls, 1e3 * t->s);
+  }
+  const char *name; double t0;
+  explicit CallTimer(const char *n) : name(n), t0(on() ? now_s() : 0.0) {}
+  ~CallTimer() {
+    if (!on()) return;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    Slot *t = slots();
+    static bool registered = false;
+    if (!registered) { atexit(report); registered = true; }
+    while (t->name && t->name != name && t < slots() + 14) t++;
+    t->name = name; t->s += now_s() - t0; t->calls++;
+  }
+};
+
 // cores this process may use: min(hardware threads, cgroup CPU quota); the GPU
 // boxes expose 256 logical CPUs but grant a quota of ~16
 static int host_threads() {
@@ -210,6 +233,8 @@ struct mi_osqp_batch {
   DevBuf<double> stage; DevBuf<int> ids, work;
   int *h_iscal = nullptr;     // pinned
   double *h_dscal = nullptr;  // pinned
+  double *pin = nullptr;      // pinned staging of the host update paths (a pageable hipMemcpy runs at ~1 GB/s here, and unevenly)
+  size_t pin_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evf0 = nullptr, evf1 = nullptr, evf2 = nullptr;
   double factor_ms_sum = 0.0, dense_ms_sum = 0.0;
   int64_t refactor_launches = 0, refactor_qps = 0, peak_qps = 0;
@@ -229,6 +254,7 @@ struct mi_osqp_batch {
     DevGuard guard(device);
     if (h_iscal) (void)hipHostFree(h_iscal);
     if (h_dscal) (void)hipHostFree(h_dscal);
+    if (pin) (void)hipHostFree(pin);
     if (h_npos) (void)hipHostFree(h_npos);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -316,6 +342,21 @@ static int ensure_stage(mi_osqp_batch *h, size_t doubles, size_t ints) {
   if (h->stage.n < doubles && (rc = h->stage.alloc(doubles))) return rc;
   if (h->ids.n < ints && (rc = h->ids.alloc(ints))) return rc;
   return 0;
+}
+
+static int ensure_pin(mi_osqp_batch *h, size_t doubles) {
+  if (h->pin_n >= doubles) return 0;
+  if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; h->pin_n = 0; }
+  HIPCHK(hipHostMalloc((void **)&h->pin, doubles * sizeof(double)));
+  h->pin_n = doubles;
+  return 0;
+}
+// memcpy on the host threads (user arrays of several MB per call in the GOMP drivers' loops)
+static void par_copy(double *dst, const double *src, size_t n) {
+  const size_t chunk = (size_t)1 << 17;       // 1 MiB
+  const int parts = (int)((n + chunk - 1) / chunk);
+  if (parts <= 2) { memcpy(dst, src, n * sizeof(double)); return; }
+  parallel_for(parts, [&](int i, int) { const size_t b = (size_t)i * chunk; memcpy(dst + b, src + b, std::min(chunk, n - b) * sizeof(double)); });
 }
 
 // upload QP-major host rows [nq][len] into a tile-interleaved device array
@@ -704,6 +745,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
   HIPCHK(hipHostMalloc((void **)&h->h_iscal, (size_t)IS_COUNT * T * sizeof(int)));
   HIPCHK(hipHostMalloc((void **)&h->h_dscal, (size_t)DS_COUNT * T * sizeof(double)));
+  if ((rc = ensure_pin(h, std::max((size_t)2 * B * m, (size_t)B * n)))) return rc;      // (host update paths: bounds, warm starts)
   HIPCHK(hipStreamSynchronize(h->stream));
   double t1 = now_s();
   // ---- per-QP numeric (host threads), uploaded in chunks to bound host memory
@@ -1078,6 +1120,7 @@ static int64_t exit_code_of(int status) {
 int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
                         const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai, const double *Av,
                         const double *l, const double *u, const mi_osqp_settings *settings, int64_t device) {
+  CallTimer timer_("batch_setup");
   if (!out) return MI_OSQP_ERR_NULL;
   *out = nullptr;
   if (n <= 0 || m < 0) return MI_OSQP_ERR_INVALID_DATA;
@@ -1094,6 +1137,7 @@ void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }
 void mi_osqp_release_device_cache(void) { devpool::release_all(); }
 
 int mi_osqp_batch_solve(mi_osqp_batch *h) {
+  CallTimer timer_("batch_solve");
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   return solve_impl(h, nullptr, nullptr);
@@ -1114,6 +1158,7 @@ int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_sta
 }
 
 int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x) {
+  CallTimer timer_("batch_get_primal");
   if (!h || !x) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   HIPCHK(hipMemcpy(x, h->x_out.p, (size_t)h->B * (*h->anp).n * sizeof(double), hipMemcpyDeviceToHost));
@@ -1127,6 +1172,7 @@ int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y) {
 }
 
 int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info) {
+  CallTimer timer_("batch_get_info");
   if (!h || !info) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
@@ -1191,6 +1237,7 @@ int mi_osqp_batch_refactor_peak(mi_osqp_batch *h, int64_t *qps, double *factor_m
 }
 
 int mi_osqp_batch_reset(mi_osqp_batch *h) {
+  CallTimer timer_("batch_reset");
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   h->clear_rho_updates = true;
@@ -1210,22 +1257,40 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
 }
 
 int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
+  CallTimer timer_("batch_warm_start_x");
   if (!h || !x) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   h->st.warm_start = 1;
   size_t cnt = (size_t)h->B * (*h->anp).n;
-  int rc = ensure_stage(h, cnt, 0);
-  if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(h->stage.p, x, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc;
+  if ((rc = ensure_stage(h, cnt, 0)) || (rc = ensure_pin(h, cnt))) return rc;
+  par_copy(h->pin, x, cnt);
+  HIPCHK(hipMemcpyAsync(h->stage.p, h->pin, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   KernelArgs a = make_args(h);
   HIPCHK(launch_warm_start(a, h->BT, h->ntiles, h->threads, h->lds, h->stream, h->stage.p));
   HIPCHK(hipStreamSynchronize(h->stream));
   return MI_OSQP_OK;
 }
 
+static int update_bounds_on_host(mi_osqp_batch *h, const double *l, const double *u);
+static int update_bounds_on_device(mi_osqp_batch *h, const double *d_l, const double *d_u, hipStream_t s, const double *h_l, const double *h_u);
+
 int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u) {
+  CallTimer timer_("batch_update_bounds");
   if (!h || !l || !u) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  // through pinned memory to the device, where the rows are scaled and checked (bounds_kernel); only when a row changes
+  // its type (equality / inequality / free: new rho vector, new factor) the host mirrors take over
+  const size_t cnt = (size_t)h->B * (*h->anp).m;
+  if (!cnt) return MI_OSQP_OK;
+  int rc;
+  if ((rc = ensure_stage(h, 2 * cnt, 0)) || (rc = ensure_pin(h, 2 * cnt))) return rc;
+  par_copy(h->pin, l, cnt); par_copy(h->pin + cnt, u, cnt);
+  HIPCHK(hipMemcpyAsync(h->stage.p, h->pin, 2 * cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return update_bounds_on_device(h, h->stage.p, h->stage.p + cnt, h->stream, l, u);
+}
+
+static int update_bounds_on_host(mi_osqp_batch *h, const double *l, const double *u) {
   h->clear_rho_updates = true;
   const Analysis &an = (*h->anp);
   int m = an.m, B = h->B, rc;
@@ -1252,8 +1317,12 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
 int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream) {
   if (!h || !d_l || !d_u) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  return update_bounds_on_device(h, d_l, d_u, stream ? (hipStream_t)stream : h->stream, nullptr, nullptr);
+}
+
+// (h_l / h_u: the same bounds on the host when the caller has them, else they are fetched if the host path is needed)
+static int update_bounds_on_device(mi_osqp_batch *h, const double *d_l, const double *d_u, hipStream_t s, const double *h_l, const double *h_u) {
   h->clear_rho_updates = true;
-  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   int m = (*h->anp).m, B = h->B;
   if (!m) return MI_OSQP_OK;
   // pass 1: validate + detect constraint-type changes without writing
@@ -1265,10 +1334,11 @@ int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, cons
   HIPCHK(hipStreamSynchronize(s));
   if (flag & 2) return MI_OSQP_ERR_INVALID_DATA;
   if (flag & 1) {   // a row changed type -> needs the refactor path: go through the host
+    if (h_l && h_u) return update_bounds_on_host(h, h_l, h_u);
     std::vector<double> hl((size_t)B * m), hu((size_t)B * m);
     HIPCHK(hipMemcpy(hl.data(), d_l, hl.size() * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hu.data(), d_u, hu.size() * sizeof(double), hipMemcpyDeviceToHost));
-    return mi_osqp_batch_update_bounds(h, hl.data(), hu.data());
+    return update_bounds_on_host(h, hl.data(), hu.data());
   }
   HIPCHK(launch_bounds(d_l, d_u, h->l.p, h->u.p, h->Esc.p, h->rho_vec.p, h->dscal.p, h->flag.p, B, m, h->BT,
                        h->st.scaling ? 1 : 0, s));
@@ -1278,6 +1348,7 @@ int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, cons
 }
 
 int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
+  CallTimer timer_("batch_update_A");
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   h->clear_rho_updates = true;

@@ -369,6 +369,45 @@ def test_wide_index_words_beyond_the_16_bit_range():
     assert np.max(np.abs(d_sol.cpu().numpy()[0] - ko)) <= 1e-9 * np.max(np.abs(ko))
 
 
+@pytest.mark.parametrize("shape", ["0", "1:64", "3:192", "16:512", "256:128"])
+def test_single_large_qp_group_shapes_agree(shape, monkeypatch):
+    """One QP with a global solve vector runs the dataflow form of the sweeps (no barrier inside a sweep, consumers poll
+    for the entries) on MI_OSQP_GROUPS workgroups of MI_OSQP_GROUP_THREADS threads; 0 = the barrier form in one workgroup.
+    Whatever the shape: oracle parity (same iteration count, x to 1e-6) and the KKT-solve op against the oracle's."""
+    import torch
+    monkeypatch.setenv("MI_OSQP_GROUPS", shape.split(":")[0])
+    if ":" in shape: monkeypatch.setenv("MI_OSQP_GROUP_THREADS", shape.split(":")[1])
+    pr = PR.grid_qp(90)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    st = s.stats()
+    assert st["N"] == 8100 + 8100 + 2 * 90 * 89 and st["tile"] == 1
+    info = s.solve()
+    ref = _oracle_batch(pr, [0])
+    _compare(info, s.primal(), ref, [0])
+    x1 = s.primal().copy()
+    rhs = np.random.default_rng(2).standard_normal((1, st["N"]))
+    d_rhs = torch.tensor(rhs, device="cuda"); d_sol = torch.empty_like(d_rhs)
+    for _ in range(3):                          # (the vector is re-armed by every call)
+        s.kkt_solve_device(d_rhs, d_sol)
+        ko = ref[0][3].kkt_solve(rhs[0])
+        assert np.max(np.abs(d_sol.cpu().numpy()[0] - ko)) <= 1e-9 * np.max(np.abs(ko))
+    # a second solve on the same handle (warm: continues from the first solution) and a fresh one after reset()
+    info2 = s.solve()
+    assert info2[0].exit_code == 0 and info2[0].iter <= info[0].iter
+    s.reset()
+    info3 = s.solve()
+    assert info3[0].iter == info[0].iter and np.array_equal(s.primal(), x1)      # (no timing-dependent arithmetic: bitwise)
+
+
+def test_dataflow_form_on_a_small_qp_with_mostly_idle_waves(monkeypatch):
+    """A small QP forced into the global-vector mode: 256 waves for a 160-row factor, most streams empty."""
+    monkeypatch.setenv("MI_OSQP_GLOBAL_XS", "1")
+    pr = PR.random_box_qp(1, n=96, mg=64, nnz_per_row=6)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    info = s.solve()
+    _compare(info, s.primal(), _oracle_batch(pr, [0]), [0])
+
+
 def test_config5_literal_size_solves():
     """BASELINE config 5 at its literal size: n = 99 856, m = 298 936 (316 x 316 grid), N = 398 792, nnz(L) = 3.3 M.
     The oracle needs minutes here, so the check is size-independent: OSQP's own termination inequalities and the

@@ -52,6 +52,30 @@ def test_schedule_replay_matches_direct_and_oracle(case, scaling):
         assert st["fwd_slots"] + st["bwd_slots"] + st["dense_tail_slots"] < 2 * st["nnz_L"]
 
 
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+@pytest.mark.parametrize("waves", [1, 3, 16, 256])
+def test_dataflow_form_of_the_sweeps_replays(case, waves):
+    """The barrier-free schedule form of the large single QPs (host_core.hpp Analysis::df): the host replay advances
+    the waves round robin, a step waits while one of its gathers is still to be written; it fails on a deadlock, on an
+    entry written twice, on an armed entry nobody writes and on a subtracting flush whose old value the sweep writes."""
+    name, P, A, l, u = case
+    n, m = A.shape[1], A.shape[0]
+    rhs = np.random.default_rng(6).standard_normal(n + m)
+    s_sched, s_direct, st = M.debug_host_kkt_solve(P, A, l, u, rhs, tri_waves=waves)
+    assert np.max(np.abs(s_sched - s_direct)) <= 1e-8 * np.max(np.abs(s_direct)), name
+    assert st["dense_tail_rows"] == 0
+
+
+def test_dataflow_form_on_a_grid_with_deep_elimination_tree():
+    pr = PR.grid_qp(40)
+    P, A = PR.qp_matrices(pr, 0)
+    rhs = np.random.default_rng(7).standard_normal(pr["n"] + pr["m"])
+    s_sched, s_direct, st = M.debug_host_kkt_solve(P, A, pr["l"][0], pr["u"][0], rhs, tri_waves=64)
+    assert np.max(np.abs(s_sched - s_direct)) <= 1e-9 * np.max(np.abs(s_direct))
+    s8, _, st8 = M.debug_host_kkt_solve(P, A, pr["l"][0], pr["u"][0], rhs)
+    assert st["fwd_levels"] >= 20 and np.max(np.abs(s8 - s_sched)) <= 1e-9 * np.max(np.abs(s_direct))
+
+
 def test_nonconvex_is_refused():
     P = sp.csc_matrix(-np.eye(3)); A = sp.eye(3).tocsc()
     with pytest.raises(M.MiOsqpError) as e:
