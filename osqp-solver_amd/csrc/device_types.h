@@ -57,6 +57,7 @@ struct KernelArgs {
   // vector steps; mw_bar = {arrival count, generation, error flag} of their grid barrier (zero between launches)
   int mw_groups;
   unsigned *mw_bar;
+  double *mw_scratch;                   // [8 slots][256 workgroups][16]: partial norms / sums of check_kernel
   // dataflow form of the triangular solves (Analysis::df; always with the wide index words and one QP): shadow offset of the
   // in-place results, flags per permuted row (bit 0 forward A step, bit 1 backward A step, bit 2 multi-row chunk)
   int df;

@@ -1108,7 +1108,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   }
   if (tri_waves > 0 && (bt != 1 || an.dt.k)) return MI_OSQP_ERR_INVALID_SETTINGS;
   build_tri_schedules(an, tri_waves > 0 ? tri_waves : nwaves, bt, tri_waves > 0);
-  build_chk_schedule(an, nwaves, bt);
+  build_chk_schedule(an, tri_waves > 0 ? tri_waves : nwaves, bt);      // (dataflow form: check_kernel runs on the whole grid too)
   build_dense_tail(an, nwaves);
   build_block_factor(an);
   // A wave that passes fewer barriers than the others would hang its workgroup (and the GPU): re-count.

@@ -221,8 +221,9 @@ struct Analysis {
 // is also limited by the index range.
 // `dense_tail_max` = largest dense tail (rows) the caller can serve, 0 = never use one.
 // `tri_waves` > 0 = the dataflow form of the triangular solves (Analysis::df: ONE QP, solve vector in global memory, no
-// dense tail): the forward / backward step streams are laid out for that many waves (of any number of workgroups); the
-// check schedule stays at nwaves.  0 = the barrier form (one workgroup of nwaves waves per tile).
+// dense tail): the forward / backward step streams and the check schedule are laid out for that many waves (of any number
+// of workgroups; a kernel with fewer waves walks the barrier-free check streams one after the other).  0 = the barrier form
+// (one workgroup of nwaves waves per tile).
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
             const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1,
             int dense_tail_max = 512, int tri_waves = 0);

@@ -544,10 +544,15 @@ __device__ __forceinline__ void run_tri(const SchedDev &s, const ValSrc<BT> &val
 // SpMV with the same streams: levels [l0, l1) of the check schedule (independent rows, no barriers)
 template <int BT, int PF, bool WIDE = false>
 __device__ __forceinline__ void run_spmv(const SchedDev &s, const ValSrc<BT> &vals, double *xs, double *out, int wave,
-                                         int lane, int l0, int l1) {
+                                         int lane, int l0, int l1, int nwaves_here = 0) {
+  // the rows are independent (no barriers): a schedule laid out for more waves than are here (the single large QPs,
+  // whose check schedule is built for the whole grid) is walked stream by stream; normally one trip
   mi_cptr lp = as_const(s.lvl_pos);
-  const uint32_t begin = lp[(size_t)l0 * s.nw + wave], end = lp[(size_t)l1 * s.nw + wave];
-  run_stream<BT, PF, false, false, false, 0, WIDE>(vals, begin, end, 0u, xs, out, lane);
+  const int step = nwaves_here > 0 ? nwaves_here : (int)s.nw;
+  for (int vw = wave; vw < (int)s.nw; vw += step) {
+    const uint32_t begin = lp[(size_t)l0 * s.nw + vw], end = lp[(size_t)l1 * s.nw + vw];
+    run_stream<BT, PF, false, false, false, 0, WIDE>(vals, begin, end, 0u, xs, out, lane);
+  }
 }
 
 // --------------------------------------------------------- block reductions
@@ -582,6 +587,32 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double *red, int ti
 #pragma unroll
   for (int k = 0; k < K; k++) v[k] = res[k * BT + (tid % BT)];
   __syncthreads();
+}
+
+// One QP shared by mw.G workgroups (check_kernel of the single large QPs): every workgroup publishes its block result,
+// all meet at a grid barrier, and every workgroup combines the G partial results in the same order - all of them hold the
+// same numbers afterwards, so the control flow that follows stays uniform over the grid.  (max of non-negative numbers / sums)
+template <int K, bool IS_MAX>
+__device__ __forceinline__ void grid_reduce(double (&v)[K], double *red, const Mw &mw, double *scratch, int ltid, int lwave, int lnw, int lane) {
+  if (mw.G <= 1) return;
+  if (ltid == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) __hip_atomic_store(scratch + (size_t)blockIdx.x * 16 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  grid_barrier(mw);
+  double w[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) w[k] = 0.0;
+  for (unsigned g = (unsigned)ltid; g < mw.G; g += blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const double o = __hip_atomic_load(scratch + (size_t)g * 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w[k] = IS_MAX ? fmax(w[k], o) : w[k] + o;
+    }
+  }
+  block_reduce<1, K, IS_MAX>(w, red, ltid, lwave, lnw, lane);
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = w[k];
 }
 
 // ------------------------------------------------------------ the ADMM kernel
@@ -929,9 +960,19 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
 template <int BT, int NT, bool GX, bool WIDE = false>
 __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   extern __shared__ double smem[];
-  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  // one QP shared by the grid (single large QPs, see iterate_kernel): tid / nthr / wave run over the grid, ltid / lwave /
+  // lnw over the workgroup (block reductions); barriers between phases that exchange data are grid barriers and every
+  // block reduction is followed by a reduction over the workgroups
+  bool dfm = false;
+  if constexpr (GX && BT == 1 && WIDE) dfm = a.df != 0 && a.mw_groups > 1;
+  const Mw mw{a.mw_bar, dfm ? (unsigned)a.mw_groups : 1u};
+  const int tile = dfm ? 0 : blockIdx.x;
+  const int ltid = threadIdx.x, lwave = __builtin_amdgcn_readfirstlane(ltid >> 6), lnw = blockDim.x >> 6;
+  const int tid = dfm ? blockIdx.x * blockDim.x + threadIdx.x : threadIdx.x, nthr = dfm ? blockDim.x * mw.G : blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
   const int b = tid % BT;
+  auto sync = [&]() { if constexpr (GX && BT == 1 && WIDE) wg_or_grid_barrier(mw); else __syncthreads(); };
+  auto gscratch = [&](int slot) { return a.mw_scratch + (size_t)slot * 256 * 16; };
   const int n = a.n, m = a.m;
   double *red;
   double *xs = solve_vector<BT, GX>(a, smem, tile, red);
@@ -954,9 +995,9 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   // ---- E11: [x;y] -> LDS, P x / A' y / A x
   for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = p.y[e];
-  __syncthreads();
-  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3);
-  __syncthreads();
+  sync();
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 0, 3, nw);
+  sync();
   // residual vectors and the norms termination + rho estimate need
   double mx[14];
 #pragma unroll
@@ -979,8 +1020,12 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
     mx[10] = fmax(mx[10], fabs(zv));      mx[11] = fmax(mx[11], fabs(ax));
     mx[12] = fmax(mx[12], fabs(ei * zv)); mx[13] = fmax(mx[13], fabs(ei * ax));
   }
-  block_reduce<BT, 14, true>(mx, red, tid, wave, nw, lane);
-  block_reduce<BT, 1, false>(sm, red, tid, wave, nw, lane);
+  block_reduce<BT, 14, true>(mx, red, ltid, lwave, lnw, lane);
+  block_reduce<BT, 1, false>(sm, red, ltid, lwave, lnw, lane);
+  if constexpr (GX && BT == 1 && WIDE) {
+    grid_reduce<14, true>(mx, red, mw, gscratch(0), ltid, lwave, lnw, lane);
+    grid_reduce<1, false>(sm, red, mw, gscratch(1), ltid, lwave, lnw, lane);
+  }
   const double pri_res = (m == 0) ? 0.0 : (unscale ? mx[9] : mx[8]);
   const double dua_res = unscale ? cinv * mx[1] : mx[0];
   double obj = sm[0];
@@ -1008,17 +1053,21 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
     mi[0] = fmax(mi[0], unscale ? fabs(p.Esc[e] * d) : fabs(d));
     si[0] += up * fmax(d, 0.0) + lo * fmin(d, 0.0);
   }
-  __syncthreads();
-  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3);
-  __syncthreads();
+  sync();
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out2, wave, lane, 0, 3, nw);
+  sync();
   for (int e = tid; e < n * BT; e += nthr) {
     const double pdx = p.out2[e], atdy = p.out2[(size_t)n * BT + e];
     const double di = unscale ? p.Dsc_inv[e] : 1.0;
     mi[2] = fmax(mi[2], fabs(di * atdy));
     mi[3] = fmax(mi[3], fabs(di * pdx));
   }
-  block_reduce<BT, 4, true>(mi, red, tid, wave, nw, lane);
-  block_reduce<BT, 2, false>(si, red, tid, wave, nw, lane);
+  block_reduce<BT, 4, true>(mi, red, ltid, lwave, lnw, lane);
+  block_reduce<BT, 2, false>(si, red, ltid, lwave, lnw, lane);
+  if constexpr (GX && BT == 1 && WIDE) {
+    grid_reduce<4, true>(mi, red, mw, gscratch(2), ltid, lwave, lnw, lane);
+    grid_reduce<2, false>(si, red, mw, gscratch(3), ltid, lwave, lnw, lane);
+  }
   const double norm_dy = mi[0], norm_dx = mi[1];
   const double cost_scaling = unscale ? c : 1.0;
 
@@ -1036,7 +1085,8 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
       if ((up < MI_INFTY * MI_MIN_SCALING && adx > eps_dinf * norm_dx) ||
           (lo > -MI_INFTY * MI_MIN_SCALING && adx < -eps_dinf * norm_dx)) viol[0] = 1.0;
     }
-    block_reduce<BT, 1, true>(viol, red, tid, wave, nw, lane);
+    block_reduce<BT, 1, true>(viol, red, ltid, lwave, lnw, lane);
+    if constexpr (GX && BT == 1 && WIDE) grid_reduce<1, true>(viol, red, mw, gscratch(approx ? 5 : 4), ltid, lwave, lnw, lane);
     if (pri_res > MI_INFTY || dua_res > MI_INFTY) return -7;   // non-convex / diverged
     int prim_ok = 0, dual_ok = 0, prim_inf = 0, dual_inf = 0;
     if (m == 0) prim_ok = 1;
@@ -1098,7 +1148,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   if (tid < BT) p.dscal[DS_RHO_EST * BT + b] = rho_est;
   // outputs for QPs that finished in this pass (done is uniform per class b)
   const int just_done = done && (p.iscal[IS_DONE * BT + b] == 0);
-  __syncthreads();
+  sync();
   if (just_done && qp >= 0) {
     const bool has_sol = !(status == -3 || status == 3 || status == -4 || status == 4 || status == -7);
     const double nanv = __builtin_nan("");
@@ -1113,7 +1163,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
       if (!has_sol) { p.y[e] = 0.0; p.z[e] = 0.0; }
     }
   }
-  __syncthreads();
+  sync();
   if (tid < BT) {
     p.iscal[IS_DONE * BT + b] = done; p.iscal[IS_STATUS * BT + b] = status;
     p.iscal[IS_RHO_UPDATES * BT + b] = rho_updates;
@@ -1147,7 +1197,7 @@ __global__ __launch_bounds__(NT) void spmv_kernel(KernelArgs a, const double *__
     for (int i = tid; i < m; i += nthr) xs[((size_t)n + i) * BT + bb] = (ok && gy) ? gy[(size_t)q * m + i] : 0.0;
   }
   __syncthreads();
-  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, res, wave, lane, 0, 3);
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, res, wave, lane, 0, 3, (int)(blockDim.x >> 6));
   __syncthreads();
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
@@ -1408,7 +1458,7 @@ __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const doub
   }
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
   __syncthreads();
-  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3);
+  run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3, (int)(blockDim.x >> 6));
   __syncthreads();
   for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
@@ -2348,6 +2398,7 @@ hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, s
   MI_DISPATCH(iterate_kernel, a);
 }
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
+  if (a.df && a.mw_groups > 1) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || !a.mw_scratch) return hipErrorInvalidValue; tiles = a.mw_groups; }
   MI_DISPATCH(check_kernel, a);
 }
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,

@@ -208,6 +208,7 @@ struct mi_osqp_batch {
   int mw_groups = 0, mw_threads = 0;    // > 0: dataflow form of the solves (Analysis::df): mw_groups workgroups of mw_threads threads share the ONE QP of the handle
   DevBuf<uint32_t> mw_bar;              // their grid barrier: arrival count, generation, error word
   DevBuf<unsigned char> rflag;
+  DevBuf<double> mw_scratch;            // partial norms / sums of the grid-wide check_kernel
   DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
   DevBuf<int> iscal, qp_of_slot, flag, npos;
   DevBuf<int2> pairs;
@@ -301,7 +302,7 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.dscal = h->dscal.p; a.iscal = h->iscal.p; a.qp_of_slot = h->qp_of_slot.p;
   a.x_out = h->x_out.p; a.y_out = h->y_out.p;
   a.xs_global = h->global_xs ? h->xs_global.p : nullptr; a.xs_len = (*h->anp).xs_total; a.wide = (*h->anp).wide ? 1 : 0;
-  a.mw_groups = h->mw_groups; a.mw_bar = h->mw_bar.p;
+  a.mw_groups = h->mw_groups; a.mw_bar = h->mw_bar.p; a.mw_scratch = h->mw_scratch.p;
   a.df = (*h->anp).df ? 1 : 0; a.df_shadow = (unsigned)(*h->anp).Next; a.rflag = h->rflag.p;
   {
     const DenseTail &dt = (*h->anp).dt;
@@ -661,7 +662,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
   if (h->global_xs) { ALLOC(xs_global, an.xs_total); }
-  if (an.df && ((rc = h->mw_bar.alloc(4)) || (rc = h->mw_bar.zero(h->stream)) || (rc = h->rflag.upload(an.rflag)))) return rc;
+  if (an.df && ((rc = h->mw_bar.alloc(4)) || (rc = h->mw_bar.zero(h->stream)) || (rc = h->rflag.upload(an.rflag)) ||
+                (rc = h->mw_scratch.alloc((size_t)8 * 256 * 16)) || (rc = h->mw_scratch.zero(h->stream)))) return rc;
   if (an.dt.k) {
     const DenseTail &dt = an.dt;
     ALLOC(dt_val, (size_t)dt.n_steps * 64);
@@ -980,7 +982,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
       if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
       HIPCHK(launch_iterate(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
       HIPCHK(hipEventRecord(h->ev1, h->stream));
-      HIPCHK(launch_check(a, BT, ntl, h->threads, h->lds, h->stream));
+      HIPCHK(launch_check(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
       HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       if ((rc = mw_barrier_ok(h))) return rc;
