@@ -86,6 +86,7 @@ class QPSolver {
                          A.values.data(), l.data(), u.data(), &s);
     status_ = rc;
     verbose_ = verbose;
+    if (rc != MI_OSQP_OK) std::cerr << "QPSolver: setup failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl;
     assert(rc == MI_OSQP_OK);                                              // [REF] :30 (assert only)
     n_ = A.cols;
   }
@@ -113,7 +114,10 @@ class QPSolver {
     mi_osqp_info info{};
     QPVector x(n_);
     int rc = mi_osqp_solve(h_, &info);
-    if (rc != MI_OSQP_OK) return {OsqpExitCode::kUnknown, x};
+    if (rc != MI_OSQP_OK) {
+      std::cerr << "QPSolver: solve failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl;
+      return {OsqpExitCode::kUnknown, x};
+    }
     mi_osqp_get_primal(h_, x.data());
     last_ = info;
     return {static_cast<OsqpExitCode>(info.exit_code), x};

@@ -2394,6 +2394,7 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
   } while (0)
 
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
+  if (getenv("MI_OSQP_DEBUG_HIP")) fprintf(stderr, "[mi_osqp] launch_iterate: df %d wide %d xs_global %p BT %d tiles %d threads %d lds %zu groups %d bar %p\n", a.df, a.wide, (void *)a.xs_global, BT, tiles, threads, lds, a.mw_groups, (void *)a.mw_bar);
   if (a.df) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || a.mw_groups < 1) return hipErrorInvalidValue; tiles = a.mw_groups; }
   MI_DISPATCH(iterate_kernel, a);
 }
@@ -2414,7 +2415,7 @@ hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads,
                             const double *rhs, double *sol, uint32_t *trace, uint32_t words) {
   if (BT != 2 || a.xs_global || threads != 512) return hipErrorInvalidValue;
   const size_t total = ((size_t)a.xs_len + 2 * (size_t)a.dt.k) * BT * sizeof(double) + (size_t)words * 4;
-  if (total > 160 * 1024) return hipErrorInvalidValue;
+  if (total > 160 * 1024 - 512) return hipErrorInvalidValue;
   (void)lds;
 #ifdef MI_OSQP_DEBUG_BUILD
   const bool waits = getenv("MI_OSQP_TRACE_WAITS") != nullptr;     // per-step ring-wait timing (slows every step down)

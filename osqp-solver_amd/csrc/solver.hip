@@ -32,6 +32,10 @@ static thread_local std::string g_last_error;
 
 #define HIPCHK(expr)                                                                     \
   do {                                                                                   \
+    if (getenv("MI_OSQP_DEBUG_HIP")) {                                                   \
+      hipError_t _s = hipGetLastError();                                                 \
+      if (_s != hipSuccess) fprintf(stderr, "[mi_osqp] stale HIP error before %s (%s:%d): %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(_s)); \
+    }                                                                                    \
     hipError_t _e = (expr);                                                              \
     if (_e != hipSuccess) {                                                              \
       g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
@@ -603,7 +607,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   // memory, one QP per tile, 512 threads (the only instantiation of the wide kernels)
   const bool wide = n + m >= 65535 || 2 * n + m >= 65535;
   if (wide) { BT = 1; h->threads = std::min(h->threads, 512); }
-  const size_t lds_cap = 160 * 1024;
+  const size_t lds_cap = 160 * 1024 - 1024;      // (the kernels carry up to 272 B of static LDS of their own: a vector that fills
+                                                 //  the 160 KB to the last byte - extra rows are handed out until it does - cannot launch)
   while (BT > 1 && lds_bytes((int)(n + m), BT, h->threads) > lds_cap) BT /= 2;
   // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
   h->global_xs = wide || lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
@@ -1405,7 +1410,7 @@ int mi_osqp_batch_spmv(mi_osqp_batch *h, const double *d_x, const double *d_y, d
     return MI_OSQP_OK;
   }
   size_t lds = (size_t)((*h->anp).Next + 2 * (*h->anp).n + (*h->anp).m) * h->BT * sizeof(double);
-  a.op_out_lds = !h->global_xs && lds <= 160 * 1024;
+  a.op_out_lds = !h->global_xs && lds <= 160 * 1024 - 1024;
   if (!a.op_out_lds) lds = h->lds;
   HIPCHK(launch_spmv(a, h->BT, h->ntiles, h->threads, lds, s, d_x, d_y, d_Px, d_Aty, d_Ax));
   HIPCHK(hipStreamSynchronize(s));

@@ -367,7 +367,46 @@ static int run_ur5e(int W) {
   std::printf(fails ? "UR5E FAILED (%d)\n" : "UR5E OK\n", fails);
   return fails ? 1 : 0;
 }
+// The reference's example program ([REF] examples/solver-example.cpp:12-16,44-70: UR5e, joint 1 by pi, two balls, y >= -0.4)
+// as its sequential driver runs it - one trajectory, one QP at a time - on the GPU QPSolver and on the oracle backend
+// (one CPU thread): wall time of run() and the difference of the trajectories.   gomp_parity example [waypoints]
+template <class S>
+static std::pair<ExitCode, QPVector> run_example_once(int W, int obst, double &seconds, int (&c)[3]) {
+  const double pi = 3.14159265358979323846;
+  std::vector<RobotBall> balls{RobotBall(&forward_kinematics_6_back, &joint_jacobian_6_back, 0.15, false),
+                               RobotBall(&forward_kinematics, &joint_jacobian, 0.05, true)};
+  std::vector<HorizontalLine> lines;
+  if (obst) lines.push_back(HorizontalLine({0, 1}, {0.3, 0, 0.35}, false));
+  GOMPSolver<6, S> g(W, 0.1, constraints::inRange<6>(constraints::of<6>(-2 * pi), constraints::of<6>(2 * pi)),
+                     constraints::inRange<6>(constraints::of<6>(-pi), constraints::of<6>(pi)),
+                     constraints::inRange<6>(constraints::of<6>(-pi * 800 / 180), constraints::of<6>(pi * 800 / 180)),
+                     constraints::inRange<3>(Vec<3>{-INF, -0.4, -INF}, Vec<3>{INF, INF, INF}), lines, balls, &inverse_kinematics, false);
+  auto t0 = std::chrono::steady_clock::now();
+  auto r = g.run({0, 0, 0, 0, 0, 0}, {pi, 0, 0, 0, 0, 0});
+  seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  c[0] = g.segments_run; c[1] = g.qp_solves; c[2] = g.qp_updates;
+  return r;
+}
+static int run_example(int W) {
+  { double t; int c[3]; (void)run_example_once<QPSolver>(40, 0, t, c); }        // HIP context, code objects
+  for (int obst = 0; obst < 2; ++obst) {
+    double tg = 0, tg2 = 0, to = 0; int cg[3], co[3];
+    auto [cg_code, xg] = run_example_once<QPSolver>(W, obst, tg, cg);
+    auto [cg2_code, xg2] = run_example_once<QPSolver>(W, obst, tg2, cg);         // pattern analyses cached, device buffers pooled
+    auto [co_code, xo] = run_example_once<OracleQPSolver>(W, obst, to, co);
+    double md = 0.0;
+    CHECK(xg.size() == xo.size());
+    for (size_t k = 0; k < std::min(xg.size(), xo.size()); ++k) md = std::fmax(md, std::fabs(xg[k] - xo[k]));
+    CHECK(cg_code == co_code && cg2_code == co_code); CHECK(cg[0] == co[0] && cg[1] == co[1] && cg[2] == co[2]); CHECK(md < 1e-6); CHECK(xg2 == xg);
+    std::printf("example W=%d obstacle=%d: %s, %d segments, %d QP solves, %d updates; GPU %.3f s (second run %.3f s), oracle on one thread %.3f s; max|dx| %.2e\n",
+                W, obst, ToString(cg_code).c_str(), cg[0], cg[1], cg[2], tg, tg2, to, md);
+  }
+  std::printf(fails ? "EXAMPLE FAILED (%d)\n" : "EXAMPLE OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && !std::strcmp(argv[1], "example")) return run_example(argc > 2 ? std::atoi(argv[2]) : 802);
   if (argc > 1 && !std::strcmp(argv[1], "kats")) return run_kats();
   if (argc > 1 && !std::strcmp(argv[1], "ur5e")) return run_ur5e(argc > 2 ? std::atoi(argv[2]) : 22);
   if (argc > 1 && !std::strcmp(argv[1], "bench"))

@@ -468,6 +468,21 @@ def test_reference_example_horizon_802_waypoints():
     assert np.max(np.abs(x - xo)) <= TOL_X
 
 
+@pytest.mark.parametrize("W", [330, 350, 372])
+def test_solve_vector_that_fills_lds_to_the_budget(W):
+    """GOMP horizons whose solve vector plus the second positions of the multi-row chunks want more than LDS holds: the extra
+    rows are handed out until the budget is used up to the last byte - which must leave room for the kernels' own static LDS
+    (a 160 KB request failed to launch: found with the reference's 802-waypoint example, whose fourth segment sits there)."""
+    D = 6
+    P, (l, A, u), warm = PR.gomp_qp(D, W, np.zeros(D), np.array([np.pi, 0, 0, 0, 0, 0]))
+    s = M.QPSolver((l, A, u), P)
+    o = O.OracleQPSolver(P, None, A, l, u)
+    s.setWarmStart(warm); o.set_warm_start(warm)
+    code, x = s.solve(); sto, xo = o.solve()
+    assert code == ST2EXIT[sto] and s.info().iter == o.info().iter
+    assert np.max(np.abs(x - xo)) <= TOL_X
+
+
 def test_sixteen_waves_per_tile_variant(monkeypatch):
     """MI_OSQP_THREADS=1024: the 16-wave instantiations of the solve kernels (one workgroup per CU) walk
     schedules built for 16 waves; results equal the default 8-wave run up to round-off, iteration counts exactly."""
