@@ -126,6 +126,12 @@ int mi_osqp_update_A(mi_osqp_solver *h, const int64_t *A_colptr, const int64_t *
                      const double *A_val);
 /* QPSolver::update, second half = OsqpSolver::SetBounds ([REF] src/osqp-wrapper.h:40). */
 int mi_osqp_update_bounds(mi_osqp_solver *h, const double *l, const double *u);
+/* QPSolver::update as ONE call ([REF] src/osqp-wrapper.h:33-43: UpdateConstraintMatrix, then SetBounds): the state it
+ * leaves is that of mi_osqp_update_A followed by mi_osqp_update_bounds, with one numeric refactorisation instead of two
+ * when the new bounds change a row's type (equality / inequality / free).  Nothing is changed when l > u somewhere or the
+ * pattern differs. */
+int mi_osqp_update_A_bounds(mi_osqp_solver *h, const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                            const double *l, const double *u);
 /* QPSolver::setWarmStart = SetPrimalWarmStart ([REF] src/osqp-wrapper.h:45-49). */
 int mi_osqp_warm_start_x(mi_osqp_solver *h, const double *x);
 /* QPSolver::solve = Solve ([REF] src/osqp-wrapper.h:52); returns error code,
@@ -153,6 +159,8 @@ int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m,
 int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *A_colptr, const int64_t *A_rowidx,
                            const double *A_val);
 int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u);
+int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                                  const double *l, const double *u);      /* see mi_osqp_update_A_bounds */
 int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x);
 /* Blocking solve of all B QPs (the ADMM iterate runs on the GPU). */
 int mi_osqp_batch_solve(mi_osqp_batch *h);

@@ -96,11 +96,11 @@ class QPSolver {
 
   void update(const QPConstraints &qp_constraints) {
     const auto &[low, A, upp] = qp_constraints;
-    int rc = mi_osqp_update_A(h_, reinterpret_cast<const int64_t *>(A.outer.data()),
-                              reinterpret_cast<const int64_t *>(A.inner.data()), A.values.data());
-    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));      // [REF] :36-38
-    rc = mi_osqp_update_bounds(h_, low.data(), upp.data());
-    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));      // [REF] :40-42
+    if ((long long)low.size() != A.rows || (long long)upp.size() != A.rows) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_INVALID_DATA));
+    // UpdateConstraintMatrix + SetBounds ([REF] :36-42) as one call: one numeric refactorisation instead of two
+    int rc = mi_osqp_update_A_bounds(h_, reinterpret_cast<const int64_t *>(A.outer.data()),
+                                     reinterpret_cast<const int64_t *>(A.inner.data()), A.values.data(), low.data(), upp.data());
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));      // [REF] :36-38, :40-42
   }
 
   void setWarmStart(const QPVector &primal_vector) {
@@ -189,10 +189,8 @@ class BatchQPSolver {
       l.insert(l.end(), lo.begin(), lo.end());
       u.insert(u.end(), up.begin(), up.end());
     }
-    int rc = mi_osqp_batch_update_A(h_, reinterpret_cast<const int64_t *>(A0.outer.data()),
-                                    reinterpret_cast<const int64_t *>(A0.inner.data()), Av.data());
-    if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));
-    rc = mi_osqp_batch_update_bounds(h_, l.data(), u.data());
+    int rc = mi_osqp_batch_update_A_bounds(h_, reinterpret_cast<const int64_t *>(A0.outer.data()),
+                                           reinterpret_cast<const int64_t *>(A0.inner.data()), Av.data(), l.data(), u.data());
     if (rc != MI_OSQP_OK) throw std::invalid_argument(mi_osqp_error_name(rc));
   }
   // bounds only (the joint-space GOMP rows never change A)

@@ -86,6 +86,7 @@ def lib():
         L.mi_osqp_batch_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, C.c_int64, ip, ip, dp, dp, ip, ip, dp,
                                           dp, dp, C.POINTER(Settings), C.c_int64]
         L.mi_osqp_batch_update_A.argtypes = [vp, ip, ip, dp]
+        L.mi_osqp_batch_update_A_bounds.argtypes = [vp, ip, ip, dp, dp, dp]
         L.mi_osqp_batch_update_bounds.argtypes = [vp, dp, dp]
         L.mi_osqp_batch_warm_start_x.argtypes = [vp, dp]
         L.mi_osqp_batch_solve.argtypes = [vp]
@@ -261,6 +262,12 @@ class BatchSolver:
             if len(Ai) != len(self._Ai):
                 raise MiOsqpError(3, "update_A")
         _chk(lib().mi_osqp_batch_update_A(self._h, _ip(Ap), _ip(Ai), _dp(Ax)), "update_A")
+
+    def update_A_bounds(self, Ax, l, u):
+        """QPSolver::update as one call: new A values and new bounds, one refactorisation."""
+        Ax = _f64(Ax).reshape(self.B, -1)
+        l, u = _f64(l).reshape(self.B, -1), _f64(u).reshape(self.B, -1)
+        _chk(lib().mi_osqp_batch_update_A_bounds(self._h, _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(l), _dp(u)), "update_A_bounds")
 
     def update_bounds(self, l, u):
         l, u = _f64(l).reshape(self.B, -1), _f64(u).reshape(self.B, -1)

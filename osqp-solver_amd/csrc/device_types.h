@@ -81,6 +81,9 @@ struct FactorArgs {
                       // null: every slot of the batch (force_all) / the slots whose IS_NEED_REFACTOR flag is set
   double sigma;
   int dt_k;           // rows of the dense tail: their pivots are counted by dense_inverse_kernel, which then checks the inertia
+  // the ONE QP of a handle shared by mw_groups workgroups (single large QPs; grid barriers between the phases of a level)
+  int mw_groups;
+  unsigned *mw_bar;
 };
 
 // dense tail: assembly of the Schur complement + its inversion (tail_kernel; one workgroup per refactored QP, after

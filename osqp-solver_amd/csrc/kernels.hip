@@ -1658,8 +1658,15 @@ __device__ __forceinline__ void fct_trsm(const FactorArgs &a, double *Lb, const 
 template <int BT>
 __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   extern __shared__ double smem[];
-  const int tile = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  // (one QP shared by the grid - single large QPs, 10^4 .. 10^5 block tasks: the grid is ONE tile, threads / waves are
+  //  numbered over the grid, the barriers between the phases of a level are grid barriers)
+  bool multi = false;
+  if constexpr (BT == 1) multi = a.mw_groups > 1;
+  const Mw mw{a.mw_bar, multi ? (unsigned)a.mw_groups : 1u};
+  const int tile = multi ? 0 : blockIdx.x;
+  const int tid = multi ? blockIdx.x * blockDim.x + threadIdx.x : threadIdx.x, nthr = multi ? blockDim.x * mw.G : blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
+  auto sync = [&]() { if constexpr (BT == 1) wg_or_grid_barrier(mw); else __syncthreads(); };
   const int m = a.m, N = a.N;
   // The QP of lane class b: with a work list the flagged QPs of the whole batch are packed BT per workgroup (a
   // refactorisation is latency-bound per tile, so fewer, fuller tiles = fewer rounds over the CUs); per-QP arrays
@@ -1671,7 +1678,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   int flag = 0;
   if (slot >= 0) flag = a.work ? 1 : (a.force_all ? (slot < a.B) : a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)]);
   if (!__syncthreads_or(flag)) return;
-  double *Ss = smem + (size_t)wave * MI_CHUNK * MI_CHUNK * BT;
+  double *Ss = smem + (size_t)(threadIdx.x >> 6) * MI_CHUNK * MI_CHUNK * BT;
   double *Lb = a.Lblk + (size_t)tile * a.storage * BT;
   double *Dl = a.Dl + (size_t)tile * N * BT;
   const double rho = a.dscal[H(DS_COUNT, DS_RHO)];
@@ -1692,8 +1699,9 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     double2 *L2p = reinterpret_cast<double2 *>(Lb);
     for (size_t e = tid; e < pairs; e += nthr) L2p[e] = make_double2(0.0, 0.0);
     if (tid == 0 && (tot & 1)) Lb[tot - 1] = 0.0;
+    if (multi && tid == 0 && slot >= 0) a.npos[slot] = 0;
   }
-  __syncthreads();
+  sync();
   // ---- assemble the permuted KKT into block storage
   {
     // 4 entries per thread and trip: the table reads, then the value reads, then the stores (independent loads in flight)
@@ -1721,30 +1729,35 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
       for (int u = 0; u < UA; u++) if (e0 + u * nthr < tot) Lb[(size_t)dst[u] * BT + b] = v[u];
     }
   }
-  __syncthreads();
+  sync();
   int npos = 0, bad_inertia = 0;
   double *dnew = a.dinv_scratch + (size_t)tile * N * BT;
   for (int L = 0; L < a.n_levels; L++) {
     const uint32_t *lv = a.lvl + 6 * L;
     if (lv[1] > lv[0]) {
       for (uint32_t t = lv[0] + wave; t < lv[1]; t += nw) fct_update<BT>(a, Lb, Dl, Ss, t, lane);
-      __syncthreads();
+      sync();
     }
     if (!(MI_DBG_SKIP(a) & 4)) for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
-    __syncthreads();
+    sync();
     if (lv[5] > lv[4] && !(MI_DBG_SKIP(a) & 8)) {
       for (uint32_t t = lv[4] + wave; t < lv[5]; t += nw) fct_trsm<BT>(a, Lb, Dl, dnew, Ss, t, lane);
-      __syncthreads();
+      sync();
     }
   }
   // ---- inertia: positive pivots of QP b summed over the workgroup (each pivot counted by one lane)
   {
     __shared__ int s_npos[4];
-    if (tid < 4) s_npos[tid] = 0;
+    if (threadIdx.x < 4) s_npos[threadIdx.x] = 0;
     __syncthreads();
     if (npos) atomicAdd(&s_npos[b], npos);
     __syncthreads();
-    if (tid < BT && slot >= 0) a.npos[slot] = s_npos[b];
+    if (multi) {                            // the workgroups add their counts; everybody reads the total behind a grid barrier
+      if (threadIdx.x == 0 && slot >= 0 && s_npos[0]) atomicAdd(&a.npos[slot], s_npos[0]);
+      sync();
+      if (threadIdx.x == 0 && slot >= 0) s_npos[0] = __hip_atomic_load(&a.npos[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    } else if (tid < BT && slot >= 0) a.npos[slot] = s_npos[b];
     if (tid < BT && flag && s_npos[b] != a.n && !MI_DBG_SKIP(a) && !a.dt_k) bad_inertia = 1;   // (dense tail: dense_inverse_kernel adds its pivots and checks)
   }
   // ---- scatter into the solve schedules (only the refactored QPs)
@@ -1768,13 +1781,14 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     scatter(bv, a.bwd_srcblk, a.bwd.n_slots);
     for (int e = tid; e < N * BT; e += nthr) a.dinv[H(N, e / BT)] = dnew[e];
   }
-  __syncthreads();
+  sync();
   if (tid < BT && slot >= 0) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = bad_inertia ? -1 : 0;   // -1: the new factor has the wrong inertia
 }
 
 template <int BT>
 static hipError_t launch_factor_t(const FactorArgs &a, int tiles, int threads, hipStream_t st) {
   const size_t lds = factor_lds_bytes(BT, threads);
+  if (a.mw_groups > 1) { if (BT != 1 || tiles != 1 || !a.mw_bar) return hipErrorInvalidValue; tiles = a.mw_groups; }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<BT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

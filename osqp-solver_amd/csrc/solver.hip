@@ -336,6 +336,12 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
   a.sigma = h->st.sigma; a.home_bt = h->BT; a.dt_k = an.dt.k;
+  // the single large QP of a dataflow handle: its 10^4 .. 10^5 block tasks are shared by several workgroups
+  a.mw_groups = 0; a.mw_bar = h->mw_bar.p;
+  if (an.df && h->B == 1 && h->mw_groups > 1) {
+    const char *eg = getenv("MI_OSQP_FACTOR_GROUPS");
+    a.mw_groups = eg ? std::max(1, std::min(256, atoi(eg))) : 32;
+  }
 #ifdef MI_OSQP_DEBUG_BUILD
   { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }      // timing experiments, diagnostic build only
 #endif
@@ -862,6 +868,7 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   fa.work = h->work.p;
   HIPCHK(hipEventRecord(h->evf0, h->stream));
+  if (fa.mw_groups > 1) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
   HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
   HIPCHK(hipEventRecord(h->evf1, h->stream));
   if ((*h->anp).dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
@@ -893,6 +900,7 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipEventRecord(h->evf2, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (fa.mw_groups > 1 && (rc = mw_barrier_ok(h))) return rc;
   {
     float f = 0.f, d = 0.f;
     HIPCHK(hipEventElapsedTime(&f, h->evf0, h->evf1)); HIPCHK(hipEventElapsedTime(&d, h->evf1, h->evf2));
@@ -1042,6 +1050,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
         } else {
           // after a compaction of this segment the host copy of the flags is stale: flag-driven sweep over the tiles
           FactorArgs fa = make_factor_args(h, 0);
+          fa.mw_groups = 0;
           HIPCHK(launch_factor(fa, BT, ntl_before, factor_threads(), h->stream));
           HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl_before * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
           HIPCHK(hipStreamSynchronize(h->stream));
@@ -1354,10 +1363,42 @@ static int update_bounds_on_device(mi_osqp_batch *h, const double *d_l, const do
   return MI_OSQP_OK;
 }
 
+static int update_A_values(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av);
+
 int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
   CallTimer timer_("batch_update_A");
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  int rc = update_A_values(h, Ap, Ai, Av);
+  if (rc || (rc = mi_osqp_batch_refactor_device(h))) return rc;
+  return snapshot(h);
+}
+
+// new A values and new bounds, ONE refactorisation (QPSolver::update: [REF] src/osqp-wrapper.h:33-43)
+int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l, const double *u) {
+  CallTimer timer_("batch_update_A_bounds");
+  if (!h || !Ap || !Ai || !Av || !l || !u) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
+  const Analysis &an = (*h->anp);
+  const int m = an.m, B = h->B;
+  for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  int rc = update_A_values(h, Ap, Ai, Av);        // (the host mirrors are authoritative from here on)
+  if (rc) return rc;
+  for (int q = 0; q < B; q++) {
+    QPNumeric &Q = h->qp[q];
+    for (int i = 0; i < m; i++) {
+      Q.l[i] = std::max(l[(size_t)q * m + i], -kInfty); Q.u[i] = std::min(u[(size_t)q * m + i], kInfty);
+      if (h->st.scaling) { Q.l[i] *= Q.E[i]; Q.u[i] *= Q.E[i]; }
+    }
+    (void)refresh_rho_types(an, Q);
+  }
+  std::vector<int> all(B);
+  for (int i = 0; i < B; i++) all[i] = i;
+  if ((rc = upload_problem(h, all, false)) || (rc = refactor_qps(h, all))) return rc;       // (factor_kernel derives the rho vectors from the new bounds)
+  return snapshot(h);
+}
+
+static int update_A_values(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
   h->clear_rho_updates = true;
   const Analysis &an = (*h->anp);
   int n = an.n, B = h->B, nnzA = an.Ap[n], rc;
@@ -1380,8 +1421,7 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
     for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
     if ((rc = upload_problem(h, ids, true)) || (rc = sync_scalars_to_device(h, ids, true))) return rc;
   }
-  if ((rc = mi_osqp_batch_refactor_device(h))) return rc;
-  return snapshot(h);
+  return MI_OSQP_OK;
 }
 
 int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
@@ -1471,6 +1511,9 @@ int mi_osqp_setup(mi_osqp_solver **out, int64_t n, int64_t m, const int64_t *Pp,
   return MI_OSQP_OK;
 }
 void mi_osqp_free(mi_osqp_solver *h) { if (h) { delete h->b; delete h; } }
+int mi_osqp_update_A_bounds(mi_osqp_solver *h, const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l, const double *u) {
+  return h ? mi_osqp_batch_update_A_bounds(h->b, Ap, Ai, Av, l, u) : MI_OSQP_ERR_NULL;
+}
 int mi_osqp_update_A(mi_osqp_solver *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
   return h ? mi_osqp_batch_update_A(h->b, Ap, Ai, Av) : MI_OSQP_ERR_NULL;
 }

@@ -210,6 +210,40 @@ def test_device_resident_io_matches_host_io():
         s2.update_bounds_device(torch.tensor(u2 + 1, device="cuda"), torch.tensor(l2, device="cuda"))
 
 
+def test_update_of_values_and_bounds_in_one_call_equals_the_two_calls():
+    """mi_osqp_batch_update_A_bounds (QPSolver::update, [REF] src/osqp-wrapper.h:33-43) = update_A then update_bounds with one
+    refactorisation: bitwise the same iterates afterwards, also when the new bounds change row types (an equality, a free row)."""
+    B = 6
+    pr = PR.random_box_qp(B, n=64, mg=48, nnz_per_row=4)
+    rng = np.random.default_rng(11)
+    Ax2 = pr["Ax"] * (1.0 + 0.1 * rng.standard_normal(pr["Ax"].shape))
+    l2, u2 = pr["l"] * 0.9, pr["u"] * 1.1
+    l2[:, 3] = u2[:, 3] = 0.05                     # becomes an equality
+    l2[:, 7] = -1e30; u2[:, 7] = 1e30              # becomes a free row
+    sa = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    sb = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    sa.solve(); sb.solve()                         # (rho has adapted: the update path starts from a used handle)
+    sa.update_A(Ax2); sa.update_bounds(l2, u2)
+    sb.update_A_bounds(Ax2, l2, u2)
+    ia, ib = sa.solve(), sb.solve()
+    assert [i.iter for i in ia] == [i.iter for i in ib] and [i.exit_code for i in ia] == [i.exit_code for i in ib]
+    np.testing.assert_array_equal(sa.primal(), sb.primal())
+    np.testing.assert_array_equal(sa.dual(), sb.dual())
+    xb = sb.primal().copy()
+    with pytest.raises(M.MiOsqpError):
+        sb.update_A_bounds(Ax2, u2 + 1.0, l2)      # l > u: refused, nothing changed
+    sb.reset(); sa.reset()
+    assert [i.iter for i in sa.solve()] == [i.iter for i in sb.solve()]
+    # and the oracle taken through the same two updates
+    for b in range(2):
+        P, A = PR.qp_matrices(pr, b)
+        o = O.OracleQPSolver(P, pr["q"][b], A, pr["l"][b], pr["u"][b]); o.solve()
+        A2 = A.copy(); A2.data = Ax2[b].copy()
+        o.update(l2[b], A2, u2[b])
+        st, xo = o.solve()
+        assert ib[b].iter == o.info().iter and np.max(np.abs(xb[b] - xo)) <= TOL_X
+
+
 def test_headline_config_properties_full_size():
     """BASELINE config 3 at full size (B=1024, n=512, m=1024): size-independent
     properties for every QP + oracle parity on a sample."""
