@@ -340,7 +340,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.mw_groups = 0; a.mw_bar = h->mw_bar.p;
   if (an.df && h->B == 1 && h->mw_groups > 1) {
     const char *eg = getenv("MI_OSQP_FACTOR_GROUPS");
-    a.mw_groups = eg ? std::max(1, std::min(256, atoi(eg))) : 32;
+    a.mw_groups = eg ? std::max(1, std::min(256, atoi(eg))) : 64;      // config 5 (ms): 1: 275, 8: 45, 16: 28, 32: 19, 64: 15, 128: 14
   }
 #ifdef MI_OSQP_DEBUG_BUILD
   { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }      // timing experiments, diagnostic build only

@@ -14,6 +14,7 @@ for g in (150, 316):
         os.environ["MI_OSQP_GROUP_THREADS"] = G.split(":")[1] if ":" in G else "512"
         s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], max_iter=200)
         st = s.stats()
+        rf = s.refactor_time()
         torch.cuda.synchronize()
         t = time.perf_counter(); info = s.solve(); t1 = time.perf_counter() - t
         x = s.primal()[0].copy()
@@ -26,5 +27,5 @@ for g in (150, 316):
         sol = d_sol.cpu().numpy()[0]
         if base is None: base = (x, sol, info[0].iter)
         print(f"g={g} G={G} iters {info[0].iter} status {info[0].exit_code} ms/iter {1e3 * t1 / max(1, info[0].iter):.3f} kkt_solve {1e3 * tk:.3f} ms "
-              f"dx {np.max(np.abs(x - base[0])):.2e} dsol {np.max(np.abs(sol - base[1])) / np.max(np.abs(base[1])):.2e} levels {st['fwd_levels']}+{st['bwd_levels']}", flush=True)
+              f"dx {np.max(np.abs(x - base[0])):.2e} dsol {np.max(np.abs(sol - base[1])) / np.max(np.abs(base[1])):.2e} levels {st['fwd_levels']}+{st['bwd_levels']} setup factor_kernel {rf[0]:.1f} ms (MI_OSQP_FACTOR_GROUPS={os.environ.get('MI_OSQP_FACTOR_GROUPS', 'default')})", flush=True)
         s.close()
