@@ -169,8 +169,9 @@ int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y_out /*[B][m]*/);
 int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info /*[B]*/);
 int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st);
 void mi_osqp_batch_free(mi_osqp_batch *h);
-/* Freed handles leave their device buffers (at most 8 GiB) in a process-wide cache for the next setup - the GOMP
- * drivers build one solver per horizon segment; this returns them to the HIP runtime. */
+/* Freed handles leave their device buffers (at most 8 GiB), pinned host buffers (at most 1 GiB) and stream / event sets in
+ * process-wide caches for the next setup - the GOMP drivers build one solver per horizon segment; this returns them to
+ * the HIP runtime. */
 void mi_osqp_release_device_cache(void);
 
 /* Device-resident I/O (HBM pointers on the solver's device; `stream` is a

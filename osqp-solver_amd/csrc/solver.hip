@@ -146,6 +146,67 @@ static void release_all() {
 }
 }  // namespace devpool
 
+// The same for pinned host memory and for streams + events: hipHostMalloc costs ~0.5 ms per call and a handle needs four
+// of them, a stream and five events - 2-3 ms of a 4 ms setup for the small QPs of a sequential GOMP run.
+namespace hostpool {
+static std::mutex mu;
+static std::multimap<size_t, void *> blocks;          // capacity in bytes -> pinned pointer
+static size_t kept = 0;
+constexpr size_t kMaxKept = (size_t)1 << 30;
+static void *take(size_t bytes, size_t &cap) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = blocks.lower_bound(bytes);
+  if (it == blocks.end() || it->first > 4 * bytes + 65536) return nullptr;
+  void *p = it->second; cap = it->first; kept -= cap;
+  blocks.erase(it);
+  return p;
+}
+static void give(void *p, size_t cap) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (kept + cap <= kMaxKept) { blocks.emplace(cap, p); kept += cap; return; }
+  }
+  (void)hipHostFree(p);
+}
+static void release_all() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &b : blocks) (void)hipHostFree(b.second);
+  blocks.clear(); kept = 0;
+}
+// pinned allocation of at least `bytes` (rounded up to 4 KiB); *cap = what to hand back to give()
+static hipError_t alloc(void **p, size_t bytes, size_t *cap) {
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  if (void *q = take(bytes, *cap)) { *p = q; return hipSuccess; }
+  *cap = bytes;
+  return hipHostMalloc(p, bytes, hipHostMallocPortable);      // (a kept block may serve a handle on another device)
+}
+}  // namespace hostpool
+namespace streampool {
+struct Bundle { int dev; hipStream_t stream; hipEvent_t ev[5]; };
+static std::mutex mu;
+static std::vector<Bundle> idle;
+static bool take(int dev, Bundle &out) {
+  std::lock_guard<std::mutex> lk(mu);
+  for (size_t i = 0; i < idle.size(); i++)
+    if (idle[i].dev == dev) { out = idle[i]; idle.erase(idle.begin() + i); return true; }
+  return false;
+}
+static void give(const Bundle &b) {           // (the stream has been synchronised)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (idle.size() < 64) { idle.push_back(b); return; }
+  }
+  for (hipEvent_t e : b.ev) if (e) (void)hipEventDestroy(e);
+  if (b.stream) (void)hipStreamDestroy(b.stream);
+}
+static void release_all() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (Bundle &b : idle) { for (hipEvent_t e : b.ev) if (e) (void)hipEventDestroy(e); if (b.stream) (void)hipStreamDestroy(b.stream); }
+  idle.clear();
+}
+}  // namespace streampool
+
 template <class T>
 struct DevBuf {
   T *p = nullptr; size_t n = 0;
@@ -236,8 +297,9 @@ struct mi_osqp_batch {
   bool clear_rho_updates = true;          // the next solve starts counting rho updates from 0 (setup / update_* / reset happened)
   int *h_npos = nullptr;
   DevBuf<double> stage; DevBuf<int> ids, work;
-  int *h_iscal = nullptr;     // pinned
+  int *h_iscal = nullptr;     // pinned (hostpool; *_cap = capacity to hand back)
   double *h_dscal = nullptr;  // pinned
+  size_t h_iscal_cap = 0, h_dscal_cap = 0, h_npos_cap = 0, pin_cap = 0;
   double *pin = nullptr;      // pinned staging of the host update paths (a pageable hipMemcpy runs at ~1 GB/s here, and unevenly)
   size_t pin_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evf0 = nullptr, evf1 = nullptr, evf2 = nullptr;
@@ -257,14 +319,13 @@ struct mi_osqp_batch {
   DevBuf<int> fail_list;
   ~mi_osqp_batch() {
     DevGuard guard(device);
-    if (h_iscal) (void)hipHostFree(h_iscal);
-    if (h_dscal) (void)hipHostFree(h_dscal);
-    if (pin) (void)hipHostFree(pin);
-    if (h_npos) (void)hipHostFree(h_npos);
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    for (hipEvent_t e : {evf0, evf1, evf2}) if (e) (void)hipEventDestroy(e);
-    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }   // (the buffers go back to the pool right after: DevBuf remembers its device)
+    if (stream) (void)hipStreamSynchronize(stream);      // (the buffers go back to their pools right after: DevBuf remembers its device)
+    hostpool::give(h_iscal, h_iscal_cap); hostpool::give(h_dscal, h_dscal_cap); hostpool::give(pin, pin_cap); hostpool::give(h_npos, h_npos_cap);
+    if (stream && ev0 && ev1 && evf0 && evf1 && evf2) streampool::give({device, stream, {ev0, ev1, evf0, evf1, evf2}});
+    else {
+      for (hipEvent_t e : {ev0, ev1, evf0, evf1, evf2}) if (e) (void)hipEventDestroy(e);
+      if (stream) (void)hipStreamDestroy(stream);
+    }
   }
 };
 
@@ -357,9 +418,9 @@ static int ensure_stage(mi_osqp_batch *h, size_t doubles, size_t ints) {
 
 static int ensure_pin(mi_osqp_batch *h, size_t doubles) {
   if (h->pin_n >= doubles) return 0;
-  if (h->pin) { (void)hipHostFree(h->pin); h->pin = nullptr; h->pin_n = 0; }
-  HIPCHK(hipHostMalloc((void **)&h->pin, doubles * sizeof(double)));
-  h->pin_n = doubles;
+  if (h->pin) { hostpool::give(h->pin, h->pin_cap); h->pin = nullptr; h->pin_n = 0; }
+  HIPCHK(hostpool::alloc((void **)&h->pin, doubles * sizeof(double), &h->pin_cap));
+  h->pin_n = h->pin_cap / sizeof(double);
   return 0;
 }
 // memcpy on the host threads (user arrays of several MB per call in the GOMP drivers' loops)
@@ -656,9 +717,15 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   HIPCHK(hipGetDeviceProperties(&prop, h->device));
   h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { g_last_error = std::string("device is not gfx950: ") + prop.gcnArchName; return MI_OSQP_ERR_DEVICE; }
-  HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
-  HIPCHK(hipEventCreate(&h->evf0)); HIPCHK(hipEventCreate(&h->evf1)); HIPCHK(hipEventCreate(&h->evf2));
+  {
+    streampool::Bundle sb;
+    if (streampool::take(h->device, sb)) { h->stream = sb.stream; h->ev0 = sb.ev[0]; h->ev1 = sb.ev[1]; h->evf0 = sb.ev[2]; h->evf1 = sb.ev[3]; h->evf2 = sb.ev[4]; }
+    else {
+      HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+      HIPCHK(hipEventCreate(&h->evf0)); HIPCHK(hipEventCreate(&h->evf1)); HIPCHK(hipEventCreate(&h->evf2));
+    }
+  }
   h->BT = BT; h->ntiles = (int)((B + BT - 1) / BT);
   h->lds = h->global_xs ? lds_bytes(0, BT, h->threads) : lds_bytes(an.Next + 2 * an.dt.k, BT, h->threads);
   if (h->lds > lds_cap) { g_last_error = "internal: LDS budget exceeded"; return MI_OSQP_ERR_ALLOC; }
@@ -705,7 +772,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
         // (+4 QPs: a refactorisation may pack its work list with up to 4 QPs per workgroup, rounded up)
         (rc = h->Lblk.alloc((size_t)bf.storage * (T + 4))) || (rc = h->Dl.alloc((size_t)an.N * (T + 4))) || (rc = h->Dl.zero(h->stream)) ||
         (rc = h->dinv_scratch.alloc((size_t)an.N * (T + 4))) || (rc = h->npos.alloc(T))) return rc;
-    HIPCHK(hipHostMalloc((void **)&h->h_npos, T * sizeof(int)));
+    HIPCHK(hostpool::alloc((void **)&h->h_npos, T * sizeof(int), &h->h_npos_cap));
   }
   // tables of the fused SpMV op: rows of [P x ; A'y ; A x] as (value position, vector index) pairs, 16 bits each; used
   // when the compact values of a tile and [x ; y] fit LDS together
@@ -756,8 +823,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
-  HIPCHK(hipHostMalloc((void **)&h->h_iscal, (size_t)IS_COUNT * T * sizeof(int)));
-  HIPCHK(hipHostMalloc((void **)&h->h_dscal, (size_t)DS_COUNT * T * sizeof(double)));
+  HIPCHK(hostpool::alloc((void **)&h->h_iscal, (size_t)IS_COUNT * T * sizeof(int), &h->h_iscal_cap));
+  HIPCHK(hostpool::alloc((void **)&h->h_dscal, (size_t)DS_COUNT * T * sizeof(double), &h->h_dscal_cap));
   if ((rc = ensure_pin(h, std::max((size_t)2 * B * m, (size_t)B * n)))) return rc;      // (host update paths: bounds, warm starts)
   HIPCHK(hipStreamSynchronize(h->stream));
   double t1 = now_s();
@@ -1150,7 +1217,7 @@ int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m, co
 }
 
 void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }
-void mi_osqp_release_device_cache(void) { devpool::release_all(); }
+void mi_osqp_release_device_cache(void) { devpool::release_all(); hostpool::release_all(); streampool::release_all(); }
 
 int mi_osqp_batch_solve(mi_osqp_batch *h) {
   CallTimer timer_("batch_solve");
