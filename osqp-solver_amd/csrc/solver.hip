@@ -397,11 +397,13 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
   a.sigma = h->st.sigma; a.home_bt = h->BT; a.dt_k = an.dt.k;
-  // the single large QP of a dataflow handle: its 10^4 .. 10^5 block tasks are shared by several workgroups
+  // a handle with ONE QP of some size (the sequential GOMP driver's horizons, config 5): its 10^3 .. 10^5 block tasks are
+  // shared by several workgroups, with grid barriers between the phases of a level (3 x levels x ~6 us)
   a.mw_groups = 0; a.mw_bar = h->mw_bar.p;
-  if (an.df && h->B == 1 && h->mw_groups > 1) {
+  if (h->B == 1 && h->BT == 1 && h->mw_bar.p && an.N >= 3000) {
     const char *eg = getenv("MI_OSQP_FACTOR_GROUPS");
-    a.mw_groups = eg ? std::max(1, std::min(256, atoi(eg))) : 64;      // config 5 (ms): 1: 275, 8: 45, 16: 28, 32: 19, 64: 15, 128: 14
+    // config 5 (ms): 1: 275, 8: 45, 16: 28, 32: 19, 64: 15, 128: 14
+    a.mw_groups = eg ? std::max(1, std::min(256, atoi(eg))) : std::max(4, std::min(64, an.N / 600));
   }
 #ifdef MI_OSQP_DEBUG_BUILD
   { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }      // timing experiments, diagnostic build only
@@ -740,8 +742,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
   if (h->global_xs) { ALLOC(xs_global, an.xs_total); }
-  if (an.df && ((rc = h->mw_bar.alloc(4)) || (rc = h->mw_bar.zero(h->stream)) || (rc = h->rflag.upload(an.rflag)) ||
-                (rc = h->mw_scratch.alloc((size_t)8 * 256 * 16)) || (rc = h->mw_scratch.zero(h->stream)))) return rc;
+  if ((an.df || B == 1) && ((rc = h->mw_bar.alloc(4)) || (rc = h->mw_bar.zero(h->stream)))) return rc;
+  if (an.df && ((rc = h->rflag.upload(an.rflag)) || (rc = h->mw_scratch.alloc((size_t)8 * 256 * 16)) || (rc = h->mw_scratch.zero(h->stream)))) return rc;
   if (an.dt.k) {
     const DenseTail &dt = an.dt;
     ALLOC(dt_val, (size_t)dt.n_steps * 64);
@@ -967,7 +969,11 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipEventRecord(h->evf2, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (fa.mw_groups > 1 && (rc = mw_barrier_ok(h))) return rc;
+  if (fa.mw_groups > 1) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(w, h->mw_bar.p, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[2]) { g_last_error = "refactorisation on several workgroups: a grid barrier timed out"; return MI_OSQP_ERR_DEVICE; }
+  }
   {
     float f = 0.f, d = 0.f;
     HIPCHK(hipEventElapsedTime(&f, h->evf0, h->evf1)); HIPCHK(hipEventElapsedTime(&d, h->evf1, h->evf2));
