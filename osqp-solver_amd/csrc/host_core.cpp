@@ -262,14 +262,18 @@ static void postorder(const std::vector<int> &parent, std::vector<int> &post) {
 
 namespace {
 struct RowWork { uint32_t row; std::vector<std::pair<uint32_t, int32_t>> ent; };   // ent: (gather index, value source)
-struct LevelWork { std::vector<RowWork> rowsA, rowsB; };                           // B rows: store instead of subtract
+// One barrier interval ("phase") of a schedule.  shared[kind]: rows dealt over all waves by load (kind 0: the flush subtracts
+// from the row, kind 1: it stores the sum); the rows of one phase never depend on each other across waves.  wave[w]: groups
+// of rows that stay on wave w, executed in this order AFTER its share of the shared rows - a later group may gather what
+// an earlier group of the same wave has just written (LDS operations of one wave execute in order: no barrier needed).
+struct RowGroup { int kind; std::vector<RowWork> rows; };
+struct LevelWork { std::vector<RowWork> shared[2]; std::vector<std::vector<RowGroup>> wave; };
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
 
-// Builds one schedule.  Work is first laid out as phases (per level: one phase for rowsA, one for rowsB, each
-// spread over the waves); the steps are then numbered WAVE-MAJOR: wave w's steps of all phases are contiguous
-// in memory and form the linear stream the device walks (sched_format.h); phase boundaries survive only as
-// barrier counts in the descriptors.
+// Builds one schedule.  Work is first laid out as phases (one per non-empty level, spread over the waves); the steps
+// are then numbered WAVE-MAJOR: wave w's steps of all phases are contiguous in memory and form the linear stream the
+// device walks (sched_format.h); phase boundaries survive only as barrier counts in the descriptors.
 void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, int bt, bool barriers, bool wide,
                    bool dataflow = false, uint32_t shadow = 0, uint32_t pad = 0) {
   sch = Schedule();
@@ -277,13 +281,12 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
   sch.nw = nw; sch.bt = bt; sch.barriers = barriers;
   sch.dataflow = dataflow; sch.shadow = shadow; sch.pad = pad;
   // a unit = work that must stay on one wave, in order
-  struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; };
+  struct StepSpec { int lt; bool flush; std::vector<const RowWork *> rows; int first_entry; int kind; bool group_start; };
   struct Unit { std::vector<StepSpec> steps; };
   struct PhaseRec { int kind; std::vector<std::vector<StepSpec>> wave; };
   std::vector<PhaseRec> phases;
-  auto pack_rows = [&](const std::vector<RowWork> &rows, int kind) {
-    if (rows.empty()) return;
-    std::vector<Unit> units;
+  // rows -> units (steps that stay together on one wave)
+  auto make_units = [&](const std::vector<RowWork> &rows, int kind, std::vector<Unit> &units) {
     std::vector<const RowWork *> longs;
     // short rows (<= 64 entries): lane-group width T and step count S <= 4 chosen to minimise the
     // padded slots T*S (ties -> fewer steps); rows with equal (T,S) are packed 64/T per unit
@@ -312,7 +315,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       int T = 64 / rpt, S = 0;
       for (const RowWork *r : grp) S = std::max(S, ((int)r->ent.size() + T - 1) / T);
       Unit u;
-      for (int st = 0; st < S; st++) u.steps.push_back({ilog2(T), st == S - 1, grp, st * T});
+      for (int st = 0; st < S; st++) u.steps.push_back({ilog2(T), st == S - 1, grp, st * T, kind, false});
       units.push_back(std::move(u));
     }
     for (int lt = 6; lt >= 0; lt--)
@@ -322,31 +325,54 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
         for (size_t i = 0; i < v.size(); i += per) {
           std::vector<const RowWork *> grp(v.begin() + i, v.begin() + std::min(v.size(), i + per));
           Unit u;
-          for (int st = 0; st < S; st++) u.steps.push_back({lt, st == S - 1, grp, st * T});
+          for (int st = 0; st < S; st++) u.steps.push_back({lt, st == S - 1, grp, st * T, kind, false});
           units.push_back(std::move(u));
         }
       }
-    // longest-processing-time assignment of units to waves
-    std::vector<size_t> order(units.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
-    std::vector<int> load(nw, 0);
-    std::vector<std::vector<size_t>> mine(nw);
-    for (size_t k : order) {
-      int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-      load[w] += (int)units[k].steps.size();
-      mine[w].push_back(k);
-    }
-    PhaseRec ph; ph.kind = kind; ph.wave.resize(nw);
-    for (int w = 0; w < nw; w++)
-      for (size_t k : mine[w])
-        for (StepSpec &st : units[k].steps) ph.wave[w].push_back(std::move(st));
-    phases.push_back(std::move(ph));
   };
   for (size_t L = 0; L < levels.size(); L++) {
     sch.level_first_phase.push_back((int)phases.size());
-    pack_rows(levels[L].rowsA, 0);
-    pack_rows(levels[L].rowsB, 1);
+    const LevelWork &lv = levels[L];
+    bool any = !lv.shared[0].empty() || !lv.shared[1].empty();
+    for (const auto &wg : lv.wave) for (const RowGroup &g : wg) any = any || !g.rows.empty();
+    if (!any) continue;
+    PhaseRec ph; ph.kind = lv.shared[0].empty() && !lv.shared[1].empty() ? 1 : 0; ph.wave.resize(nw);
+    std::vector<int> load(nw, 0);
+    // the rows that stay on their wave count as load before the shared rows are dealt
+    std::vector<std::vector<std::vector<Unit>>> own(nw);
+    for (int w = 0; w < nw && w < (int)lv.wave.size(); w++)
+      for (const RowGroup &g : lv.wave[w]) {
+        own[w].emplace_back();
+        make_units(g.rows, g.kind, own[w].back());
+        for (const Unit &u : own[w].back()) load[w] += (int)u.steps.size();
+      }
+    for (int kind = 0; kind < 2; kind++) {
+      if (lv.shared[kind].empty()) continue;
+      std::vector<Unit> units;
+      make_units(lv.shared[kind], kind, units);
+      // longest-processing-time assignment of units to waves
+      std::vector<size_t> order(units.size());
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return units[a].steps.size() > units[b].steps.size(); });
+      std::vector<std::vector<size_t>> mine(nw);
+      for (size_t k : order) {
+        int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[w] += (int)units[k].steps.size();
+        mine[w].push_back(k);
+      }
+      for (int w = 0; w < nw; w++) {
+        bool first = true;
+        for (size_t k : mine[w])
+          for (StepSpec &st : units[k].steps) { st.group_start = first; first = false; ph.wave[w].push_back(std::move(st)); }
+      }
+    }
+    for (int w = 0; w < nw; w++)
+      for (auto &units : own[w]) {
+        bool first = true;
+        for (Unit &u : units)
+          for (StepSpec &st : u.steps) { st.group_start = first; first = false; ph.wave[w].push_back(std::move(st)); }
+      }
+    phases.push_back(std::move(ph));
   }
   sch.level_first_phase.push_back((int)phases.size());
   sch.n_phases = (int)phases.size();
@@ -359,6 +385,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
     sch.wave_range[2 * w] = sch.n_steps;
     int last_phase = 0;        // phase of the wave's previous step: barriers owed = phase boundaries crossed since
     size_t L = 0;
+    std::vector<uint32_t> group_starts;      // steps that open a group inside a phase: what they gather may have just been written
     for (int p = 0; p < sch.n_phases; p++) {
       while (L < levels.size() && sch.level_first_phase[L] == p) sch.lvl_pos[L++ * nw + w] = sch.n_steps;   // (empty levels share a phase index)
       uint32_t *e = &sch.phase[(size_t)p * sch.phase_stride() + 1 + 4 * w];
@@ -372,7 +399,8 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
         sch.src.resize((size_t)sch.n_steps * 64, MI_SRC_ZERO);
         uint32_t nbar = 0;
         if (barriers && k == 0) { nbar = (uint32_t)(p - last_phase); last_phase = p; }
-        uint32_t d = (nbar << 12) | (uint32_t)st.lt | (phases[p].kind == 1 ? MI_D_STORE : 0u), ob = 0;
+        uint32_t d = (nbar << 12) | (uint32_t)st.lt | (st.kind == 1 ? MI_D_STORE : 0u), ob = 0;
+        if (st.group_start && k > 0) group_starts.push_back(stepno);
         const int T = 1 << st.lt;
         for (int g = 0; g < (int)st.rows.size(); g++) {
           const auto &ent = st.rows[g]->ent;
@@ -400,6 +428,7 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
       const uint32_t b0 = sch.wave_range[2 * w], e0 = sch.n_steps;
       std::vector<char> level_start(e0 - b0 + 1, 0);
       for (size_t l2 = 0; l2 <= levels.size(); l2++) level_start[sch.lvl_pos[l2 * nw + w] - b0] = 1;
+      for (uint32_t q : group_starts) level_start[q - b0] = 1;      // (no gather is issued ahead across a group boundary)
       auto eligible = [&](uint32_t q) { return MI_D_NBAR(sch.step[q]) == 0 && !level_start[q - b0]; };
       for (uint32_t q = b0; q + MI_D_LOOKAHEAD < e0; q++) {
         bool okk = true;
@@ -443,6 +472,18 @@ void pack_schedule(const std::vector<LevelWork> &levels, Schedule &sch, int nw, 
   }
 }
 }  // namespace
+
+// The plain form: per level of the chunk dependency graph one phase for the A rows and one for the B rows of its chunks,
+// all rows dealt over the waves.
+static std::vector<LevelWork> plain_levels(const std::vector<int> &order, std::vector<std::vector<RowWork>> &rowsA,
+                                           std::vector<std::vector<RowWork>> &rowsB, const std::vector<int> &lev, int maxlev) {
+  std::vector<LevelWork> lw(2 * (size_t)(maxlev + 1));
+  for (int c : order) {
+    for (RowWork &r : rowsA[c]) lw[2 * (size_t)lev[c]].shared[0].push_back(std::move(r));
+    for (RowWork &r : rowsB[c]) lw[2 * (size_t)lev[c] + 1].shared[1].push_back(std::move(r));
+  }
+  return lw;
+}
 
 static void build_tri_schedules(Analysis &an, int nw, int bt, bool df) {
   int N = an.N;
@@ -495,7 +536,8 @@ static void build_tri_schedules(Analysis &an, int nw, int bt, bool df) {
       lev[c] = L; maxlev = std::max(maxlev, L);
     }
     an.chunk_lev = lev;
-    std::vector<LevelWork> lw(maxlev + 1);
+    // per chunk: its A rows (couplings to earlier chunks, subtracted in place) and B rows (product with the inverted block)
+    std::vector<std::vector<RowWork>> rowsA(nch), rowsB(nch);
     for (int c = 0; c < nch; c++) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
       for (int i = c0; i < c1; i++) {
@@ -504,15 +546,18 @@ static void build_tri_schedules(Analysis &an, int nw, int bt, bool df) {
           int j = an.Rj[t];
           if (j < c0 && j < ts) rw.ent.push_back({f_x(j), an.Rpos[t]});
         }
-        if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
+        if (!rw.ent.empty()) rowsA[c].push_back(std::move(rw));
         if (r >= 2 && c0 < ts) {
           RowWork rb; rb.row = (uint32_t)an.xloc[i];
           for (int k = c0; k < i; k++) rb.ent.push_back({f_t(k), an.inv_index(c, i - c0, k - c0)});
           rb.ent.push_back({f_t(i), MI_SRC_ONE});
-          lw[lev[c]].rowsB.push_back(std::move(rb));
+          rowsB[c].push_back(std::move(rb));
         }
       }
     }
+    std::vector<int> order(nch);
+    std::iota(order.begin(), order.end(), 0);
+    std::vector<LevelWork> lw = plain_levels(order, rowsA, rowsB, lev, maxlev);
     pack_schedule(lw, an.fwd, nw, bt, !df, an.wide, df, SH, PAD);
   }
   // ---- backward: columns descending, sources are rows j > column.  Column k of a chunk: phase A works in
@@ -527,25 +572,28 @@ static void build_tri_schedules(Analysis &an, int nw, int bt, bool df) {
         for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) { int j = an.Li[p]; if (j >= c1) L = std::max(L, lev[chunk_of[j]] + 1); }
       lev[c] = L; maxlev = std::max(maxlev, L);
     }
-    std::vector<LevelWork> lw(maxlev + 1);
+    std::vector<std::vector<RowWork>> rowsA(nch), rowsB(nch);
+    std::vector<int> order;
     for (int c = nch - 1; c >= 0; c--) {
       int c0 = an.chunk_start[c], c1 = an.chunk_start[c + 1], r = c1 - c0;
       if (c0 >= ts) continue;
+      order.push_back(c);
       for (int col = c1 - 1; col >= c0; col--) {
         RowWork rw; rw.row = (uint32_t)an.xloc[col];
         for (int p = an.Lp[col]; p < an.Lp[col + 1]; p++) {
           int j = an.Li[p];
           if (j >= c1) rw.ent.push_back({b_x(j), p});
         }
-        if (!rw.ent.empty()) lw[lev[c]].rowsA.push_back(std::move(rw));
+        if (!rw.ent.empty()) rowsA[c].push_back(std::move(rw));
         if (r >= 2) {
           RowWork rb; rb.row = (uint32_t)col;
           rb.ent.push_back({b_t(col), MI_SRC_ONE});
           for (int i = col + 1; i < c1; i++) rb.ent.push_back({b_t(i), an.inv_index(c, i - c0, col - c0)});
-          lw[lev[c]].rowsB.push_back(std::move(rb));
+          rowsB[c].push_back(std::move(rb));
         }
       }
     }
+    std::vector<LevelWork> lw = plain_levels(order, rowsA, rowsB, lev, maxlev);
     pack_schedule(lw, an.bwd, nw, bt, !df, an.wide, df, SH, PAD);
   }
 }
@@ -570,7 +618,7 @@ static void build_chk_schedule(Analysis &an, int nw, int bt) {
       aty[c].ent.push_back({(uint32_t)(n + r), nnzP + k});
       ax[r].ent.push_back({(uint32_t)c, nnzP + k});
     }
-  lw[0].rowsA = std::move(px); lw[1].rowsA = std::move(aty); lw[2].rowsA = std::move(ax);
+  lw[0].shared[0] = std::move(px); lw[1].shared[0] = std::move(aty); lw[2].shared[0] = std::move(ax);
   pack_schedule(lw, an.chk, nw, bt, false, an.wide);
 }
 
@@ -1356,14 +1404,31 @@ static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs
   const int nw = s.nw;
   std::vector<uint32_t> pos(nw), epoch(nw, 0u);
   for (int w = 0; w < nw; w++) pos[w] = s.wave_range[2 * w];
+  // per entry of the vector: the epoch of its last write / read and who did it (-2 = several waves).  Within one epoch an
+  // entry may be written and read by ONE wave (its LDS operations execute in order; the interpreter walks a wave's steps in
+  // stream order too); any other mix of a write with another access in the same epoch is a race.
   std::vector<int64_t> wr_epoch(tri ? xs_len : 0, -1), rd_epoch(tri ? xs_len : 0, -1);
+  std::vector<int> wr_wave(tri ? xs_len : 0, -1), rd_wave(tri ? xs_len : 0, -1);
   std::vector<std::vector<double>> acc(nw, std::vector<double>(64, 0.0));
+  // gathers issued ahead (MI_D_AHEAD on step q = the gather of step q + MI_D_LOOKAHEAD happens at step q): the values a
+  // later step will use are taken when the device takes them
+  std::vector<std::vector<std::vector<double>>> ahead(nw);
+  std::vector<uint32_t> ahead_first(nw, 0u);
   bool ok = true;
   int64_t cur = 0;
-  auto gather = [&](uint32_t e) { if (tri) { if (wr_epoch[e] == cur) ok = false; rd_epoch[e] = cur; } return xs[e]; };
-  auto store = [&](uint32_t e, double v) {
-    if (tri) { if (wr_epoch[e] == cur || rd_epoch[e] == cur) ok = false; wr_epoch[e] = cur; xs[e] = v; }
-    else out[e] = v;
+  auto gather = [&](int w, uint32_t e) {
+    if (tri) {
+      if (wr_epoch[e] == cur && wr_wave[e] != w) ok = false;
+      if (rd_epoch[e] != cur) { rd_epoch[e] = cur; rd_wave[e] = w; } else if (rd_wave[e] != w) rd_wave[e] = -2;
+    }
+    return xs[e];
+  };
+  auto store = [&](int w, uint32_t e, double v) {
+    if (tri) {
+      if (wr_epoch[e] == cur && wr_wave[e] != w) ok = false;
+      if (rd_epoch[e] == cur && rd_wave[e] != w) ok = false;
+      wr_epoch[e] = cur; wr_wave[e] = w; xs[e] = v;
+    } else out[e] = v;
   };
   for (;; cur++) {
     bool done = true;
@@ -1374,16 +1439,33 @@ static bool replay(const Schedule &s, const double *canon, double *xs, size_t xs
         epoch[w] += MI_D_NBAR(d);
         if (MI_D_TYPE(d) == MI_D_TYPE_ROW) {
           const uint32_t lt = MI_D_LT(d), T = 1u << lt;
+          std::vector<double> mine;
+          if (d & MI_D_PRE) {                                      // gathered MI_D_LOOKAHEAD steps ago
+            if (ahead[w].empty() || ahead_first[w] != st) return false;
+            mine = std::move(ahead[w].front()); ahead[w].erase(ahead[w].begin()); ahead_first[w] = st + 1;      // (consecutive PRE steps follow consecutive AHEAD steps)
+          }
+          if (d & MI_D_AHEAD) {
+            const uint32_t s2 = st + MI_D_LOOKAHEAD;
+            if (s2 >= s.wave_range[2 * w + 1] || !(s.step[s2] & MI_D_PRE) || MI_D_NBAR(s.step[s2])) return false;
+            std::vector<double> v(64, 0.0);
+            for (uint32_t ln = 0; ln < 64; ln++) { const uint32_t slot = s2 * 64 + ln; if (s.src[slot] != MI_SRC_ZERO) v[ln] = gather(w, s.idx[slot]); }
+            if (ahead[w].empty()) ahead_first[w] = s2;
+            ahead[w].push_back(std::move(v));
+          }
           for (uint32_t ln = 0; ln < 64; ln++) {
             const uint32_t slot = st * 64 + ln;
-            if (s.src[slot] != MI_SRC_ZERO) acc[w][ln] += (s.src[slot] == MI_SRC_ONE ? 1.0 : canon[s.src[slot]]) * gather(s.idx[slot]);
+            if (s.src[slot] != MI_SRC_ZERO)
+              acc[w][ln] += (s.src[slot] == MI_SRC_ONE ? 1.0 : canon[s.src[slot]]) * ((d & MI_D_PRE) ? mine[ln] : gather(w, s.idx[slot]));
           }
           if (d & MI_D_FLUSH) {
             for (uint32_t g = 0; g < 64 / T; g++) {
               double sum = 0.0;
               for (uint32_t ln = g * T; ln < (g + 1) * T; ln++) sum += acc[w][ln];
               const uint32_t row = s.outA[s.step_ob[st] + g];
-              if (row != kNoRow) store(row, (tri && !(d & MI_D_STORE)) ? xs[row] - sum : sum);
+              if (row != kNoRow) {
+                const bool sub = tri && !(d & MI_D_STORE);
+                store(w, row, sub ? gather(w, row) - sum : sum);
+              }
             }
             std::fill(acc[w].begin(), acc[w].end(), 0.0);
           }
