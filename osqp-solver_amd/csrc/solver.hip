@@ -660,10 +660,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if (h->st.adaptive_rho && !h->st.adaptive_rho_interval)   // deterministic "auto" (upstream non-PROFILING rule)
     h->st.adaptive_rho_interval = h->st.check_termination ? 4 * h->st.check_termination : 100;
   for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
-  {
-    const char *eth = getenv("MI_OSQP_THREADS");
-    h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 512;
-  }
+  const char *eth = getenv("MI_OSQP_THREADS");
+  h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 512;
   // ---- tile shape (needed by the schedule layout)
   // 2 QPs per tile: iterate_kernel<2> needs 112 VGPRs, so two 512-thread workgroups share a CU and
   // cover each other's barrier stalls; measured best on the 1024-QP headline batch (4 and 1 are slower)
@@ -679,6 +677,18 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   const size_t lds_cap = 160 * 1024 - 1024;      // (the kernels carry up to 272 B of static LDS of their own: a vector that fills
                                                  //  the 160 KB to the last byte - extra rows are handed out until it does - cannot launch)
   while (BT > 1 && lds_bytes((int)(n + m), BT, h->threads) > lds_cap) BT /= 2;
+  // 16 waves per tile where a tile has its CU to itself anyway - no more tiles than CUs, or a vector of more than half the
+  // LDS: 1 024 against 512 threads measured -10 % on 256 GOMP QPs (7 DOF x 100 waypoints), -18 % on 1 024 of them (2 per
+  // tile, 100 KB), -4..7 % on 128-QP shards of the headline batch; the headline batch itself (512 tiles of 40 KB: two
+  // 8-wave workgroups per CU cover each other's barrier stalls) stays at 8 waves
+  if (!eth && !wide && BT <= 2 && !getenv("MI_OSQP_GLOBAL_XS") && lds_bytes((int)(n + m), BT, 1024) <= lds_cap) {     // (16-wave kernels: 1 or 2 QPs per tile)
+    int dev = (int)device, cus = 256;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    (void)hipGetLastError();
+    const int64_t tiles = (B + BT - 1) / BT;
+    if (tiles <= cus || lds_bytes((int)(n + m), BT, 1024) > 80 * 1024) h->threads = 1024;
+  }
   // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
   h->global_xs = wide || lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
   // rows that may get a second vector position (phase B of the solves): what still fits LDS (analyze() also

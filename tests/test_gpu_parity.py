@@ -518,13 +518,17 @@ def test_solve_vector_that_fills_lds_to_the_budget(W):
 
 
 def test_sixteen_waves_per_tile_variant(monkeypatch):
-    """MI_OSQP_THREADS=1024: the 16-wave instantiations of the solve kernels (one workgroup per CU) walk
-    schedules built for 16 waves; results equal the default 8-wave run up to round-off, iteration counts exactly."""
+    """The 8-wave and 16-wave instantiations of the solve kernels (512 / 1 024 threads per tile; a batch with no more tiles
+    than CUs gets 16 waves by default) walk schedules built for their wave count; results equal up to round-off, iteration
+    counts exactly."""
     pr = PR.random_box_qp(10, n=96, mg=64, nnz_per_row=6)
     def run():
         s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
         info = s.solve()
         return s.stats()["threads_per_block"], [i.iter for i in info], s.primal().copy()
+    tdef, _, _ = run()
+    assert tdef == 1024                                      # 10 tiles on 256 CUs
+    monkeypatch.setenv("MI_OSQP_THREADS", "512")
     t8, it8, x8 = run()
     monkeypatch.setenv("MI_OSQP_THREADS", "1024")
     t16, it16, x16 = run()
@@ -540,11 +544,11 @@ def test_phase_trace_diagnostics_reproduce_the_op():
     same solution bit for bit and returns one (before, after) clock stamp pair per phase barrier and wave."""
     import torch
     pr = PR.random_box_qp(8, n=96, mg=64, nnz_per_row=6)
-    os.environ["MI_OSQP_TILE"] = "2"
+    os.environ["MI_OSQP_TILE"] = "2"; os.environ["MI_OSQP_THREADS"] = "512"       # (the shape the traced twin exists for)
     try:
         s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
     finally:
-        del os.environ["MI_OSQP_TILE"]
+        del os.environ["MI_OSQP_TILE"]; del os.environ["MI_OSQP_THREADS"]
     B, N = 8, pr["n"] + pr["m"]
     rhs = torch.randn(B, N, dtype=torch.float64, device="cuda")
     sol_t = torch.empty_like(rhs); sol_o = torch.empty_like(rhs)
