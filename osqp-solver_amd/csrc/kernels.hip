@@ -1658,13 +1658,15 @@ __device__ __forceinline__ void fct_trsm(const FactorArgs &a, double *Lb, const 
 template <int BT>
 __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   extern __shared__ double smem[];
-  // (one QP shared by the grid - single large QPs, 10^4 .. 10^5 block tasks: the grid is ONE tile, threads / waves are
-  //  numbered over the grid, the barriers between the phases of a level are grid barriers)
+  // (a QP shared by mw_groups consecutive workgroups - short work lists: a lone QP is a chain of latency-bound levels, and
+  //  the single large QPs have 10^4 .. 10^5 block tasks: threads / waves are numbered over the group, the barriers between
+  //  the phases of a level are barriers of the group, each group with its own counters)
   bool multi = false;
   if constexpr (BT == 1) multi = a.mw_groups > 1;
-  const Mw mw{a.mw_bar, multi ? (unsigned)a.mw_groups : 1u};
-  const int tile = multi ? 0 : blockIdx.x;
-  const int tid = multi ? blockIdx.x * blockDim.x + threadIdx.x : threadIdx.x, nthr = multi ? blockDim.x * mw.G : blockDim.x;
+  const unsigned G = multi ? (unsigned)a.mw_groups : 1u;
+  const int tile = (int)(blockIdx.x / G), gidx = (int)(blockIdx.x % G);
+  const Mw mw{a.mw_bar + 4 * (size_t)tile, G};
+  const int tid = gidx * (int)blockDim.x + (int)threadIdx.x, nthr = (int)(blockDim.x * G);
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6, b = tid % BT;
   auto sync = [&]() { if constexpr (BT == 1) wg_or_grid_barrier(mw); else __syncthreads(); };
   const int m = a.m, N = a.N;
@@ -1788,7 +1790,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
 template <int BT>
 static hipError_t launch_factor_t(const FactorArgs &a, int tiles, int threads, hipStream_t st) {
   const size_t lds = factor_lds_bytes(BT, threads);
-  if (a.mw_groups > 1) { if (BT != 1 || tiles != 1 || !a.mw_bar) return hipErrorInvalidValue; tiles = a.mw_groups; }
+  if (a.mw_groups > 1) { if (BT != 1 || !a.mw_bar) return hipErrorInvalidValue; tiles *= a.mw_groups; }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<BT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;

@@ -397,14 +397,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
   a.sigma = h->st.sigma; a.home_bt = h->BT; a.dt_k = an.dt.k;
-  // a handle with ONE QP of some size (the sequential GOMP driver's horizons, config 5): its 10^3 .. 10^5 block tasks are
-  // shared by several workgroups, with grid barriers between the phases of a level (3 x levels x ~6 us)
-  a.mw_groups = 0; a.mw_bar = h->mw_bar.p;
-  if (h->B == 1 && h->BT == 1 && h->mw_bar.p && an.N >= 3000) {
-    const char *eg = getenv("MI_OSQP_FACTOR_GROUPS");
-    // config 5 (ms): 1: 275, 8: 45, 16: 28, 32: 19, 64: 15, 128: 14
-    a.mw_groups = eg ? std::max(1, std::min(256, atoi(eg))) : std::max(4, std::min(64, an.N / 600));
-  }
+  a.mw_groups = 0; a.mw_bar = h->mw_bar.p;      // (device_refactor_slots decides how many workgroups share a QP)
 #ifdef MI_OSQP_DEBUG_BUILD
   { const char *e = getenv("MI_OSQP_FACTOR_SKIP"); a.debug_skip = e ? atoi(e) : 0; }      // timing experiments, diagnostic build only
 #endif
@@ -752,7 +745,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   ALLOC(Dsc, n); ALLOC(Dsc_inv, n); ALLOC(Esc, m); ALLOC(Esc_inv, m); ALLOC(dx, n); ALLOC(dy, m);
   ALLOC(out1, 2 * n + m); ALLOC(out2, 2 * n + m); ALLOC(dscal, DS_COUNT);
   if (h->global_xs) { ALLOC(xs_global, an.xs_total); }
-  if ((an.df || B == 1) && ((rc = h->mw_bar.alloc(4)) || (rc = h->mw_bar.zero(h->stream)))) return rc;
+  if ((rc = h->mw_bar.alloc(4 * (size_t)std::max(h->n_cus, 1))) || (rc = h->mw_bar.zero(h->stream))) return rc;      // (one set of barrier words per work tile)
   if (an.df && ((rc = h->rflag.upload(an.rflag)) || (rc = h->mw_scratch.alloc((size_t)8 * 256 * 16)) || (rc = h->mw_scratch.zero(h->stream)))) return rc;
   if (an.dt.k) {
     const DenseTail &dt = an.dt;
@@ -946,8 +939,18 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   if (h->work.n < work.size() && (rc = h->work.alloc((size_t)h->ntiles * BT + 4))) return rc;
   HIPCHK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   fa.work = h->work.p;
+  // Short work lists (the rho updates of the last few QPs of a batch, a strong-scaling shard, a handle with one QP): the
+  // block tasks of a QP are shared by several workgroups with barriers of the group between the phases of a level
+  // (3 x levels x ~6 us): one QP of config 5 (ms): 1: 275, 8: 45, 16: 28, 32: 19, 64: 15, 128: 14
+  if (kbt == 1 && h->mw_bar.p && (*h->anp).N >= 1000) {
+    const char *eg = getenv("MI_OSQP_FACTOR_GROUPS");
+    const int cap = h->B == 1 ? std::max(4, std::min(64, (*h->anp).N / 600)) : 8;
+    int G = eg ? std::max(1, std::min(256, atoi(eg))) : cap;
+    G = std::min(G, std::max(1, h->n_cus / wtiles));
+    fa.mw_groups = G > 1 ? G : 0;
+  }
   HIPCHK(hipEventRecord(h->evf0, h->stream));
-  if (fa.mw_groups > 1) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
+  if (fa.mw_groups > 1) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t) * (size_t)wtiles, h->stream));
   HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
   HIPCHK(hipEventRecord(h->evf1, h->stream));
   if ((*h->anp).dt.k) {      // the tail blocks now hold the Schur complement: invert it into the stream of the symmetric product
@@ -980,9 +983,10 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (fa.mw_groups > 1) {
-    uint32_t w[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(w, h->mw_bar.p, sizeof(w), hipMemcpyDeviceToHost));
-    if (w[2]) { g_last_error = "refactorisation on several workgroups: a grid barrier timed out"; return MI_OSQP_ERR_DEVICE; }
+    std::vector<uint32_t> w(4 * (size_t)wtiles, 0u);
+    HIPCHK(hipMemcpy(w.data(), h->mw_bar.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int t = 0; t < wtiles; t++)
+      if (w[4 * (size_t)t + 2]) { g_last_error = "refactorisation on several workgroups: a barrier of the group timed out"; return MI_OSQP_ERR_DEVICE; }
   }
   {
     float f = 0.f, d = 0.f;
