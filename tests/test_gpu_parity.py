@@ -442,6 +442,50 @@ def test_dataflow_form_on_a_small_qp_with_mostly_idle_waves(monkeypatch):
     _compare(info, s.primal(), _oracle_batch(pr, [0]), [0])
 
 
+def test_single_large_qp_infeasible_and_rho_updates_on_the_grid(monkeypatch):
+    """The exit paths of the grid-wide check_kernel (dataflow handles): a primal infeasible QP (certificate from the
+    reductions over all workgroups) and a solve with several rho updates (factor_kernel on several workgroups inside the
+    solve), both against the oracle: same exit code, same iteration count."""
+    monkeypatch.setenv("MI_OSQP_GLOBAL_XS", "1")        # a 40 x 40 grid through the single-large-QP path
+    pr = PR.grid_qp(40)
+    n = pr["n"]
+    l, u = pr["l"].copy(), pr["u"].copy()
+    # x0 in [1, 2], x1 in [-2, -1], but x1 - x0 in [0.5, 1] (row n of A = first difference row): no such point
+    l[0, 0], u[0, 0] = 1.0, 2.0
+    l[0, 1], u[0, 1] = -2.0, -1.0
+    l[0, n], u[0, n] = 0.5, 1.0
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], l, u)
+    info = s.solve()
+    P, A = PR.qp_matrices(pr, 0)
+    o = O.OracleQPSolver(P, pr["q"][0], A, l[0], u[0])
+    sto, _ = o.solve()
+    assert ST2EXIT[sto] == info[0].exit_code == M.EXIT_NAMES.index("kPrimalInfeasible") and info[0].iter == o.info().iter
+    assert np.all(np.isnan(s.primal()[0]))
+    # tight tolerances on the feasible problem: hundreds of iterations, rho adapts more than once
+    kw = dict(eps_abs=1e-7, eps_rel=1e-7)
+    s2 = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
+    i2 = s2.solve()
+    ref = _oracle_batch(pr, [0], **kw)
+    _compare(i2, s2.primal(), ref, [0])
+    assert i2[0].rho_updates >= 1 and i2[0].rho_updates == ref[0][2].rho_updates
+
+
+def test_refactorisation_shared_by_workgroup_groups_is_bitwise_the_single_workgroup_one(monkeypatch):
+    """Short work lists share each QP among several workgroups (factor_kernel, barriers of the group between the phases of
+    a level): same tasks, same arithmetic - bitwise the results of MI_OSQP_FACTOR_GROUPS=1."""
+    pr = PR.random_box_qp(1024)
+    for k in ("Px", "Ax", "q", "l", "u"): pr[k] = pr[k][:5]
+    def run():
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+        info = s.solve()
+        return [i.iter for i in info], [i.rho_updates for i in info], s.primal().copy(), s.dual().copy()
+    ita, rua, xa, ya = run()
+    monkeypatch.setenv("MI_OSQP_FACTOR_GROUPS", "1")
+    itb, rub, xb, yb = run()
+    assert ita == itb and rua == rub and max(rua) >= 1
+    np.testing.assert_array_equal(xa, xb); np.testing.assert_array_equal(ya, yb)
+
+
 def test_config5_literal_size_solves():
     """BASELINE config 5 at its literal size: n = 99 856, m = 298 936 (316 x 316 grid), N = 398 792, nnz(L) = 3.3 M.
     The oracle needs minutes here, so the check is size-independent: OSQP's own termination inequalities and the
