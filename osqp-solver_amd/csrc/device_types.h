@@ -143,6 +143,18 @@ hipError_t launch_swap_plain(double *base, const int2 *pairs, int npairs, int le
 hipError_t launch_swap_int(int *base, const int2 *pairs, int npairs, int len, int BT, hipStream_t st);
 hipError_t launch_swap_sched(double *base, const int2 *pairs, int npairs, const SchedDev &sd, int BT, hipStream_t st);
 hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, int BT, hipStream_t st);
+// Row E2 on the device (ruiz_kernel): new raw A values (and bounds) of every QP of the batch -> unscale, Ruiz rescale,
+// scaled bounds; one workgroup per QP, the arithmetic and its order are those of host_core.cpp scale_qp / unscale_qp.
+struct RuizArgs {
+  int n, m, nnzP, nnzA, B, BT, iters;
+  const int32_t *Prow, *Pcol, *Arow, *Acol;   // per entry of triu(P) / A: row, column
+  const double *rawA;                        // [B][nnzA] new values of A (natural CSC order)
+  const double *rawl, *rawu;                 // [B][m] new bounds, or null: keep the bounds (unscale, rescale)
+  double *pa_val, *q, *Dsc, *Dsc_inv, *Esc, *Esc_inv, *l, *u, *dscal;      // tile-interleaved state of the handle
+  double *dn, *en;                           // scratch [B][n], [B][m]
+  double *pa_out;                            // [B][nnzP + nnzA]: the scaled values once more, QP-major (for the check-stream scatter)
+};
+hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st);
 hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
 hipError_t launch_fail_slots(const KernelArgs &a, const int *slots, int nfail, int BT, int iter, hipStream_t st);
 hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,

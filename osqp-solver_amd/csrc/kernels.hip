@@ -2375,6 +2375,114 @@ __global__ void bounds_kernel(const double *__restrict__ gl, const double *__res
   if (want != rho_vec[e]) atomicOr(changed, 1);
 }
 
+// ---- row E2 on the device: Ruiz equilibration of [[P, A'],[A, 0]] + cost normalisation after new A values ------------
+// One workgroup per QP.  Same operations in the same order as host_core.cpp unscale_qp / scale_qp (and the oracle):
+// infinity norms are maxima (exact in any order: atomic max on the bit patterns of non-negative doubles), every product is a
+// separate multiplication, square roots and reciprocals are the correctly rounded ones, and the one sum (the mean column
+// norm of P) is added up by one thread in index order - so the result equals the host's bit for bit.
+__device__ __forceinline__ double ruiz_limit(double v) { v = v < 1e-4 ? 1.0 : v; return v > 1e4 ? 1e4 : v; }
+__device__ __forceinline__ void ruiz_amax(double *p, double a) {
+  atomicMax(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(a));
+}
+__global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
+  __shared__ double s_red[16];
+  const int qp = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int n = a.n, m = a.m, nnzP = a.nnzP, nnzA = a.nnzA, pa_len = nnzP + nnzA;
+  const size_t tile = (size_t)(qp / a.BT), b = (size_t)(qp % a.BT), BT = (size_t)a.BT;
+  auto H = [&](size_t len, size_t i) { return (tile * len + i) * BT + b; };
+  double *dn = a.dn + (size_t)qp * n, *en = a.en + (size_t)qp * m;
+  const double *rawA = a.rawA + (size_t)qp * nnzA;
+  // (dn / en are updated by atomics, which execute in L2: they are read and reset past the CU's L1 as well)
+  auto ld = [](const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st0 = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  double c = a.dscal[H(DS_COUNT, DS_C)];
+  const double cinv0 = a.dscal[H(DS_COUNT, DS_CINV)];
+  // ---- unscale P and q with the scaling in force; A is replaced; the bounds are replaced or unscaled
+  for (int k = tid; k < nnzP; k += nthr) {
+    double v = a.pa_val[H(pa_len, k)];
+    v *= cinv0; v *= a.Dsc_inv[H(n, a.Prow[k])]; v *= a.Dsc_inv[H(n, a.Pcol[k])];
+    a.pa_val[H(pa_len, k)] = v;
+  }
+  for (int j = tid; j < n; j += nthr) a.q[H(n, j)] *= cinv0 * a.Dsc_inv[H(n, j)];
+  for (int k = tid; k < nnzA; k += nthr) a.pa_val[H(pa_len, nnzP + k)] = rawA[k];
+  for (int i = tid; i < m; i += nthr) {
+    double lo, up;
+    if (a.rawl) { lo = fmax(a.rawl[(size_t)qp * m + i], -MI_INFTY); up = fmin(a.rawu[(size_t)qp * m + i], MI_INFTY); }
+    else { const double ei = a.Esc_inv[H(m, i)]; lo = a.l[H(m, i)] * ei; up = a.u[H(m, i)] * ei; }
+    a.l[H(m, i)] = lo; a.u[H(m, i)] = up;
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += nthr) a.Dsc[H(n, j)] = 1.0;
+  for (int i = tid; i < m; i += nthr) a.Esc[H(m, i)] = 1.0;
+  c = 1.0;
+  __syncthreads();
+  auto p_norms = [&]() {                  // dn = column infinity norms of the symmetric P (upper triangle stored)
+    for (int j = tid; j < n; j += nthr) st0(&dn[j], 0.0);
+    __syncthreads();
+    for (int k = tid; k < nnzP; k += nthr) {
+      const double v = fabs(a.pa_val[H(pa_len, k)]);
+      const int i = a.Prow[k], j = a.Pcol[k];
+      ruiz_amax(&dn[j], v);
+      if (i != j) ruiz_amax(&dn[i], v);
+    }
+  };
+  for (int it = 0; it < a.iters; it++) {
+    for (int i = tid; i < m; i += nthr) st0(&en[i], 0.0);
+    p_norms();
+    for (int k = tid; k < nnzA; k += nthr) {
+      const double v = fabs(a.pa_val[H(pa_len, nnzP + k)]);
+      ruiz_amax(&dn[a.Acol[k]], v);
+      ruiz_amax(&en[a.Arow[k]], v);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nthr) st0(&dn[j], 1.0 / sqrt(ruiz_limit(ld(&dn[j]))));
+    for (int i = tid; i < m; i += nthr) st0(&en[i], 1.0 / sqrt(ruiz_limit(ld(&en[i]))));
+    __syncthreads();
+    for (int k = tid; k < nnzP; k += nthr) { double v = a.pa_val[H(pa_len, k)]; v *= ld(&dn[a.Prow[k]]); v *= ld(&dn[a.Pcol[k]]); a.pa_val[H(pa_len, k)] = v; }
+    for (int k = tid; k < nnzA; k += nthr) { double v = a.pa_val[H(pa_len, nnzP + k)]; v *= ld(&en[a.Arow[k]]); v *= ld(&dn[a.Acol[k]]); a.pa_val[H(pa_len, nnzP + k)] = v; }
+    for (int j = tid; j < n; j += nthr) { const double d = ld(&dn[j]); a.q[H(n, j)] *= d; a.Dsc[H(n, j)] *= d; }
+    for (int i = tid; i < m; i += nthr) a.Esc[H(m, i)] *= ld(&en[i]);
+    __syncthreads();
+    // cost normalisation: c = 1 / max(mean column norm of P, |q|_inf), both limited
+    p_norms();
+    double nq = 0.0;
+    for (int j = tid; j < n; j += nthr) nq = fmax(nq, fabs(a.q[H(n, j)]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nq = fmax(nq, shfl_xor_d(nq, off));
+    if (lane == 0) s_red[wave] = nq;
+    __syncthreads();                       // (also: the norms of P are complete)
+    if (tid == 0) {
+      double mean = 0.0;
+      for (int j = 0; j < n; j++) mean += ld(&dn[j]);      // index order, like the host
+      mean /= (double)n;
+      double q1 = s_red[0];
+      for (int w = 1; w < nw; w++) q1 = fmax(q1, s_red[w]);
+      q1 = ruiz_limit(q1);
+      double ct = ruiz_limit(fmax(mean, q1));
+      s_red[15] = 1.0 / ct;
+    }
+    __syncthreads();
+    const double ct = s_red[15];
+    for (int k = tid; k < nnzP; k += nthr) a.pa_val[H(pa_len, k)] *= ct;
+    for (int j = tid; j < n; j += nthr) a.q[H(n, j)] *= ct;
+    c *= ct;
+    __syncthreads();
+  }
+  for (int j = tid; j < n; j += nthr) a.Dsc_inv[H(n, j)] = 1.0 / a.Dsc[H(n, j)];
+  for (int i = tid; i < m; i += nthr) {
+    const double e = a.Esc[H(m, i)];
+    a.Esc_inv[H(m, i)] = 1.0 / e;
+    a.l[H(m, i)] *= e; a.u[H(m, i)] *= e;
+  }
+  if (tid == 0) { a.dscal[H(DS_COUNT, DS_C)] = c; a.dscal[H(DS_COUNT, DS_CINV)] = 1.0 / c; }
+  for (int k = tid; k < pa_len; k += nthr) a.pa_out[(size_t)qp * pa_len + k] = a.pa_val[H(pa_len, k)];
+}
+hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
+  if (a.B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ruiz_kernel, dim3(a.B), dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+
 // --------------------------------------------------------------- launchers
 
 // all iterate kernels are built for <= 512 threads per workgroup (256 VGPRs per lane

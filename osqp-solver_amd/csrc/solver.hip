@@ -294,6 +294,8 @@ struct mi_osqp_batch {
   int sp_npass = 0;
   uint32_t sp_ell_off[4] = {0, 0, 0, 0}, sp_ell_k[4] = {0, 0, 0, 0};
   bool host_rho_stale = false;
+  bool host_scaling_stale = false;      // the device has re-equilibrated (ruiz_kernel): P, A, q, D, E, c of the host mirrors lag behind
+  DevBuf<int32_t> rz_prow, rz_pcol, rz_arow, rz_acol;      // per entry of triu(P) / A: row, column (row E2 on the device)
   bool clear_rho_updates = true;          // the next solve starts counting rho updates from 0 (setup / update_* / reset happened)
   int *h_npos = nullptr;
   DevBuf<double> stage; DevBuf<int> ids, work;
@@ -739,6 +741,11 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if ((rc = h->fwd.upload(an.fwd)) || (rc = h->bwd.upload(an.bwd)) || (rc = h->chk.upload(an.chk))) return rc;
   { std::vector<uint32_t> pv(an.pinv.begin(), an.pinv.end()); if ((rc = h->pinv.upload(pv))) return rc; }
   { std::vector<uint32_t> xv(an.xloc.begin(), an.xloc.end()); if ((rc = h->xloc.upload(xv))) return rc; }
+  {
+    std::vector<int32_t> pr(an.Pi.begin(), an.Pi.begin() + an.Pp[n]), pc(an.Pp[n]), ar(an.Ai.begin(), an.Ai.begin() + an.Ap[n]), ac(an.Ap[n]);
+    for (int j = 0; j < n; j++) { for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) pc[k] = j; for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) ac[k] = j; }
+    if ((rc = h->rz_prow.upload(pr)) || (rc = h->rz_pcol.upload(pc)) || (rc = h->rz_arow.upload(ar)) || (rc = h->rz_acol.upload(ac))) return rc;
+  }
 #define ALLOC(buf, len) if ((rc = h->buf.alloc((size_t)(len) * T)) || (rc = h->buf.zero(h->stream))) return rc
   ALLOC(fwd_val, (size_t)an.fwd.phys_steps() * 64); ALLOC(bwd_val, (size_t)an.bwd.phys_steps() * 64); ALLOC(chk_val, (size_t)an.chk.phys_steps() * 64); ALLOC(dinv, an.N);
   ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
@@ -1376,6 +1383,7 @@ int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
 }
 
 static int update_bounds_on_host(mi_osqp_batch *h, const double *l, const double *u);
+static int ensure_mirrors(mi_osqp_batch *h);
 static int update_bounds_on_device(mi_osqp_batch *h, const double *d_l, const double *d_u, hipStream_t s, const double *h_l, const double *h_u);
 
 int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double *u) {
@@ -1394,6 +1402,7 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
 }
 
 static int update_bounds_on_host(mi_osqp_batch *h, const double *l, const double *u) {
+  { int rc0 = ensure_mirrors(h); if (rc0) return rc0; }
   h->clear_rho_updates = true;
   const Analysis &an = (*h->anp);
   int m = an.m, B = h->B, rc;
@@ -1452,10 +1461,88 @@ static int update_bounds_on_device(mi_osqp_batch *h, const double *d_l, const do
 
 static int update_A_values(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av);
 
+// The host mirrors of the scaled problem after the device has re-equilibrated: fetched when a host path needs them
+// (a bounds update that changes row types, MI_OSQP_HOST_RUIZ).
+static int ensure_mirrors(mi_osqp_batch *h) {
+  if (!h->host_scaling_stale) return 0;
+  const Analysis &an = (*h->anp);
+  const int n = an.n, m = an.m, B = h->B, nnzP = an.Pp[n], nnzA = an.Ap[n], pa_len = nnzP + nnzA;
+  int rc;
+  if ((rc = ensure_stage(h, (size_t)B * std::max({pa_len, n, m, 1}) + 1, 0))) return rc;
+  std::vector<double> tmp;
+  auto down = [&](const double *src, int len) -> int {
+    tmp.resize((size_t)B * len);
+    if (!len) return 0;
+    HIPCHK(launch_deinterleave(src, h->stage.p, B, len, h->BT, h->stream));
+    HIPCHK(hipMemcpyAsync(tmp.data(), h->stage.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  };
+  if ((rc = down(h->pa_val.p, pa_len))) return rc;
+  for (int q = 0; q < B; q++) {
+    std::copy(tmp.begin() + (size_t)q * pa_len, tmp.begin() + (size_t)q * pa_len + nnzP, h->qp[q].Pv.begin());
+    std::copy(tmp.begin() + (size_t)q * pa_len + nnzP, tmp.begin() + (size_t)(q + 1) * pa_len, h->qp[q].Av.begin());
+  }
+  if ((rc = down(h->q.p, n))) return rc;
+  for (int q = 0; q < B; q++) std::copy(tmp.begin() + (size_t)q * n, tmp.begin() + (size_t)(q + 1) * n, h->qp[q].q.begin());
+  if ((rc = down(h->Dsc.p, n))) return rc;
+  for (int q = 0; q < B; q++) for (int j = 0; j < n; j++) { h->qp[q].D[j] = tmp[(size_t)q * n + j]; h->qp[q].Dinv[j] = 1.0 / h->qp[q].D[j]; }
+  if ((rc = down(h->Esc.p, m))) return rc;
+  for (int q = 0; q < B; q++) for (int i = 0; i < m; i++) { h->qp[q].E[i] = tmp[(size_t)q * m + i]; h->qp[q].Einv[i] = 1.0 / h->qp[q].E[i]; }
+  const size_t dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
+  for (int q = 0; q < B; q++) {
+    h->qp[q].c = h->h_dscal[(size_t)(q / h->BT) * DS_COUNT * h->BT + DS_C * h->BT + q % h->BT];
+    h->qp[q].cinv = 1.0 / h->qp[q].c;
+  }
+  h->host_scaling_stale = false;
+  h->host_bounds_stale = true;
+  if ((rc = sync_bounds_to_host(h))) return rc;
+  for (int q = 0; q < B; q++) (void)refresh_rho_types(an, h->qp[q]);
+  h->host_rho_stale = true;
+  return sync_rho_to_host(h);
+}
+
+// Row E13's A / bounds update with row E2 on the device: raw values through pinned memory, ruiz_kernel (unscale, new A,
+// equilibrate, scale the bounds), the check streams re-scattered, ONE refactorisation of every QP.  l / u null: bounds kept.
+static int device_update(mi_osqp_batch *h, const double *Av, const double *l, const double *u) {
+  const Analysis &an = (*h->anp);
+  const int n = an.n, m = an.m, B = h->B, nnzP = an.Pp[n], nnzA = an.Ap[n], pa_len = nnzP + nnzA;
+  h->clear_rho_updates = true;
+  const size_t cA = (size_t)B * nnzA, cb = l ? (size_t)B * m : 0, cpa = (size_t)B * pa_len;
+  int rc;
+  if ((rc = ensure_pin(h, cA + 2 * cb + 1)) || (rc = ensure_stage(h, cA + 2 * cb + cpa + 1, (size_t)B))) return rc;
+  par_copy(h->pin, Av, cA);
+  if (l) { par_copy(h->pin + cA, l, cb); par_copy(h->pin + cA + cb, u, cb); }
+  HIPCHK(hipMemcpyAsync(h->stage.p, h->pin, (cA + 2 * cb) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RuizArgs r{};
+  r.n = n; r.m = m; r.nnzP = nnzP; r.nnzA = nnzA; r.B = B; r.BT = h->BT; r.iters = (int)h->st.scaling;
+  r.Prow = h->rz_prow.p; r.Pcol = h->rz_pcol.p; r.Arow = h->rz_arow.p; r.Acol = h->rz_acol.p;
+  r.rawA = h->stage.p; r.rawl = l ? h->stage.p + cA : nullptr; r.rawu = l ? h->stage.p + cA + cb : nullptr;
+  r.pa_val = h->pa_val.p; r.q = h->q.p; r.Dsc = h->Dsc.p; r.Dsc_inv = h->Dsc_inv.p; r.Esc = h->Esc.p; r.Esc_inv = h->Esc_inv.p;
+  r.l = h->l.p; r.u = h->u.p; r.dscal = h->dscal.p;
+  r.dn = h->out1.p; r.en = h->out1.p + (size_t)B * n;              // (scratch of check_kernel: (2n + m) doubles per QP)
+  r.pa_out = h->stage.p + cA + 2 * cb;
+  HIPCHK(launch_ruiz(r, h->stream));
+  std::vector<int> ids(B);
+  for (int i = 0; i < B; i++) ids[i] = i;
+  HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(launch_scatter(r.pa_out, h->chk_val.p, h->chk.src.p, h->ids.p, B, pa_len, h->chk.view(an.chk), h->BT, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->host_scaling_stale = true; h->host_bounds_stale = true; h->host_rho_stale = true;
+  if ((rc = refactor_qps(h, std::move(ids)))) return rc;          // (factor_kernel derives the rho vectors from the bounds in force)
+  return snapshot(h);
+}
+static bool host_ruiz() { return getenv("MI_OSQP_HOST_RUIZ") != nullptr; }
+
 int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
   CallTimer timer_("batch_update_A");
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  const Analysis &an = (*h->anp);
+  for (int j = 0; j <= an.n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
+  for (int k = 0; k < an.Ap[an.n]; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
+  if (!host_ruiz()) return device_update(h, Av, nullptr, nullptr);
   int rc = update_A_values(h, Ap, Ai, Av);
   if (rc || (rc = mi_osqp_batch_refactor_device(h))) return rc;
   return snapshot(h);
@@ -1469,6 +1556,9 @@ int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *Ap, const int
   const Analysis &an = (*h->anp);
   const int m = an.m, B = h->B;
   for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  for (int j = 0; j <= an.n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
+  for (int k = 0; k < an.Ap[an.n]; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
+  if (!host_ruiz()) return device_update(h, Av, l, u);
   int rc = update_A_values(h, Ap, Ai, Av);        // (the host mirrors are authoritative from here on)
   if (rc) return rc;
   for (int q = 0; q < B; q++) {
@@ -1486,6 +1576,7 @@ int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *Ap, const int
 }
 
 static int update_A_values(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av) {
+  { int rc0 = ensure_mirrors(h); if (rc0) return rc0; }
   h->clear_rho_updates = true;
   const Analysis &an = (*h->anp);
   int n = an.n, B = h->B, nnzA = an.Ap[n], rc;

@@ -244,6 +244,36 @@ def test_update_of_values_and_bounds_in_one_call_equals_the_two_calls():
         assert ib[b].iter == o.info().iter and np.max(np.abs(xb[b] - xo)) <= TOL_X
 
 
+@pytest.mark.parametrize("tile", [1, 2])
+def test_ruiz_on_the_device_equals_the_host_equilibration_bitwise(tile, monkeypatch):
+    """Row E2 after new A values runs on the device (ruiz_kernel: maxima by atomics, separate multiplications, one sum in
+    index order); MI_OSQP_HOST_RUIZ=1 keeps the host path (scale_qp) - same iterates bit for bit, with and without new
+    bounds, scaling on and off, GOMP pattern (many all-zero rows with infinite bounds) and random pattern."""
+    monkeypatch.setenv("MI_OSQP_TILE", str(tile))
+    rng = np.random.default_rng(21)
+    cases = [(PR.random_box_qp(5, n=64, mg=48, nnz_per_row=4), {}), (PR.random_box_qp(3, n=64, mg=48, nnz_per_row=4), dict(scaling=0)),
+             (PR.gomp_batch(4, 3, 12), {})]
+    for pr, kw in cases:
+        Ax2 = pr["Ax"] * (1.0 + 0.2 * rng.standard_normal(pr["Ax"].shape))
+        l2, u2 = pr["l"] - 0.05 * np.abs(pr["l"]), pr["u"] + 0.05 * np.abs(pr["u"])
+        res = []
+        for host in (False, True):
+            if host: monkeypatch.setenv("MI_OSQP_HOST_RUIZ", "1")
+            else: monkeypatch.delenv("MI_OSQP_HOST_RUIZ", raising=False)
+            s = M.BatchSolver(pr["P"], pr["Px"], pr.get("q"), pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
+            s.solve()
+            s.update_A_bounds(Ax2, l2, u2)
+            i1 = s.solve(); x1, y1 = s.primal().copy(), s.dual().copy()
+            s.update_A(pr["Ax"])                                   # values back, bounds kept
+            i2 = s.solve(); x2 = s.primal().copy()
+            s.update_bounds(pr["l"], pr["u"])                      # (host mirrors are fetched from the device if a row changes type)
+            i3 = s.solve(); x3 = s.primal().copy()
+            res.append(([i.iter for i in i1], x1, y1, [i.iter for i in i2], x2, [i.iter for i in i3], x3))
+        dev, hst = res
+        assert dev[0] == hst[0] and dev[3] == hst[3] and dev[5] == hst[5]
+        for k in (1, 2, 4, 6): np.testing.assert_array_equal(dev[k], hst[k])
+
+
 def test_headline_config_properties_full_size():
     """BASELINE config 3 at full size (B=1024, n=512, m=1024): size-independent
     properties for every QP + oracle parity on a sample."""
