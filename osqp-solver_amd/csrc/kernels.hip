@@ -2386,6 +2386,7 @@ __device__ __forceinline__ void ruiz_amax(double *p, double a) {
 }
 __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
   __shared__ double s_red[16];
+  __shared__ double s_stage[2048];
   const int qp = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int n = a.n, m = a.m, nnzP = a.nnzP, nnzA = a.nnzA, pa_len = nnzP + nnzA;
   const size_t tile = (size_t)(qp / a.BT), b = (size_t)(qp % a.BT), BT = (size_t)a.BT;
@@ -2451,9 +2452,16 @@ __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
     for (int off = 1; off < 64; off <<= 1) nq = fmax(nq, shfl_xor_d(nq, off));
     if (lane == 0) s_red[wave] = nq;
     __syncthreads();                       // (also: the norms of P are complete)
+    // the mean column norm: added up in index order like the host does, by one thread, from LDS (staged by everybody)
+    double mean = 0.0;
+    for (int base = 0; base < n; base += 2048) {
+      const int cnt = min(2048, n - base);
+      for (int j = tid; j < cnt; j += nthr) s_stage[j] = ld(&dn[base + j]);
+      __syncthreads();
+      if (tid == 0) for (int j = 0; j < cnt; j++) mean += s_stage[j];
+      __syncthreads();
+    }
     if (tid == 0) {
-      double mean = 0.0;
-      for (int j = 0; j < n; j++) mean += ld(&dn[j]);      // index order, like the host
       mean /= (double)n;
       double q1 = s_red[0];
       for (int w = 1; w < nw; w++) q1 = fmax(q1, s_red[w]);

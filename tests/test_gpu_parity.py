@@ -258,8 +258,8 @@ def test_ruiz_on_the_device_equals_the_host_equilibration_bitwise(tile, monkeypa
         l2, u2 = pr["l"] - 0.05 * np.abs(pr["l"]), pr["u"] + 0.05 * np.abs(pr["u"])
         res = []
         for host in (False, True):
-            if host: monkeypatch.setenv("MI_OSQP_HOST_RUIZ", "1")
-            else: monkeypatch.delenv("MI_OSQP_HOST_RUIZ", raising=False)
+            monkeypatch.delenv("MI_OSQP_DEVICE_RUIZ" if host else "MI_OSQP_HOST_RUIZ", raising=False)
+            monkeypatch.setenv("MI_OSQP_HOST_RUIZ" if host else "MI_OSQP_DEVICE_RUIZ", "1")      # (small batches default to the host)
             s = M.BatchSolver(pr["P"], pr["Px"], pr.get("q"), pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
             s.solve()
             s.update_A_bounds(Ax2, l2, u2)
