@@ -14,12 +14,16 @@ for trial in range(int(os.environ.get("TRIALS", "24"))):
     NMAX = int(os.environ.get("NMAX", "220"))
     n = int(rng.integers(3, NMAX)); mg = int(rng.integers(1, NMAX + 40)); nnz = int(rng.integers(1, min(n, 12) + 1))
     B = int(rng.integers(1, 7))
-    tile = int(rng.choice([1, 2, 4])); thr = int(rng.choice([128, 256, 512, 1024]))
+    tile = int(rng.choice([1, 2, 4])); thr = int(rng.choice([0, 128, 256, 512, 1024]))      # 0: the default thread count
     if thr == 1024 and tile == 4: thr = 512
     os.environ["MI_OSQP_TILE"] = str(tile); os.environ["MI_OSQP_THREADS"] = str(thr)
+    if thr == 0: os.environ.pop("MI_OSQP_THREADS")
     if rng.random() < 0.25: os.environ["MI_OSQP_GLOBAL_XS"] = "1"
     else: os.environ.pop("MI_OSQP_GLOBAL_XS", None)
     if os.environ.get("MI_OSQP_GLOBAL_XS") and thr == 1024: thr = 512; os.environ["MI_OSQP_THREADS"] = "512"
+    # (a single QP with a global vector takes the dataflow path; half of those runs use few, odd group shapes)
+    os.environ.pop("MI_OSQP_GROUPS", None); os.environ.pop("MI_OSQP_GROUP_THREADS", None)
+    if rng.random() < 0.5: os.environ["MI_OSQP_GROUPS"] = str(int(rng.choice([1, 3, 7, 32]))); os.environ["MI_OSQP_GROUP_THREADS"] = str(int(rng.choice([64, 192, 512])))
     pr = PR.random_box_qp(B, n=n, mg=mg, nnz_per_row=nnz, pattern_seed=int(rng.integers(1 << 30)))
     eps = float(rng.choice([1e-3, 1e-6]))
     kw = dict(eps_abs=eps, eps_rel=eps)

@@ -38,7 +38,11 @@ for trial in range(int(os.environ.get("TRIALS", "40"))):
     if rng.random() < 0.5: e = float(10 ** rng.uniform(-7, -2)); kw["eps_abs"] = e; kw["eps_rel"] = e
     if rng.random() < 0.2: kw["scaled_termination"] = 1
     os.environ["MI_OSQP_TILE"] = str(int(rng.choice([1, 2, 4])))
-    seq = rng.choice(["solve", "solve2", "warm", "updA", "bounds"])
+    # round 2: equilibration of the update path on the device / on the host; a single QP through the dataflow path
+    os.environ.pop("MI_OSQP_DEVICE_RUIZ", None); os.environ.pop("MI_OSQP_HOST_RUIZ", None); os.environ.pop("MI_OSQP_GLOBAL_XS", None)
+    os.environ["MI_OSQP_DEVICE_RUIZ" if rng.random() < 0.6 else "MI_OSQP_HOST_RUIZ"] = "1"
+    if B == 1 and rng.random() < 0.5: os.environ["MI_OSQP_GLOBAL_XS"] = "1"; os.environ["MI_OSQP_TILE"] = "1"
+    seq = rng.choice(["solve", "solve2", "warm", "updA", "updAB", "bounds"])
     try:
         s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
         Ax2 = pr["Ax"] * (1.0 + 0.05 * np.sin(np.arange(pr["Ax"].shape[1])))[None, :]
@@ -47,6 +51,7 @@ for trial in range(int(os.environ.get("TRIALS", "40"))):
         info = s.solve()
         if seq == "solve2": info = s.solve()
         if seq == "updA": s.update_A(Ax2); info = s.solve()
+        if seq == "updAB": s.update_A_bounds(Ax2, pr["l"] - 0.05, pr["u"] + 0.05); info = s.solve()
         if seq == "bounds": s.update_bounds(pr["l"] - 0.05, pr["u"] + 0.05); info = s.solve()
         x = s.primal()
     except Exception as ex:
@@ -63,6 +68,8 @@ for trial in range(int(os.environ.get("TRIALS", "40"))):
         if seq == "solve2": st, xo = o.solve()
         if seq == "updA":
             A2 = A.copy(); A2.data = Ax2[b].copy(); o.update(pr["l"][b], A2, pr["u"][b]); st, xo = o.solve()
+        if seq == "updAB":
+            A2 = A.copy(); A2.data = Ax2[b].copy(); o.update(pr["l"][b] - 0.05, A2, pr["u"][b] + 0.05); st, xo = o.solve()
         if seq == "bounds": o.update_bounds_only(pr["l"][b] - 0.05, pr["u"][b] + 0.05); st, xo = o.solve()
         io = o.info()
         tol = 1e-3 if st in (-2, 2) else 1e-6
