@@ -1250,7 +1250,11 @@ int mi_osqp_batch_solve(mi_osqp_batch *h) {
   CallTimer timer_("batch_solve");
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
-  return solve_impl(h, nullptr, nullptr);
+  const int rc = solve_impl(h, nullptr, nullptr);
+  if (CallTimer::on() && getenv("MI_OSQP_DEBUG_SOLVES"))
+    fprintf(stderr, "[mi_osqp] solve B=%d N=%d: %ld segments of <= 25 iterations, %.0f QP-iterations in total, iterate %.2f ms, refactor %.2f ms (%ld)\n", h->B,
+            (*h->anp).N, (long)h->last_launches, (double)h->last_total_iters, 1e3 * h->last_device_s, 1e3 * h->last_refactor_s, (long)h->last_refactors);
+  return rc;
 }
 
 int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream) {

@@ -9,4 +9,5 @@ g++ -std=c++17 -O2 -Iinclude tests/cpp/gomp_parity.cpp -o gpurun_out/gomp_parity
 out="${1:-gpurun_out/gomp_bench.txt}"
 : > "$out"
 for i in 1 2 3; do timeout -k 10 300 gpurun_out/gomp_parity bench 2>&1 | tee -a "$out"; done
+timeout -k 10 600 gpurun_out/gomp_parity obstbench 2>&1 | tee -a "$out"
 MI_OSQP_DEBUG_TIMING=1 timeout -k 10 300 gpurun_out/gomp_parity bench 2>&1 | grep -v "setup: ordering\|^\[mi_osqp\] setup" | tee -a "$out"

@@ -367,6 +367,55 @@ static int run_ur5e(int W) {
   std::printf(fails ? "UR5E FAILED (%d)\n" : "UR5E OK\n", fails);
   return fails ? 1 : 0;
 }
+// The batched driver on a scene WITH an obstacle (3-link arm, one collision ball, a bar to pass above, a floor): every SQP
+// step re-linearises the obstacle rows, i.e. QPSolver::update on the whole batch (new A values + bounds: equilibration and
+// refactorisation on the device) before the next batched solve.   gomp_parity obstbench [trajectories] [waypoints] [sample]
+static int run_obstacle_bench(int B, int W, int sample) {
+  const double pi = 3.14159265358979323846;
+  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}};
+  std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
+  auto pos = constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi));
+  auto vel = constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi));
+  auto acc = constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180));
+  auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF});
+  std::vector<Ctrl<3>> starts, ends;
+  std::mt19937_64 rng(4242);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  for (int b = 0; b < B; ++b) {
+    starts.push_back({-0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+    ends.push_back({0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+  }
+  using clk = std::chrono::steady_clock;
+  { BatchGOMPSolver<3> warm(40, 0.1, pos, vel, acc, c3d, lines, balls); (void)warm.run({starts[0]}, {ends[0]}); }
+  BatchGOMPSolver<3> bg((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls);
+  auto t0 = clk::now();
+  auto r1 = bg.run(starts, ends);
+  const double t1 = std::chrono::duration<double>(clk::now() - t0).count();
+  t0 = clk::now();
+  auto r2 = bg.run(starts, ends);
+  const double t2 = std::chrono::duration<double>(clk::now() - t0).count();
+  int ok = 0, solves = 0, updates = 0;
+  for (int b = 0; b < B; ++b) { ok += r2[b].first == ExitCode::kOptimal; solves += bg.qp_solves[b]; updates += bg.qp_updates[b]; CHECK(r2[b].first == r1[b].first); CHECK(r2[b].second == r1[b].second); }
+  std::printf("batched driver with an obstacle: %d trajectories (D=3, W=%d): first run %.3f s, second run %.3f s = %.1f trajectories/s; %d QP solves, %d updates in %d batched solves, %d optimal\n",
+              B, W, t1, t2, B / t2, solves, updates, bg.batch_solves, ok);
+  std::printf("  of which: building constraints %.3f s, QP setup %.3f s, batched solves %.3f s, checks + re-linearisation + updates %.3f s\n",
+              bg.seconds_build, bg.seconds_setup, bg.seconds_solve, bg.seconds_update);
+  sample = std::min(sample, B);
+  t0 = clk::now();
+  double md = 0.0;
+  for (int b = 0; b < sample; ++b) {
+    GOMPSolver<3, OracleQPSolver> o((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+    auto [code, x] = o.run(starts[b], ends[b]);
+    CHECK(code == r2[b].first); CHECK(o.qp_solves == bg.qp_solves[b] && o.qp_updates == bg.qp_updates[b]);
+    if (x.size() == r2[b].second.size()) for (size_t k = 0; k < x.size(); ++k) md = std::fmax(md, std::fabs(x[k] - r2[b].second[k]));
+  }
+  const double to = std::chrono::duration<double>(clk::now() - t0).count();
+  CHECK(md <= 1e-6);
+  std::printf("sequential driver on the oracle (1 thread): %d trajectories: %.3f s = %.1f trajectories/s; max|dx| vs batch %.3e\n", sample, to, sample / to, md);
+  std::printf(fails ? "OBSTBENCH FAILED (%d)\n" : "OBSTBENCH OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 // The reference's example program ([REF] examples/solver-example.cpp:12-16,44-70: UR5e, joint 1 by pi, two balls, y >= -0.4)
 // as its sequential driver runs it - one trajectory, one QP at a time - on the GPU QPSolver and on the oracle backend
 // (one CPU thread): wall time of run() and the difference of the trajectories.   gomp_parity example [waypoints]
@@ -407,6 +456,8 @@ static int run_example(int W) {
 
 int main(int argc, char **argv) {
   if (argc > 1 && !std::strcmp(argv[1], "example")) return run_example(argc > 2 ? std::atoi(argv[2]) : 802);
+  if (argc > 1 && !std::strcmp(argv[1], "obstbench"))
+    return run_obstacle_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "kats")) return run_kats();
   if (argc > 1 && !std::strcmp(argv[1], "ur5e")) return run_ur5e(argc > 2 ? std::atoi(argv[2]) : 22);
   if (argc > 1 && !std::strcmp(argv[1], "bench"))
