@@ -8,8 +8,14 @@ import osqp_solver_amd as M
 from osqp_solver_amd import problems as PR
 
 B = int(os.environ.get("B", "1024"))
-pr = PR.random_box_qp(B)
-s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+os.environ.setdefault("MI_OSQP_TILE", "2"); os.environ.setdefault("MI_OSQP_THREADS", "512")      # the shape the traced twin exists for
+if os.environ.get("GOMP"):                                 # GOMP=D,W: a batch of joint-space GOMP QPs instead of the headline batch
+    D, W = (int(v) for v in os.environ["GOMP"].split(","))
+    pr = PR.gomp_batch(B, D, W)
+    s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
+else:
+    pr = PR.random_box_qp(B)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
 n, m = pr["n"], pr["m"]
 rhs = torch.randn(B, n + m, dtype=torch.float64, device="cuda"); sol = torch.empty_like(rhs)
 for _ in range(3):
