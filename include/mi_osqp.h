@@ -211,6 +211,8 @@ int mi_osqp_multi_batch_setup(mi_osqp_multi **out, int64_t n_devices, const int6
                               const double *l, const double *u, const mi_osqp_settings *settings);
 int mi_osqp_multi_batch_update_A(mi_osqp_multi *h, const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val);
 int mi_osqp_multi_batch_update_bounds(mi_osqp_multi *h, const double *l, const double *u);
+int mi_osqp_multi_batch_update_A_bounds(mi_osqp_multi *h, const int64_t *A_colptr, const int64_t *A_rowidx, const double *A_val,
+                                        const double *l, const double *u);
 int mi_osqp_multi_batch_warm_start_x(mi_osqp_multi *h, const double *x);
 int mi_osqp_multi_batch_solve(mi_osqp_multi *h);
 int mi_osqp_multi_batch_get_primal(mi_osqp_multi *h, double *x_out /*[B][n]*/);

@@ -118,6 +118,7 @@ def lib():
                                                 ip, ip, dp, dp, dp, C.POINTER(Settings)]
         L.mi_osqp_multi_batch_update_A.argtypes = [vp, ip, ip, dp]
         L.mi_osqp_multi_batch_update_bounds.argtypes = [vp, dp, dp]
+        L.mi_osqp_multi_batch_update_A_bounds.argtypes = [vp, ip, ip, dp, dp, dp]
         L.mi_osqp_multi_batch_warm_start_x.argtypes = [vp, dp]
         L.mi_osqp_multi_batch_solve.argtypes = [vp]
         L.mi_osqp_multi_batch_get_primal.argtypes = [vp, dp]
@@ -411,6 +412,11 @@ class MultiBatchSolver:
     def update_bounds(self, l, u):
         l, u = _f64(l).reshape(self.B, -1), _f64(u).reshape(self.B, -1)
         _chk(lib().mi_osqp_multi_batch_update_bounds(self._h, _dp(l), _dp(u)), "multi update_bounds")
+
+    def update_A_bounds(self, Ax, l, u):
+        Ax = _f64(Ax).reshape(self.B, -1)
+        l, u = _f64(l).reshape(self.B, -1), _f64(u).reshape(self.B, -1)
+        _chk(lib().mi_osqp_multi_batch_update_A_bounds(self._h, _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(l), _dp(u)), "multi update_A_bounds")
 
     def warm_start_x(self, x):
         x = _f64(x).reshape(self.B, -1)

@@ -1804,6 +1804,13 @@ int mi_osqp_multi_batch_update_bounds(mi_osqp_multi *h, const double *l, const d
   if (!h || !l || !u) return MI_OSQP_ERR_NULL;
   return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_update_bounds(h->shard[k], l + h->begin[k] * h->m, u + h->begin[k] * h->m); });
 }
+int mi_osqp_multi_batch_update_A_bounds(mi_osqp_multi *h, const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l, const double *u) {
+  if (!h || !Ap || !Ai || !Av || !l || !u) return MI_OSQP_ERR_NULL;
+  const int64_t nnzA = Ap[h->n];
+  return multi_fan_out(h, [&](size_t k) {
+    return mi_osqp_batch_update_A_bounds(h->shard[k], Ap, Ai, Av + h->begin[k] * nnzA, l + h->begin[k] * h->m, u + h->begin[k] * h->m);
+  });
+}
 int mi_osqp_multi_batch_warm_start_x(mi_osqp_multi *h, const double *x) {
   if (!h || !x) return MI_OSQP_ERR_NULL;
   return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_warm_start_x(h->shard[k], x + h->begin[k] * h->n); });

@@ -69,6 +69,11 @@ def test_multi_device_abi_two_shards_match_single_handle_and_oracle():
     multi.warm_start_x(x2); one.warm_start_x(x1)
     j2 = multi.solve(); j1 = one.solve()
     assert [(i.status_val, i.iter) for i in j1] == [(i.status_val, i.iter) for i in j2] and np.array_equal(one.primal(), multi.primal())
+    # QPSolver::update as one call (new A values + bounds) through the sharded handle
+    Ax2 = pr["Ax"] * 1.05
+    multi.update_A_bounds(Ax2, pr["l"] * 0.7, pr["u"] * 0.7); one.update_A_bounds(Ax2, pr["l"] * 0.7, pr["u"] * 0.7)
+    k2 = multi.solve(); k1 = one.solve()
+    assert [(i.status_val, i.iter) for i in k1] == [(i.status_val, i.iter) for i in k2] and np.array_equal(one.primal(), multi.primal())
 
 
 def test_one_nonconvex_qp_is_isolated_from_the_batch():
