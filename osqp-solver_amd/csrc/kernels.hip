@@ -358,7 +358,7 @@ __device__ __forceinline__ void run_stream(const ValSrc<BT> &vs, uint32_t begin,
 struct Mw { unsigned *bar; unsigned G; };
 __device__ __forceinline__ void grid_barrier(const Mw &mw) {
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !__hip_atomic_load(&mw.bar[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {      // (after a time-out nobody waits again)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned gen = __hip_atomic_load(&mw.bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
