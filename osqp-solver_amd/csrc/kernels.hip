@@ -2528,6 +2528,9 @@ hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
   if (getenv("MI_OSQP_DEBUG_HIP")) fprintf(stderr, "[mi_osqp] launch_iterate: df %d wide %d xs_global %p BT %d tiles %d threads %d lds %zu groups %d bar %p\n", a.df, a.wide, (void *)a.xs_global, BT, tiles, threads, lds, a.mw_groups, (void *)a.mw_bar);
   if (a.df) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || a.mw_groups < 1) return hipErrorInvalidValue; tiles = a.mw_groups; }
+#ifdef MI_OSQP_DEBUG_BUILD
+  if (a.df && getenv("MI_OSQP_DEBUG_DROP_GROUP") && tiles > 1) tiles--;       // fault injection: a workgroup of the grid never shows up
+#endif
   MI_DISPATCH(iterate_kernel, a);
 }
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
