@@ -195,6 +195,46 @@ int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64
                                    double *device_seconds, double *refactor_seconds, int64_t *refactor_count,
                                    double *compact_seconds);
 
+/* ------------------------------------------------------ continuous batching
+ * The reference's SQP loop is per trajectory: solve -> check -> re-linearise -> update -> solve again
+ * ([REF] src/gomp-solver.h:70-88), with a fresh QPSolver per horizon segment ([REF] src/gomp-solver.h:61-65).  The QPs of a
+ * batch therefore do not finish together, and a planner must not wait for the slowest of them.  These entry points address
+ * single QPs of a batch handle (`ids`: n_ids QP numbers in [0, B); per-QP arguments are QP-major in the order of `ids`) and
+ * advance whatever is iterating without blocking:
+ *
+ *     reinit_some / update_A_bounds_some / warm_start_x_some   new data for QPs that are not iterating
+ *     solve_begin_some                                         Solve() entry of those QPs (own iteration count from 0)
+ *     advance(n_segments)                                      enqueue: every iterating QP runs n_segments x L iterations, L =
+ *                                                              gcd(check_termination, adaptive_rho_interval, max_iter) = 25 by
+ *                                                              default, with the checks / rho updates / refactorisations a
+ *                                                              blocking solve of its own would see at those iterations
+ *     poll(wait, ...)                                          which QPs finished in the oldest advance not polled yet
+ *     get_primal_some / get_dual_some / get_info_some          results of finished QPs (host memory, no device access)
+ *
+ * Every QP takes exactly the iterations of a mi_osqp_batch_solve of its own: same exit code, iteration count, rho updates
+ * and solution, bit for bit.  Nothing here waits for the device except poll() (and a full staging ring); at most two
+ * advances may be waiting for their poll().  A blocking mi_osqp_batch_* call ends the continuous mode of the handle (solves
+ * in flight are forgotten).  Not available for handles whose solve vector does not fit LDS (large single QPs).
+ *
+ * reinit_some = QPSolver::QPSolver for those QPs ([REF] src/osqp-wrapper.h:16-31) with the P and q given at setup and new
+ * A values / bounds: equilibration from the raw data, rho = settings.rho, zero iterates, no rho updates - the state
+ * mi_osqp_batch_setup leaves for that QP, bit for bit, without analysis or allocation.
+ * update_A_bounds_some = QPSolver::update ([REF] src/osqp-wrapper.h:33-43) for those QPs. */
+int mi_osqp_batch_reinit_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids,
+                              const double *A_val /*[n_ids][nnzA]*/, const double *l /*[n_ids][m]*/, const double *u);
+int mi_osqp_batch_update_A_bounds_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids,
+                                       const double *A_val, const double *l, const double *u);
+int mi_osqp_batch_warm_start_x_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *x /*[n_ids][n]*/);
+int mi_osqp_batch_solve_begin_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids);
+int mi_osqp_batch_advance(mi_osqp_batch *h, int64_t n_segments);
+/* wait != 0: block until the oldest unpolled advance has run; wait == 0: *n_finished = -1 when it has not.  ids_out receives
+ * the QPs that finished in it (capacity >= B is always enough; too small: error, *n_finished = the number, nothing consumed). */
+int mi_osqp_batch_poll(mi_osqp_batch *h, int64_t wait, int64_t *n_finished, int64_t *ids_out, int64_t capacity);
+int mi_osqp_batch_get_primal_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, double *x_out /*[n_ids][n]*/);
+int mi_osqp_batch_get_dual_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, double *y_out /*[n_ids][m]*/);
+int mi_osqp_batch_get_info_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, mi_osqp_info *info /*[n_ids]*/);
+int64_t mi_osqp_batch_running(mi_osqp_batch *h);      /* QPs whose solve has been begun and not been reported by poll() */
+
 /* ---------------------------------------------------------- multi-GPU batch
  * The batch is the shard axis across the GPUs of a node (the runs of a planner are independent,
  * [REF] src/gomp-solver.h:38-55): the B QPs are cut into n_devices contiguous blocks (the first B % n_devices one QP

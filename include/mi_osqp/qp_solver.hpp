@@ -273,4 +273,128 @@ class BatchQPSolver {
   bool pristine_ = true;            // no update() since construction: the handle's setup snapshot is the post-construction state
 };
 
+// Continuous twin of BatchQPSolver on the per-QP entry points of mi_osqp.h ("continuous batching"): K slots that share ONE
+// sparsity pattern, each slot one QPSolver of the reference in its own phase of life - constructed ([REF]
+// src/osqp-wrapper.h:16-31 -> reinit), warm-started (:45-49), solving (:51-54), updated (:33-43) - while the others keep
+// iterating.  begin() + advance() + poll() replace the blocking solve(); a finished slot's result() is what solve()
+// would have returned for it, bit for bit.  Error behaviour as QPSolver: invalid updates throw std::invalid_argument.
+class ContinuousQPSolver {
+ public:
+  // every slot starts as a copy of (c0, P); P and q = 0 stay, A values and bounds are per slot (reinit / update)
+  ContinuousQPSolver(long long slots, const QPConstraints &c0, const QPMatrixSparse &P, bool verbose = false,
+                     const mi_osqp_settings *custom = nullptr)
+      : K_(slots) {
+    assert(slots > 0);
+    const auto &[lo, A, up] = c0;
+    n_ = A.cols; m_ = A.rows; nnzA_ = (long long)A.values.size();
+    mi_osqp_settings s;
+    mi_osqp_default_settings(&s);
+    if (custom) s = *custom;
+    s.verbose = verbose;
+    std::vector<double> Pv, Av, l, u;
+    for (long long k = 0; k < K_; k++) {
+      Pv.insert(Pv.end(), P.values.begin(), P.values.end());
+      Av.insert(Av.end(), A.values.begin(), A.values.end());
+      l.insert(l.end(), lo.begin(), lo.end());
+      u.insert(u.end(), up.begin(), up.end());
+    }
+    int rc = MI_OSQP_ERR_INVALID_DATA;
+    if (P.rows == n_ && P.cols == n_ && (long long)lo.size() == m_ && (long long)up.size() == m_) {
+      P_ = P; A_outer_ = A.outer; A_inner_ = A.inner;
+      rc = mi_osqp_batch_setup(&h_, K_, n_, m_, reinterpret_cast<const int64_t *>(P.outer.data()),
+                               reinterpret_cast<const int64_t *>(P.inner.data()), Pv.data(), nullptr,
+                               reinterpret_cast<const int64_t *>(A.outer.data()), reinterpret_cast<const int64_t *>(A.inner.data()),
+                               Av.data(), l.data(), u.data(), &s, -1);
+    }
+    status_ = rc;
+    if (rc != MI_OSQP_OK) std::cerr << "ContinuousQPSolver: setup failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl;
+    assert(rc == MI_OSQP_OK);
+  }
+  ~ContinuousQPSolver() { mi_osqp_batch_free(h_); }
+  ContinuousQPSolver(const ContinuousQPSolver &) = delete;
+  ContinuousQPSolver &operator=(const ContinuousQPSolver &) = delete;
+
+  // same objective, same pattern of A: a solver built for one run of a planner serves the next one
+  bool compatible(long long slots, const QPConstraints &c0, const QPMatrixSparse &P) const {
+    const QPMatrixSparse &A = std::get<1>(c0);
+    return status_ == MI_OSQP_OK && slots == K_ && A.rows == m_ && A.cols == n_ && A.outer == A_outer_ && A.inner == A_inner_ &&
+           P.outer == P_.outer && P.inner == P_.inner && P.values == P_.values;
+  }
+
+  // QPSolver's constructor for the listed slots (new A values and bounds; P as built)
+  void reinit(const std::vector<long long> &ids, const std::vector<const QPConstraints *> &cs) { newData(ids, cs, true); }
+  // QPSolver::update for the listed slots
+  void update(const std::vector<long long> &ids, const std::vector<const QPConstraints *> &cs) { newData(ids, cs, false); }
+  void setWarmStart(const std::vector<long long> &ids, const std::vector<const QPVector *> &xs) {
+    if (ids.empty()) return;
+    xbuf_.clear();
+    for (const QPVector *x : xs) { assert((long long)x->size() == n_); xbuf_.insert(xbuf_.end(), x->begin(), x->end()); }
+    const int rc = mi_osqp_batch_warm_start_x_some(h_, (int64_t)ids.size(), reinterpret_cast<const int64_t *>(ids.data()), xbuf_.data());
+    if (rc != MI_OSQP_OK) std::cerr << "ContinuousQPSolver: warm start failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl;
+    assert(rc == MI_OSQP_OK);
+  }
+  // QPSolver::solve, first half: the listed slots start iterating with the next advance()
+  void begin(const std::vector<long long> &ids) {
+    if (ids.empty()) return;
+    const int rc = mi_osqp_batch_solve_begin_some(h_, (int64_t)ids.size(), reinterpret_cast<const int64_t *>(ids.data()));
+    if (rc != MI_OSQP_OK) std::cerr << "ContinuousQPSolver: begin failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl;
+    assert(rc == MI_OSQP_OK);
+  }
+  // enqueue one segment (25 iterations + checks with default settings) for every slot that is iterating; does not wait
+  bool advance(int segments = 1) {
+    const int rc = mi_osqp_batch_advance(h_, segments);
+    if (rc != MI_OSQP_OK) std::cerr << "ContinuousQPSolver: advance failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl;
+    return rc == MI_OSQP_OK;
+  }
+  // slots that finished in the oldest advance not polled yet (waits for it)
+  std::vector<long long> poll() {
+    std::vector<long long> out((size_t)K_);
+    int64_t nf = 0;
+    const int rc = mi_osqp_batch_poll(h_, 1, &nf, reinterpret_cast<int64_t *>(out.data()), K_);
+    if (rc != MI_OSQP_OK) { std::cerr << "ContinuousQPSolver: poll failed: " << mi_osqp_error_name(rc) << " (" << mi_osqp_last_error() << ")" << std::endl; nf = 0; }
+    out.resize((size_t)std::max<int64_t>(nf, 0));
+    return out;
+  }
+  // QPSolver::solve, second half: exit code and primal solution of a finished slot
+  std::pair<OsqpExitCode, QPVector> result(long long id) {
+    const int64_t i = id;
+    mi_osqp_info info{};
+    QPVector x((size_t)n_);
+    if (mi_osqp_batch_get_info_some(h_, 1, &i, &info) != MI_OSQP_OK || mi_osqp_batch_get_primal_some(h_, 1, &i, x.data()) != MI_OSQP_OK)
+      return {OsqpExitCode::kUnknown, x};
+    last_ = info;
+    return {static_cast<OsqpExitCode>(info.exit_code), x};
+  }
+  long long running() const { return mi_osqp_batch_running(h_); }
+  long long size() const { return K_; }
+  int setup_status() const { return status_; }
+  const mi_osqp_info &last_info() const { return last_; }
+
+ private:
+  void newData(const std::vector<long long> &ids, const std::vector<const QPConstraints *> &cs, bool fresh) {
+    if (ids.empty()) return;
+    if (ids.size() != cs.size()) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_INVALID_DATA));
+    abuf_.clear(); lbuf_.clear(); ubuf_.clear();
+    for (const QPConstraints *c : cs) {
+      const auto &[lo, A, up] = *c;
+      if (A.outer != A_outer_ || A.inner != A_inner_) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_PATTERN_CHANGED));
+      if ((long long)lo.size() != m_ || (long long)up.size() != m_) throw std::invalid_argument(mi_osqp_error_name(MI_OSQP_ERR_INVALID_DATA));
+      abuf_.insert(abuf_.end(), A.values.begin(), A.values.end());
+      lbuf_.insert(lbuf_.end(), lo.begin(), lo.end());
+      ubuf_.insert(ubuf_.end(), up.begin(), up.end());
+    }
+    const int64_t *pid = reinterpret_cast<const int64_t *>(ids.data());
+    const int rc = fresh ? mi_osqp_batch_reinit_some(h_, (int64_t)ids.size(), pid, abuf_.data(), lbuf_.data(), ubuf_.data())
+                         : mi_osqp_batch_update_A_bounds_some(h_, (int64_t)ids.size(), pid, abuf_.data(), lbuf_.data(), ubuf_.data());
+    if (rc != MI_OSQP_OK) throw std::invalid_argument(std::string(mi_osqp_error_name(rc)) + " (" + mi_osqp_last_error() + ")");
+  }
+  mi_osqp_batch *h_ = nullptr;
+  long long K_ = 0, n_ = 0, m_ = 0, nnzA_ = 0;
+  int status_ = 0;
+  QPMatrixSparse P_;
+  std::vector<long long> A_outer_, A_inner_;
+  std::vector<double> abuf_, lbuf_, ubuf_, xbuf_;
+  mi_osqp_info last_{};
+};
+
 }  // namespace miosqp_ref

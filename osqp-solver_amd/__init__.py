@@ -105,6 +105,16 @@ def lib():
         L.mi_osqp_batch_kernel_time.argtypes = [vp, dp, ip]
         L.mi_osqp_batch_refactor_time.argtypes = [vp, dp, dp, ip, ip]
         L.mi_osqp_batch_refactor_peak.argtypes = [vp, ip, dp, dp]
+        L.mi_osqp_batch_reinit_some.argtypes = [vp, C.c_int64, ip, dp, dp, dp]
+        L.mi_osqp_batch_update_A_bounds_some.argtypes = [vp, C.c_int64, ip, dp, dp, dp]
+        L.mi_osqp_batch_warm_start_x_some.argtypes = [vp, C.c_int64, ip, dp]
+        L.mi_osqp_batch_solve_begin_some.argtypes = [vp, C.c_int64, ip]
+        L.mi_osqp_batch_advance.argtypes = [vp, C.c_int64]
+        L.mi_osqp_batch_poll.argtypes = [vp, C.c_int64, ip, ip, C.c_int64]
+        L.mi_osqp_batch_get_primal_some.argtypes = [vp, C.c_int64, ip, dp]
+        L.mi_osqp_batch_get_dual_some.argtypes = [vp, C.c_int64, ip, dp]
+        L.mi_osqp_batch_get_info_some.argtypes = [vp, C.c_int64, ip, C.POINTER(Info)]
+        L.mi_osqp_batch_running.argtypes = [vp]; L.mi_osqp_batch_running.restype = C.c_int64
         L.mi_osqp_setup.argtypes = [C.POINTER(vp), C.c_int64, C.c_int64, ip, ip, dp, dp, ip, ip, dp, dp, dp, C.POINTER(Settings)]
         L.mi_osqp_update_A.argtypes = [vp, ip, ip, dp]
         L.mi_osqp_update_bounds.argtypes = [vp, dp, dp]
@@ -308,6 +318,53 @@ class BatchSolver:
         nq, f, d = C.c_int64(), C.c_double(), C.c_double()
         _chk(lib().mi_osqp_batch_refactor_peak(self._h, C.byref(nq), C.byref(f), C.byref(d)), "refactor_peak")
         return nq.value, f.value, d.value
+
+    # ---- continuous batching: per-QP entry points + non-blocking advance / poll (mi_osqp.h "continuous batching")
+    def reinit_some(self, ids, Ax, l, u):
+        ids = _i64(ids); k = len(ids)
+        Ax, l, u = _f64(Ax).reshape(k, -1), _f64(l).reshape(k, -1), _f64(u).reshape(k, -1)
+        _chk(lib().mi_osqp_batch_reinit_some(self._h, k, _ip(ids), _dp(Ax), _dp(l), _dp(u)), "reinit_some")
+
+    def update_A_bounds_some(self, ids, Ax, l, u):
+        ids = _i64(ids); k = len(ids)
+        Ax, l, u = _f64(Ax).reshape(k, -1), _f64(l).reshape(k, -1), _f64(u).reshape(k, -1)
+        _chk(lib().mi_osqp_batch_update_A_bounds_some(self._h, k, _ip(ids), _dp(Ax), _dp(l), _dp(u)), "update_A_bounds_some")
+
+    def warm_start_x_some(self, ids, x):
+        ids = _i64(ids); x = _f64(x).reshape(len(ids), -1)
+        _chk(lib().mi_osqp_batch_warm_start_x_some(self._h, len(ids), _ip(ids), _dp(x)), "warm_start_x_some")
+
+    def solve_begin_some(self, ids):
+        ids = _i64(ids)
+        _chk(lib().mi_osqp_batch_solve_begin_some(self._h, len(ids), _ip(ids)), "solve_begin_some")
+
+    def advance(self, n_segments=1):
+        _chk(lib().mi_osqp_batch_advance(self._h, n_segments), "advance")
+
+    def poll(self, wait=True):
+        """QP ids that finished in the oldest advance not polled yet (None: wait=False and it has not run yet)."""
+        out = np.empty(self.B, dtype=np.int64)
+        nf = C.c_int64()
+        _chk(lib().mi_osqp_batch_poll(self._h, 1 if wait else 0, C.byref(nf), _ip(out), self.B), "poll")
+        return None if nf.value < 0 else out[:nf.value].copy()
+
+    def running(self):
+        return int(lib().mi_osqp_batch_running(self._h))
+
+    def primal_some(self, ids):
+        ids = _i64(ids); x = np.empty((len(ids), self.n))
+        _chk(lib().mi_osqp_batch_get_primal_some(self._h, len(ids), _ip(ids), _dp(x)), "get_primal_some")
+        return x
+
+    def dual_some(self, ids):
+        ids = _i64(ids); y = np.empty((len(ids), self.m))
+        _chk(lib().mi_osqp_batch_get_dual_some(self._h, len(ids), _ip(ids), _dp(y)), "get_dual_some")
+        return y
+
+    def info_some(self, ids):
+        ids = _i64(ids); arr = (Info * len(ids))()
+        _chk(lib().mi_osqp_batch_get_info_some(self._h, len(ids), _ip(ids), arr), "get_info_some")
+        return list(arr)
 
     # ---- device-resident variants (torch tensors on the solver's GPU)
     def solve_device(self, x_out=None, status=None, iters=None, stream=None):

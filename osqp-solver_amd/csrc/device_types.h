@@ -27,7 +27,9 @@ struct DenseTailDev {
 // per-QP double scalars, laid out [tile][DS_COUNT][BT]
 enum { DS_C = 0, DS_CINV, DS_RHO, DS_RHO_EST, DS_PRI_RES, DS_DUA_RES, DS_OBJ, DS_COUNT };
 // per-QP int scalars, laid out [tile][IS_COUNT][BT]
-enum { IS_STATUS = 0, IS_ITER, IS_RHO_UPDATES, IS_DONE, IS_NEED_REFACTOR, IS_COUNT };
+// (IS_ITER0: the launch iteration count at which the QP's current solve began - 0 in a blocking solve; the continuous
+//  entry points start QPs at different launches, and every QP counts its iterations from its own start)
+enum { IS_STATUS = 0, IS_ITER, IS_RHO_UPDATES, IS_DONE, IS_NEED_REFACTOR, IS_ITER0, IS_COUNT };
 
 struct KernelArgs {
   int n, m, N, B;
@@ -63,6 +65,9 @@ struct KernelArgs {
   int df;
   unsigned df_shadow;
   const unsigned char *rflag;
+  // per-QP entry points (continuous batching): sel[slot] = 0: the slot is not addressed by this launch, j + 1: it is, and
+  // its input is row j of the launch's QP-major argument.  null = every QP, row = QP id.
+  const int *sel;
 };
 
 // device block refactorisation (row E13); tables are host_core.hpp BlockFactor
@@ -147,6 +152,9 @@ hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, 
 // scaled bounds; one workgroup per QP, the arithmetic and its order are those of host_core.cpp scale_qp / unscale_qp.
 struct RuizArgs {
   int n, m, nnzP, nnzA, B, BT, iters;
+  const int *ids;                            // non-null: workgroup j serves QP ids[j] (B = length of the list); rawA / rawl / rawu / pa_out are indexed by j
+  int fresh;                                 // 1: equilibrate from the raw P and q kept since setup (rawP / rawq, [QP][nnzP], [QP][n]) instead of
+  const double *rawP, *rawq;                 //    unscaling the values in force: bit for bit what setup computes for (P, q, rawA, rawl, rawu)
   const int32_t *Prow, *Pcol, *Arow, *Acol;   // per entry of triu(P) / A: row, column
   const double *rawA;                        // [B][nnzA] new values of A (natural CSC order)
   const double *rawl, *rawu;                 // [B][m] new bounds, or null: keep the bounds (unscale, rescale)
@@ -155,6 +163,19 @@ struct RuizArgs {
   double *pa_out;                            // [B][nnzP + nnzA]: the scaled values once more, QP-major (for the check-stream scatter)
 };
 hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st);
+// ---- per-QP entry points (continuous batching; solver.hip "continuous")
+// begin a solve of the listed slots: status unsolved, own iteration count 0 from launch iteration `tick` on; slots whose factor
+// is invalid (IS_NEED_REFACTOR < 0) end at once as kNonConvex.  clear[j] != 0: the count of rho updates restarts at 0.
+hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int tick, int cold, hipStream_t st);
+// the state a fresh setup leaves in the listed slots: zero iterates, rho = rho0, no rho updates, idle
+hipError_t launch_fresh_slots(const KernelArgs &a, const int *slots, int nslots, int BT, double rho0, hipStream_t st);
+// work[0 .. nslots) = the slots whose IS_NEED_REFACTOR flag is 1 (any order), then -1
+hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipStream_t st);
+// slots still iterating whose refactorisation lost the inertia (flag -1): kNonConvex at own iteration iter_end - IS_ITER0
+hipError_t launch_fail_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st);
+// dst[slot] = src[slot] for the listed slots: [slot][per] streams / [tile][len][BT] interleaved arrays
+hipError_t launch_copy_slot_streams(double *dst, const double *src, const int *slots, int nslots, size_t per, hipStream_t st);
+hipError_t launch_copy_slot_rows(double *dst, const double *src, const int *slots, int nslots, int len, int BT, hipStream_t st);
 hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
 hipError_t launch_fail_slots(const KernelArgs &a, const int *slots, int nfail, int BT, int iter, hipStream_t st);
 hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,

@@ -21,6 +21,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "sched_format.h"
 
@@ -982,7 +984,8 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   const int qp = a.qp_of_slot[tile * BT + b];
   int done = p.iscal[IS_DONE * BT + b];
   if (__syncthreads_and(done)) return;
-  const int iter = a.iter_end;
+  // the QP's own iteration count: QPs of a continuous batch (solver.hip) start at different launches
+  const int iter = a.iter_end - p.iscal[IS_ITER0 * BT + b];
   int status = p.iscal[IS_STATUS * BT + b];
   int rho_updates = p.iscal[IS_RHO_UPDATES * BT + b];
   double rho = p.dscal[DS_RHO * BT + b];
@@ -991,6 +994,9 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   const bool is_last = iter >= a.max_iter;
   const bool is_check = a.check_termination && (iter % a.check_termination == 0);
   const bool is_rho = a.adaptive_rho && a.rho_interval && (iter % a.rho_interval == 0);
+  // (the tests below hold barriers: what one QP of the tile needs, every thread of the workgroup walks through)
+  bool any_check = is_check || is_last, any_last = is_last;
+  if constexpr (BT > 1) { any_check = __syncthreads_or(any_check); any_last = __syncthreads_or(any_last); }
   int need_refactor = 0;
   // ---- E11: [x;y] -> LDS, P x / A' y / A x
   for (int e = tid; e < n * BT; e += nthr) xs[e] = p.x[e];
@@ -1106,7 +1112,7 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   };
 
   int new_status = 0;
-  if (is_check || is_last) new_status = decide(false);
+  if (any_check) { const int s0 = decide(false); if (is_check || is_last) new_status = s0; }
   double rho_est = p.dscal[DS_RHO_EST * BT + b];
   // ---- E13: rho estimate from the SCALED residual norms
   auto rho_estimate = [&]() -> double {
@@ -1126,11 +1132,9 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
       rho_updates++;
     }
   }
-  if (!done && new_status == 0 && is_last) {
-    new_status = decide(true);
-    if (new_status == 0) new_status = -2;   // max iterations reached
-  } else if (is_last) {
-    decide(true);   // keep barriers uniform across the workgroup
+  if (any_last) {
+    const int s1 = decide(true);            // (every thread: the decision holds barriers)
+    if (!done && new_status == 0 && is_last) new_status = s1 ? s1 : -2;      // -2: max iterations reached
   }
   if (!done && new_status != 0) {
     // ---- E14: store_solution
@@ -1448,19 +1452,23 @@ __global__ __launch_bounds__(NT) void warm_start_kernel(KernelArgs a, const doub
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), b = tid % BT;
   const int n = a.n, m = a.m;
   const int qp = tile * BT + b;
+  // per-QP form (a.sel): only the addressed QPs of the tile take a new x and z; input row = position in the caller's list
+  const int row = a.sel ? a.sel[qp] - 1 : (qp < a.B ? qp : -1);
+  if (!__syncthreads_or(row >= 0)) return;
   double *lds_rest;
   double *xs = solve_vector<BT, GX>(a, smem, tile, lds_rest);
   const TilePtrs<BT> p = tile_ptrs<BT>(a, tile);
   for (int e = tid; e < n * BT; e += nthr) {
-    double v = qp < a.B ? x0[(size_t)qp * n + e / BT] : 0.0;
+    double v = row >= 0 ? x0[(size_t)row * n + e / BT] : 0.0;
     if (a.scaling) v *= p.Dsc_inv[e];
-    xs[e] = v; p.x[e] = v;
+    xs[e] = v;
+    if (row >= 0 || !a.sel) p.x[e] = v;
   }
   for (int e = tid; e < m * BT; e += nthr) xs[(size_t)n * BT + e] = 0.0;
   __syncthreads();
   run_spmv<BT, MI_PFV, WIDE>(a.chk, p.vchk, xs, p.out1, wave, lane, 2, 3, (int)(blockDim.x >> 6));
   __syncthreads();
-  for (int e = tid; e < m * BT; e += nthr) p.z[e] = p.out1[(size_t)2 * n * BT + e];
+  for (int e = tid; e < m * BT; e += nthr) if (row >= 0 || !a.sel) p.z[e] = p.out1[(size_t)2 * n * BT + e];
 }
 
 // ------------------------------------------- device refactorisation (row E13)
@@ -2355,6 +2363,119 @@ hipError_t launch_fail_slots(const KernelArgs &a, const int *slots, int nfail, i
   hipLaunchKernelGGL(fail_slots_kernel, dim3(nfail), dim3(256), 0, st, a, slots, BT, iter);
   return hipGetLastError();
 }
+// ---- per-QP entry points (continuous batching, solver.hip): one workgroup per listed slot (slot = tile * BT + b) --------
+// What fail_slots_kernel does to a slot, for callers that already sit in a workgroup of that slot.
+__device__ __forceinline__ void fail_one_slot(const KernelArgs &a, int slot, int BT, int iter, int tid, int nthr) {
+  const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
+  const double nanv = __builtin_nan("");
+  for (int i = tid; i < a.n; i += nthr) { a.x[(tile * a.n + i) * BT + b] = 0.0; if (slot < a.B) a.x_out[(size_t)slot * a.n + i] = nanv; }
+  for (int j = tid; j < a.m; j += nthr) {
+    a.z[(tile * a.m + j) * BT + b] = 0.0; a.y[(tile * a.m + j) * BT + b] = 0.0;
+    if (slot < a.B) a.y_out[(size_t)slot * a.m + j] = nanv;
+  }
+  if (tid == 0) {
+    int *is = a.iscal + tile * IS_COUNT * BT;
+    is[IS_DONE * BT + b] = 1; is[IS_STATUS * BT + b] = -7; is[IS_ITER * BT + b] = iter;
+    double *ds = a.dscal + tile * DS_COUNT * BT;
+    ds[DS_OBJ * BT + b] = nanv; ds[DS_PRI_RES * BT + b] = nanv; ds[DS_DUA_RES * BT + b] = nanv;
+  }
+}
+// Solve() entry of the listed QPs ([EXT] osqp_solve: status unsolved, iteration count 0; warm_start off: cold iterates).
+// A QP without a valid factor (the last refactorisation of its KKT matrix lost the inertia) ends at once as kNonConvex.
+__global__ void start_slots_kernel(KernelArgs a, const int *__restrict__ slots, const int *__restrict__ clear, int BT, int tick, int cold) {
+  const int slot = slots[blockIdx.x], tid = threadIdx.x, nthr = blockDim.x;
+  if (slot < 0) return;
+  const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
+  int *is = a.iscal + tile * IS_COUNT * BT;
+  if (is[IS_NEED_REFACTOR * BT + b] < 0) { fail_one_slot(a, slot, BT, 0, tid, nthr); return; }
+  if (cold) {
+    for (int i = tid; i < a.n; i += nthr) a.x[(tile * a.n + i) * BT + b] = 0.0;
+    for (int j = tid; j < a.m; j += nthr) { a.z[(tile * a.m + j) * BT + b] = 0.0; a.y[(tile * a.m + j) * BT + b] = 0.0; }
+  }
+  if (tid == 0) {
+    is[IS_STATUS * BT + b] = -10; is[IS_ITER * BT + b] = 0; is[IS_DONE * BT + b] = 0; is[IS_NEED_REFACTOR * BT + b] = 0;
+    is[IS_ITER0 * BT + b] = tick;
+    if (clear[blockIdx.x]) is[IS_RHO_UPDATES * BT + b] = 0;
+  }
+}
+hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int tick, int cold, hipStream_t st) {
+  if (!nslots) return hipSuccess;
+  hipLaunchKernelGGL(start_slots_kernel, dim3(nslots), dim3(256), 0, st, a, slots, clear, BT, tick, cold);
+  return hipGetLastError();
+}
+// The iterates and scalars a fresh setup leaves (batch_setup_impl: zero x, y, z; rho = rho estimate = settings.rho; no rho
+// updates; residuals / objective 0), and the slot idle until its solve is begun.  c / 1/c belong to the equilibration.
+__global__ void fresh_slots_kernel(KernelArgs a, const int *__restrict__ slots, int BT, double rho0) {
+  const int slot = slots[blockIdx.x], tid = threadIdx.x, nthr = blockDim.x;
+  if (slot < 0) return;
+  const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
+  for (int i = tid; i < a.n; i += nthr) { a.x[(tile * a.n + i) * BT + b] = 0.0; a.dx[(tile * a.n + i) * BT + b] = 0.0; }
+  for (int j = tid; j < a.m; j += nthr) { a.z[(tile * a.m + j) * BT + b] = 0.0; a.y[(tile * a.m + j) * BT + b] = 0.0; a.dy[(tile * a.m + j) * BT + b] = 0.0; }
+  if (tid == 0) {
+    int *is = a.iscal + tile * IS_COUNT * BT;
+    is[IS_STATUS * BT + b] = -10; is[IS_ITER * BT + b] = 0; is[IS_RHO_UPDATES * BT + b] = 0; is[IS_DONE * BT + b] = 1;
+    is[IS_NEED_REFACTOR * BT + b] = 0; is[IS_ITER0 * BT + b] = 0;
+    double *ds = a.dscal + tile * DS_COUNT * BT;
+    ds[DS_RHO * BT + b] = rho0; ds[DS_RHO_EST * BT + b] = rho0; ds[DS_PRI_RES * BT + b] = 0.0; ds[DS_DUA_RES * BT + b] = 0.0; ds[DS_OBJ * BT + b] = 0.0;
+  }
+}
+hipError_t launch_fresh_slots(const KernelArgs &a, const int *slots, int nslots, int BT, double rho0, hipStream_t st) {
+  if (!nslots) return hipSuccess;
+  hipLaunchKernelGGL(fresh_slots_kernel, dim3(nslots), dim3(256), 0, st, a, slots, BT, rho0);
+  return hipGetLastError();
+}
+// The refactorisation work list of a launch that nobody on the host has looked at: the slots whose rho changed in the
+// check that has just run (flag 1), packed in front, -1 behind them.  One workgroup.
+__global__ __launch_bounds__(1024) void worklist_kernel(const int *__restrict__ iscal, int *work, int nslots, int BT) {
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  for (int s = threadIdx.x; s < nslots; s += blockDim.x) work[s] = -1;
+  __syncthreads();
+  for (int s = threadIdx.x; s < nslots; s += blockDim.x)
+    if (iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] == 1) work[atomicAdd(&s_cnt, 1)] = s;
+}
+hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipStream_t st) {
+  hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, st, iscal, work, nslots, BT);
+  return hipGetLastError();
+}
+// After the refactorisations of a launch: a QP still iterating whose new factor lost the inertia ends as kNonConvex
+// ([EXT] osqp_solve: adapt_rho fails -> OSQP_NON_CVX); the flag stays -1 until a refactorisation of that QP succeeds.
+__global__ void fail_flagged_kernel(KernelArgs a, int BT) {
+  const int slot = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
+  const int *is = a.iscal + tile * IS_COUNT * BT;
+  if (is[IS_NEED_REFACTOR * BT + b] >= 0 || is[IS_DONE * BT + b]) return;
+  fail_one_slot(a, slot, BT, a.iter_end - is[IS_ITER0 * BT + b], tid, nthr);
+}
+hipError_t launch_fail_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st) {
+  if (!nslots) return hipSuccess;
+  hipLaunchKernelGGL(fail_flagged_kernel, dim3(nslots), dim3(64), 0, st, a, BT);
+  return hipGetLastError();
+}
+__global__ void copy_slot_streams_kernel(double *dst, const double *__restrict__ src, const int *__restrict__ slots, size_t per) {
+  const int slot = slots[blockIdx.y];
+  if (slot < 0) return;
+  const size_t off = (size_t)slot * per;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) dst[off + e] = src[off + e];
+}
+hipError_t launch_copy_slot_streams(double *dst, const double *src, const int *slots, int nslots, size_t per, hipStream_t st) {
+  if (!nslots || !per) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<size_t>(64, (per + 255) / 256);
+  hipLaunchKernelGGL(copy_slot_streams_kernel, dim3(gx, nslots), dim3(256), 0, st, dst, src, slots, per);
+  return hipGetLastError();
+}
+__global__ void copy_slot_rows_kernel(double *dst, const double *__restrict__ src, const int *__restrict__ slots, int len, int BT) {
+  const int slot = slots[blockIdx.y];
+  if (slot < 0) return;
+  const size_t base = (size_t)(slot / BT) * len * BT + slot % BT;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) dst[base + (size_t)i * BT] = src[base + (size_t)i * BT];
+}
+hipError_t launch_copy_slot_rows(double *dst, const double *src, const int *slots, int nslots, int len, int BT, hipStream_t st) {
+  if (!nslots || !len) return hipSuccess;
+  const unsigned gx = (unsigned)std::min(16, (len + 255) / 256);
+  hipLaunchKernelGGL(copy_slot_rows_kernel, dim3(gx, nslots), dim3(256), 0, st, dst, src, slots, len, BT);
+  return hipGetLastError();
+}
 // bounds update on device: l,u <- E .* clip(l,u); flags a constraint-type change
 __global__ void bounds_kernel(const double *__restrict__ gl, const double *__restrict__ gu, double *l, double *u,
                               const double *__restrict__ Esc, const double *__restrict__ rho_vec,
@@ -2387,28 +2508,34 @@ __device__ __forceinline__ void ruiz_amax(double *p, double a) {
 __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
   __shared__ double s_red[16];
   __shared__ double s_stage[2048];
-  const int qp = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int jq = blockIdx.x, qp = a.ids ? a.ids[jq] : jq;      // jq: position in the caller's list (= row of its QP-major arguments)
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int n = a.n, m = a.m, nnzP = a.nnzP, nnzA = a.nnzA, pa_len = nnzP + nnzA;
   const size_t tile = (size_t)(qp / a.BT), b = (size_t)(qp % a.BT), BT = (size_t)a.BT;
   auto H = [&](size_t len, size_t i) { return (tile * len + i) * BT + b; };
   double *dn = a.dn + (size_t)qp * n, *en = a.en + (size_t)qp * m;
-  const double *rawA = a.rawA + (size_t)qp * nnzA;
+  const double *rawA = a.rawA + (size_t)jq * nnzA;
   // (dn / en are updated by atomics, which execute in L2: they are read and reset past the CU's L1 as well)
   auto ld = [](const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto st0 = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   double c = a.dscal[H(DS_COUNT, DS_C)];
   const double cinv0 = a.dscal[H(DS_COUNT, DS_CINV)];
   // ---- unscale P and q with the scaling in force; A is replaced; the bounds are replaced or unscaled
-  for (int k = tid; k < nnzP; k += nthr) {
-    double v = a.pa_val[H(pa_len, k)];
-    v *= cinv0; v *= a.Dsc_inv[H(n, a.Prow[k])]; v *= a.Dsc_inv[H(n, a.Pcol[k])];
-    a.pa_val[H(pa_len, k)] = v;
+  if (a.fresh) {       // the QP as setup sees it: P and q as given then
+    for (int k = tid; k < nnzP; k += nthr) a.pa_val[H(pa_len, k)] = a.rawP[(size_t)qp * nnzP + k];
+    for (int j = tid; j < n; j += nthr) a.q[H(n, j)] = a.rawq[(size_t)qp * n + j];
+  } else {
+    for (int k = tid; k < nnzP; k += nthr) {
+      double v = a.pa_val[H(pa_len, k)];
+      v *= cinv0; v *= a.Dsc_inv[H(n, a.Prow[k])]; v *= a.Dsc_inv[H(n, a.Pcol[k])];
+      a.pa_val[H(pa_len, k)] = v;
+    }
+    for (int j = tid; j < n; j += nthr) a.q[H(n, j)] *= cinv0 * a.Dsc_inv[H(n, j)];
   }
-  for (int j = tid; j < n; j += nthr) a.q[H(n, j)] *= cinv0 * a.Dsc_inv[H(n, j)];
   for (int k = tid; k < nnzA; k += nthr) a.pa_val[H(pa_len, nnzP + k)] = rawA[k];
   for (int i = tid; i < m; i += nthr) {
     double lo, up;
-    if (a.rawl) { lo = fmax(a.rawl[(size_t)qp * m + i], -MI_INFTY); up = fmin(a.rawu[(size_t)qp * m + i], MI_INFTY); }
+    if (a.rawl) { lo = fmax(a.rawl[(size_t)jq * m + i], -MI_INFTY); up = fmin(a.rawu[(size_t)jq * m + i], MI_INFTY); }
     else { const double ei = a.Esc_inv[H(m, i)]; lo = a.l[H(m, i)] * ei; up = a.u[H(m, i)] * ei; }
     a.l[H(m, i)] = lo; a.u[H(m, i)] = up;
   }
@@ -2483,7 +2610,7 @@ __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
     a.l[H(m, i)] *= e; a.u[H(m, i)] *= e;
   }
   if (tid == 0) { a.dscal[H(DS_COUNT, DS_C)] = c; a.dscal[H(DS_COUNT, DS_CINV)] = 1.0 / c; }
-  for (int k = tid; k < pa_len; k += nthr) a.pa_out[(size_t)qp * pa_len + k] = a.pa_val[H(pa_len, k)];
+  for (int k = tid; k < pa_len; k += nthr) a.pa_out[(size_t)jq * pa_len + k] = a.pa_val[H(pa_len, k)];
 }
 hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;

@@ -319,9 +319,33 @@ struct mi_osqp_batch {
   // of the batch is unaffected ([REF] src/osqp-wrapper.h:51-54: solve() never throws, one exit code per solver).
   std::vector<char> failed;
   DevBuf<int> fail_list;
+  // raw triu(P) and q as setup received them ([QP][nnzP], [QP][n]): what mi_osqp_batch_reinit_some equilibrates from
+  DevBuf<double> rawP, rawq;
+  // ---- continuous batching (the per-QP entry points + advance / poll; section "continuous" below)
+  struct Cont {
+    bool on = false;
+    int tick = 0, L = 25;                    // launch iteration count; iterations per segment (gcd of the check / rho / max_iter periods)
+    int64_t adv_seq = 0, polled_seq = 0;     // segments enqueued / segments whose flags the host has read
+    std::vector<char> running, clear_rho;    // per QP: a solve is in flight; its next solve counts rho updates from 0
+    std::vector<int64_t> start_seq;          // per QP: adv_seq when its solve was begun (older flag copies do not concern it)
+    std::vector<mi_osqp_info> info;          // per QP: result of its last finished solve
+    int n_running = 0;
+    // flag copies of the last two advances (pinned): iscal / dscal images + the event behind them
+    int *h_is[2] = {nullptr, nullptr}; double *h_ds[2] = {nullptr, nullptr}; size_t h_is_cap[2] = {0, 0}, h_ds_cap[2] = {0, 0};
+    hipEvent_t ev[2] = {nullptr, nullptr}; int64_t seq_of[2] = {0, 0};
+    // solutions of finished QPs land in pinned host memory straight from check_kernel ([B][n], [B][m])
+    double *xh = nullptr, *yh = nullptr; size_t xh_cap = 0, yh_cap = 0;
+    // staging ring of the per-QP calls: regions are handed out once per call and recycled when the ring wraps (after a
+    // synchronisation), so a call never waits for an earlier call's copy
+    char *ring_h = nullptr; size_t ring_cap = 0, ring_h_cap = 0, ring_head = 0;
+    DevBuf<char> ring_d;
+    DevBuf<int> work;                        // device-built refactorisation work list of an advance
+  } cont;
   ~mi_osqp_batch() {
     DevGuard guard(device);
     if (stream) (void)hipStreamSynchronize(stream);      // (the buffers go back to their pools right after: DevBuf remembers its device)
+    for (int k = 0; k < 2; k++) { hostpool::give(cont.h_is[k], cont.h_is_cap[k]); hostpool::give(cont.h_ds[k], cont.h_ds_cap[k]); if (cont.ev[k]) (void)hipEventDestroy(cont.ev[k]); }
+    hostpool::give(cont.xh, cont.xh_cap); hostpool::give(cont.yh, cont.yh_cap); hostpool::give(cont.ring_h, cont.ring_h_cap);
     hostpool::give(h_iscal, h_iscal_cap); hostpool::give(h_dscal, h_dscal_cap); hostpool::give(pin, pin_cap); hostpool::give(h_npos, h_npos_cap);
     if (stream && ev0 && ev1 && evf0 && evf1 && evf2) streampool::give({device, stream, {ev0, ev1, evf0, evf1, evf2}});
     else {
@@ -635,6 +659,7 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
 }
 
 static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
+static int cont_leave(mi_osqp_batch *h);      // (a blocking call ends the continuous mode of a handle: section "continuous")
 
 // multi-workgroup mode: a grid barrier that gave up waiting (a workgroup of the grid was not resident) leaves its error
 // word set; the results of that launch are garbage
@@ -834,6 +859,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     }
   }
   if ((rc = h->x_out.alloc((size_t)B * n)) || (rc = h->y_out.alloc((size_t)B * std::max<int64_t>(m, 1)))) return rc;
+  if ((rc = h->rawP.alloc((size_t)B * std::max(an.Pp[n], 1))) || (rc = h->rawq.alloc((size_t)B * n))) return rc;
   if ((rc = h->x_out.zero(h->stream)) || (rc = h->y_out.zero(h->stream))) return rc;
   HIPCHK(hostpool::alloc((void **)&h->h_iscal, (size_t)IS_COUNT * T * sizeof(int), &h->h_iscal_cap));
   HIPCHK(hostpool::alloc((void **)&h->h_dscal, (size_t)DS_COUNT * T * sizeof(double), &h->h_dscal_cap));
@@ -851,6 +877,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     // QPs whose P, A, q equal those of the chunk's first QP (GOMP: all of them, only bounds differ) reuse its
     // equilibration.  The numeric factorisation itself happens on the device, below.
     std::vector<char> dup(c1 - c0, 0);
+    std::vector<double> raw_pq((size_t)(c1 - c0) * (an.Pp[n] + n));
     for (int k = 1; k < c1 - c0; k++) {
       const int qi = c0 + k;
       dup[k] = !memcmp(Pv + (size_t)qi * nnzPin, Pv + (size_t)c0 * nnzPin, sizeof(double) * nnzPin) &&
@@ -863,6 +890,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
       QPNumeric &Q = h->qp[qi];
       load_qp(an, h->st, Pv + (size_t)qi * nnzPin, q ? q + (size_t)qi * n : nullptr, Av + (size_t)qi * nnzA,
               l + (size_t)qi * m, u + (size_t)qi * m, Q);
+      std::copy(Q.Pv.begin(), Q.Pv.end(), raw_pq.begin() + (size_t)k * (an.Pp[n] + n));          // (before the equilibration)
+      std::copy(Q.q.begin(), Q.q.end(), raw_pq.begin() + (size_t)k * (an.Pp[n] + n) + an.Pp[n]);
       if (h->st.scaling) { if (second_pass) scale_like(an, h->qp[c0], Q); else scale_qp(an, h->st, Q); }
       set_rho_vec(an, h->st, Q);
     };
@@ -873,6 +902,14 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     std::vector<int> ids(c1 - c0);
     for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
     if ((rc = upload_rho(h, ids)) || (rc = upload_problem(h, ids, true))) return rc;
+    {     // raw triu(P) and q of the chunk, QP-major (mi_osqp_batch_reinit_some)
+      const size_t per = (size_t)an.Pp[n] + n;
+      if ((rc = ensure_stage(h, raw_pq.size() + 1, 0))) return rc;
+      HIPCHK(hipMemcpyAsync(h->stage.p, raw_pq.data(), raw_pq.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      if (an.Pp[n]) HIPCHK(hipMemcpy2DAsync(h->rawP.p + (size_t)c0 * an.Pp[n], (size_t)an.Pp[n] * 8, h->stage.p, per * 8, (size_t)an.Pp[n] * 8, (size_t)(c1 - c0), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipMemcpy2DAsync(h->rawq.p + (size_t)c0 * n, (size_t)n * 8, h->stage.p + an.Pp[n], per * 8, (size_t)n * 8, (size_t)(c1 - c0), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
     t_upload += now_s() - tb;
   }
   {
@@ -1250,6 +1287,7 @@ int mi_osqp_batch_solve(mi_osqp_batch *h) {
   CallTimer timer_("batch_solve");
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   const int rc = solve_impl(h, nullptr, nullptr);
   if (CallTimer::on() && getenv("MI_OSQP_DEBUG_SOLVES"))
     fprintf(stderr, "[mi_osqp] solve B=%d N=%d: %ld segments of <= 25 iterations, %.0f QP-iterations in total, iterate %.2f ms, refactor %.2f ms (%ld)\n", h->B,
@@ -1260,6 +1298,7 @@ int mi_osqp_batch_solve(mi_osqp_batch *h) {
 int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream) {
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   int rc = solve_impl(h, d_x_out, (hipStream_t)stream);
   if (rc) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -1275,12 +1314,14 @@ int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x) {
   CallTimer timer_("batch_get_primal");
   if (!h || !x) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   HIPCHK(hipMemcpy(x, h->x_out.p, (size_t)h->B * (*h->anp).n * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OSQP_OK;
 }
 int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y) {
   if (!h || !y) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   if ((*h->anp).m) HIPCHK(hipMemcpy(y, h->y_out.p, (size_t)h->B * (*h->anp).m * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OSQP_OK;
 }
@@ -1289,6 +1330,7 @@ int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info) {
   CallTimer timer_("batch_get_info");
   if (!h || !info) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
   HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(h->h_dscal, h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost));
@@ -1354,6 +1396,7 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
   CallTimer timer_("batch_reset");
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   h->clear_rho_updates = true;
   auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
     if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1374,6 +1417,7 @@ int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
   CallTimer timer_("batch_warm_start_x");
   if (!h || !x) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   h->st.warm_start = 1;
   size_t cnt = (size_t)h->B * (*h->anp).n;
   int rc;
@@ -1394,6 +1438,7 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
   CallTimer timer_("batch_update_bounds");
   if (!h || !l || !u) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   // through pinned memory to the device, where the rows are scaled and checked (bounds_kernel); only when a row changes
   // its type (equality / inequality / free: new rho vector, new factor) the host mirrors take over
   const size_t cnt = (size_t)h->B * (*h->anp).m;
@@ -1433,6 +1478,7 @@ static int update_bounds_on_host(mi_osqp_batch *h, const double *l, const double
 int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream) {
   if (!h || !d_l || !d_u) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   return update_bounds_on_device(h, d_l, d_u, stream ? (hipStream_t)stream : h->stream, nullptr, nullptr);
 }
 
@@ -1552,6 +1598,7 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
   CallTimer timer_("batch_update_A");
   if (!h || !Ap || !Ai || !Av) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   const Analysis &an = (*h->anp);
   for (int j = 0; j <= an.n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
   for (int k = 0; k < an.Ap[an.n]; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
@@ -1566,6 +1613,7 @@ int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *Ap, const int
   CallTimer timer_("batch_update_A_bounds");
   if (!h || !Ap || !Ai || !Av || !l || !u) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   const Analysis &an = (*h->anp);
   const int m = an.m, B = h->B;
   for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
@@ -1618,6 +1666,7 @@ static int update_A_values(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
 int mi_osqp_batch_refactor_device(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   std::vector<int> all(h->B);
   for (int i = 0; i < h->B; i++) all[i] = i;
   return refactor_qps(h, std::move(all));
@@ -1685,6 +1734,392 @@ int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double 
   HIPCHK(e);
   return MI_OSQP_OK;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ continuous
+// Per-QP entry points + a non-blocking advance: the reference's SQP loop is per trajectory - solve, check, re-linearise,
+// update, solve again ([REF] src/gomp-solver.h:70-88) - so the QPs of a batch do not finish together and must not wait
+// for each other.  A QP's solve is begun with solve_begin_some, advance() enqueues one segment (L iterations + check +
+// the refactorisations the check asks for) for every QP that is iterating, poll() reports the QPs that finished, and the
+// caller updates / warm-starts / begins them again while the rest keeps iterating.  Every QP counts its iterations from
+// its own begin (IS_ITER0), so it takes exactly the iterations, rho updates and checks of a blocking solve of its own:
+// results are those of mi_osqp_batch_solve bit for bit.  Nothing in these calls waits for the device except poll().
+
+static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+static int cont_enter(mi_osqp_batch *h) {
+  mi_osqp_batch::Cont &c = h->cont;
+  if (c.on) return MI_OSQP_OK;
+  if (h->global_xs || h->mw_groups > 0) { g_last_error = "continuous batching serves LDS-resident QPs (a large single QP has no batch to be continuous in)"; return MI_OSQP_ERR_INVALID_DATA; }
+  const Analysis &an = (*h->anp);
+  const int B = h->B, n = an.n, m = an.m, BT = h->BT, nslots = h->ntiles * BT;
+  const Settings &S = h->st;
+  int L = (int)S.max_iter;
+  if (S.check_termination > 0) L = gcd_i(L, (int)S.check_termination);
+  if (S.adaptive_rho && S.adaptive_rho_interval > 0) L = gcd_i(L, (int)S.adaptive_rho_interval);
+  c.L = std::max(1, L);
+  c.running.assign((size_t)B, 0); c.clear_rho.assign((size_t)B, 0); c.start_seq.assign((size_t)B, 0);
+  c.info.assign((size_t)B, mi_osqp_info{});
+  c.n_running = 0; c.tick = 0; c.adv_seq = c.polled_seq = 0;
+  const size_t icnt = (size_t)h->ntiles * IS_COUNT * BT, dcnt = (size_t)h->ntiles * DS_COUNT * BT;
+  for (int k = 0; k < 2; k++) {
+    if (!c.h_is[k]) HIPCHK(hostpool::alloc((void **)&c.h_is[k], icnt * sizeof(int), &c.h_is_cap[k]));
+    if (!c.h_ds[k]) HIPCHK(hostpool::alloc((void **)&c.h_ds[k], dcnt * sizeof(double), &c.h_ds_cap[k]));
+    if (!c.ev[k]) HIPCHK(hipEventCreateWithFlags(&c.ev[k], hipEventDisableTiming));
+    c.seq_of[k] = 0;
+  }
+  if (!c.xh) HIPCHK(hostpool::alloc((void **)&c.xh, (size_t)B * n * sizeof(double), &c.xh_cap));
+  if (!c.yh) HIPCHK(hostpool::alloc((void **)&c.yh, (size_t)B * std::max(m, 1) * sizeof(double), &c.yh_cap));
+  if (!c.ring_h) {
+    // a few rounds of per-QP calls: (A values + bounds + a warm start) of every QP, twice
+    const size_t per_qp = ((size_t)an.Ap[n] + 2 * (size_t)m + (size_t)n + 16) * sizeof(double);
+    const size_t want = std::max<size_t>((size_t)4 << 20, std::min<size_t>((size_t)256 << 20, 2 * per_qp * (size_t)B));
+    HIPCHK(hostpool::alloc((void **)&c.ring_h, want, &c.ring_h_cap));
+    c.ring_cap = c.ring_h_cap;
+    int rc = c.ring_d.alloc(c.ring_cap);
+    if (rc) return rc;
+    c.ring_head = 0;
+  }
+  int rc;
+  if (c.work.n < (size_t)nslots + 4 && (rc = c.work.alloc((size_t)nslots + 4))) return rc;
+  // the state of the last blocking solve, if any, stays valid; every slot is idle until its solve is begun
+  HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
+  for (int t = 0; t < h->ntiles; t++)
+    for (int b = 0; b < BT; b++) {
+      int *p = h->h_iscal + (size_t)t * IS_COUNT * BT;
+      p[IS_DONE * BT + b] = 1; p[IS_ITER0 * BT + b] = 0;
+      if (h->clear_rho_updates) p[IS_RHO_UPDATES * BT + b] = 0;
+      if (t * BT + b < B && h->failed[(size_t)t * BT + b]) p[IS_NEED_REFACTOR * BT + b] = -1;
+    }
+  h->clear_rho_updates = false;
+  HIPCHK(hipMemcpyAsync(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> ident((size_t)nslots);
+  for (int sl = 0; sl < nslots; sl++) ident[sl] = sl < B ? sl : -1;
+  HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  c.on = true;
+  return MI_OSQP_OK;
+}
+
+// leave the continuous mode (a blocking call follows): wait for what is enqueued, forget the solves in flight
+static int cont_leave(mi_osqp_batch *h) {
+  mi_osqp_batch::Cont &c = h->cont;
+  if (!c.on) return MI_OSQP_OK;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT;
+  HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
+  for (int q = 0; q < h->B; q++) {
+    h->failed[q] = h->h_iscal[(size_t)(q / h->BT) * IS_COUNT * h->BT + IS_NEED_REFACTOR * h->BT + q % h->BT] < 0;
+    if (c.clear_rho[q]) h->clear_rho_updates = true;      // (coarser than per QP, like the whole-batch update calls)
+  }
+  // the solutions of the finished QPs, for the whole-batch getters
+  HIPCHK(hipMemcpy(h->x_out.p, c.xh, (size_t)h->B * (*h->anp).n * sizeof(double), hipMemcpyHostToDevice));
+  if ((*h->anp).m) HIPCHK(hipMemcpy(h->y_out.p, c.yh, (size_t)h->B * (*h->anp).m * sizeof(double), hipMemcpyHostToDevice));
+  c.on = false; c.n_running = 0;
+  h->host_bounds_stale = h->host_rho_stale = true;
+  return MI_OSQP_OK;
+}
+
+// a region of the staging ring: host pointer + the device address of the same offset
+struct RingSpan { char *host; char *dev; };
+static int ring_take(mi_osqp_batch *h, size_t bytes, RingSpan &out) {
+  mi_osqp_batch::Cont &c = h->cont;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes > c.ring_cap) { g_last_error = "per-QP call larger than the staging ring"; return MI_OSQP_ERR_ALLOC; }
+  if (c.ring_head + bytes > c.ring_cap) { HIPCHK(hipStreamSynchronize(h->stream)); c.ring_head = 0; }      // everything handed out so far has been consumed
+  out.host = c.ring_h + c.ring_head; out.dev = c.ring_d.p + c.ring_head;
+  c.ring_head += bytes;
+  return MI_OSQP_OK;
+}
+static int ring_upload(mi_osqp_batch *h, const RingSpan &sp, size_t bytes) {
+  if (bytes) HIPCHK(hipMemcpyAsync(sp.dev, sp.host, bytes, hipMemcpyHostToDevice, h->stream));
+  return MI_OSQP_OK;
+}
+
+static int cont_check_ids(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, bool must_be_idle) {
+  if (n_ids < 0 || (n_ids > 0 && !ids)) return MI_OSQP_ERR_NULL;
+  if (n_ids > h->B) return MI_OSQP_ERR_INVALID_DATA;
+  for (int64_t j = 0; j < n_ids; j++) {
+    if (ids[j] < 0 || ids[j] >= h->B) return MI_OSQP_ERR_INVALID_DATA;
+    if (must_be_idle && h->cont.running[(size_t)ids[j]]) { g_last_error = "QP " + std::to_string(ids[j]) + " is still iterating"; return MI_OSQP_ERR_INVALID_DATA; }
+  }
+  return MI_OSQP_OK;
+}
+
+// the id list (as int) and, on request, the selection map of the tile kernels (slot -> position in the list + 1)
+static int cont_stage_ids(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, int **d_ids, int **d_sel) {
+  const int nslots = h->ntiles * h->BT;
+  RingSpan sp;
+  int rc = ring_take(h, ((size_t)n_ids + (d_sel ? (size_t)nslots : 0)) * sizeof(int), sp);
+  if (rc) return rc;
+  int *hi = (int *)sp.host;
+  for (int64_t j = 0; j < n_ids; j++) hi[j] = (int)ids[j];
+  if (d_sel) {
+    int *hs = hi + n_ids;
+    for (int sl = 0; sl < nslots; sl++) hs[sl] = 0;
+    for (int64_t j = 0; j < n_ids; j++) hs[ids[j]] = (int)j + 1;        // (a QP listed twice: its last row wins)
+    *d_sel = (int *)sp.dev + n_ids;
+  }
+  *d_ids = (int *)sp.dev;
+  return ring_upload(h, sp, ((size_t)n_ids + (d_sel ? (size_t)nslots : 0)) * sizeof(int));
+}
+
+// the listed slots' share of the setup snapshot (mi_osqp_batch_reset restores it)
+static int snapshot_some(mi_osqp_batch *h, const int *d_ids, int nq) {
+  const Analysis &an = (*h->anp);
+  hipStream_t st = h->stream;
+  HIPCHK(launch_copy_slot_streams(h->fwd_val0.p, h->fwd_val.p, d_ids, nq, (size_t)an.fwd.phys_steps() * 64, st));
+  HIPCHK(launch_copy_slot_streams(h->bwd_val0.p, h->bwd_val.p, d_ids, nq, (size_t)an.bwd.phys_steps() * 64, st));
+  if (an.dt.k) HIPCHK(launch_copy_slot_streams(h->dt_val0.p, h->dt_val.p, d_ids, nq, (size_t)an.dt.n_steps * 64, st));
+  HIPCHK(launch_copy_slot_rows(h->dinv0.p, h->dinv.p, d_ids, nq, an.N, h->BT, st));
+  HIPCHK(launch_copy_slot_rows(h->rho_vec0.p, h->rho_vec.p, d_ids, nq, an.m, h->BT, st));
+  HIPCHK(launch_copy_slot_rows(h->rho_inv0.p, h->rho_inv.p, d_ids, nq, an.m, h->BT, st));
+  HIPCHK(launch_copy_slot_rows(h->dscal0.p, h->dscal.p, d_ids, nq, DS_COUNT, h->BT, st));
+  return MI_OSQP_OK;
+}
+
+// the refactorisation kernels for a device-resident work list of `count` entries (slots, -1 = none): one QP per workgroup,
+// no group sharing (other handles' kernels may hold the CUs: nothing here may spin on a co-resident partner)
+static int enqueue_refactor_list(mi_osqp_batch *h, const int *d_work, int count) {
+  if (count <= 0) return MI_OSQP_OK;
+  const Analysis &an = (*h->anp);
+  FactorArgs fa = make_factor_args(h, 0);
+  fa.work = d_work; fa.mw_groups = 0;
+  HIPCHK(launch_factor(fa, 1, count, factor_threads(), h->stream));
+  if (an.dt.k) {
+    const DenseTail &dt = an.dt;
+    TailArgs da{};
+    da.n = an.n; da.N = an.N; da.s = dt.s; da.k = dt.k; da.kbt = 1; da.home_bt = h->BT;
+    da.storage = an.bf.storage; da.n_slots = dt.n_steps * 64u; da.n_lt = dt.n_lt; da.n_ltcol = dt.n_ltcol; da.n_quads = (uint32_t)(dt.asm_q64.size() / 64);
+    da.nh = h->dt_nh; da.cs_doubles = h->dt_cs_doubles; da.work = d_work;
+    da.lt_pos = h->dt_lt_pos.p; da.ltcol_col = h->dt_ltcol_col.p; da.tile_tab = h->dt_tile_tab.p; da.wave_tiles = h->dt_wave_tiles.p;
+    da.dt_task = h->dt_task.p; da.dt_task_step = h->dt_task_step.p; da.n_tasks = (uint32_t)(dt.task.size() / 4);
+    da.asm_q64 = h->dt_asm_q64.p; da.diag_tile = h->dt_diag_tile.p; da.src_tile = h->dt_src_tile.p;
+    da.Lblk = h->Lblk.p; da.Dl = h->Dl.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
+    da.trace = nullptr;
+    HIPCHK(launch_tail(da, count, h->dt_lds_asm, h->dt_lds, h->stream));
+  }
+  return MI_OSQP_OK;
+}
+
+// new A values + bounds of the listed QPs: equilibration on the device (fresh: from the raw P and q of setup; else unscale
+// with the scaling in force first, as QPSolver::update does), check streams, refactorisation, snapshot.  All enqueued.
+static int cont_new_data(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *Av, const double *l, const double *u, bool fresh) {
+  const Analysis &an = (*h->anp);
+  const int n = an.n, m = an.m, nnzP = an.Pp[n], nnzA = an.Ap[n], pa_len = nnzP + nnzA, nq = (int)n_ids;
+  int rc;
+  for (size_t k = 0; k < (size_t)nq * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  int *d_ids = nullptr;
+  if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, nullptr))) return rc;
+  const size_t cA = (size_t)nq * nnzA, cb = (size_t)nq * m, cpa = (size_t)nq * pa_len;
+  RingSpan in, out;
+  if ((rc = ring_take(h, (cA + 2 * cb) * sizeof(double), in)) || (rc = ring_take(h, std::max<size_t>(cpa, 1) * sizeof(double), out))) return rc;
+  double *hin = (double *)in.host, *din = (double *)in.dev;
+  memcpy(hin, Av, cA * sizeof(double)); memcpy(hin + cA, l, cb * sizeof(double)); memcpy(hin + cA + cb, u, cb * sizeof(double));
+  if ((rc = ring_upload(h, in, (cA + 2 * cb) * sizeof(double)))) return rc;
+  KernelArgs ka = make_args(h);
+  if (fresh) HIPCHK(launch_fresh_slots(ka, d_ids, nq, h->BT, h->st.rho, h->stream));
+  RuizArgs r{};
+  r.n = n; r.m = m; r.nnzP = nnzP; r.nnzA = nnzA; r.B = nq; r.BT = h->BT; r.iters = (int)h->st.scaling;
+  r.ids = d_ids; r.fresh = fresh ? 1 : 0; r.rawP = h->rawP.p; r.rawq = h->rawq.p;
+  r.Prow = h->rz_prow.p; r.Pcol = h->rz_pcol.p; r.Arow = h->rz_arow.p; r.Acol = h->rz_acol.p;
+  r.rawA = din; r.rawl = din + cA; r.rawu = din + cA + cb;
+  r.pa_val = h->pa_val.p; r.q = h->q.p; r.Dsc = h->Dsc.p; r.Dsc_inv = h->Dsc_inv.p; r.Esc = h->Esc.p; r.Esc_inv = h->Esc_inv.p;
+  r.l = h->l.p; r.u = h->u.p; r.dscal = h->dscal.p;
+  r.dn = h->out1.p; r.en = h->out1.p + (size_t)h->B * n;
+  r.pa_out = (double *)out.dev;
+  HIPCHK(launch_ruiz(r, h->stream));
+  HIPCHK(launch_scatter(r.pa_out, h->chk_val.p, h->chk.src.p, d_ids, nq, pa_len, h->chk.view(an.chk), h->BT, h->stream));
+  if ((rc = enqueue_refactor_list(h, d_ids, nq))) return rc;
+  if ((rc = snapshot_some(h, d_ids, nq))) return rc;
+  for (int64_t j = 0; j < n_ids; j++) { h->cont.clear_rho[(size_t)ids[j]] = 1; h->failed[(size_t)ids[j]] = 0; }
+  h->host_scaling_stale = true; h->host_bounds_stale = true; h->host_rho_stale = true;
+  return MI_OSQP_OK;
+}
+
+extern "C" {
+
+int mi_osqp_batch_reinit_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *Av, const double *l, const double *u) {
+  CallTimer timer_("batch_reinit_some");
+  if (!h || (n_ids > 0 && (!Av || !l || !u))) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
+  int rc;
+  if ((rc = cont_enter(h)) || (rc = cont_check_ids(h, n_ids, ids, true))) return rc;
+  if (!n_ids) return MI_OSQP_OK;
+  return cont_new_data(h, n_ids, ids, Av, l, u, true);
+}
+
+int mi_osqp_batch_update_A_bounds_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *Av, const double *l, const double *u) {
+  CallTimer timer_("batch_update_A_bounds_some");
+  if (!h || (n_ids > 0 && (!Av || !l || !u))) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
+  int rc;
+  if ((rc = cont_enter(h)) || (rc = cont_check_ids(h, n_ids, ids, true))) return rc;
+  if (!n_ids) return MI_OSQP_OK;
+  return cont_new_data(h, n_ids, ids, Av, l, u, false);
+}
+
+int mi_osqp_batch_warm_start_x_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *x) {
+  CallTimer timer_("batch_warm_start_x_some");
+  if (!h || (n_ids > 0 && !x)) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
+  int rc;
+  if ((rc = cont_enter(h)) || (rc = cont_check_ids(h, n_ids, ids, true))) return rc;
+  if (!n_ids) return MI_OSQP_OK;
+  h->st.warm_start = 1;
+  const size_t cnt = (size_t)n_ids * (*h->anp).n;
+  int *d_ids = nullptr, *d_sel = nullptr;
+  RingSpan sp;
+  if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, &d_sel)) || (rc = ring_take(h, cnt * sizeof(double), sp))) return rc;
+  memcpy(sp.host, x, cnt * sizeof(double));
+  if ((rc = ring_upload(h, sp, cnt * sizeof(double)))) return rc;
+  KernelArgs a = make_args(h);
+  a.sel = d_sel;
+  HIPCHK(launch_warm_start(a, h->BT, h->ntiles, h->threads, h->lds, h->stream, (const double *)sp.dev));
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_solve_begin_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids) {
+  CallTimer timer_("batch_solve_begin_some");
+  if (!h) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
+  int rc;
+  if ((rc = cont_enter(h)) || (rc = cont_check_ids(h, n_ids, ids, true))) return rc;
+  if (!n_ids) return MI_OSQP_OK;
+  mi_osqp_batch::Cont &c = h->cont;
+  if (c.n_running == 0) c.tick = 0;           // (launches already enqueued carry their own iteration numbers)
+  RingSpan sp;
+  if ((rc = ring_take(h, 2 * (size_t)n_ids * sizeof(int), sp))) return rc;
+  int *hi = (int *)sp.host;
+  for (int64_t j = 0; j < n_ids; j++) {
+    const size_t q = (size_t)ids[j];
+    hi[j] = (int)q; hi[n_ids + j] = c.clear_rho[q] ? 1 : 0;
+    c.clear_rho[q] = 0;
+  }
+  if ((rc = ring_upload(h, sp, 2 * (size_t)n_ids * sizeof(int)))) return rc;
+  KernelArgs a = make_args(h);
+  a.x_out = c.xh; a.y_out = c.yh;
+  // (a QP whose last refactorisation lost the inertia carries flag -1 on the device: start_slots_kernel ends it as kNonConvex)
+  HIPCHK(launch_start_slots(a, (const int *)sp.dev, (const int *)sp.dev + n_ids, (int)n_ids, h->BT, c.tick, h->st.warm_start ? 0 : 1, h->stream));
+  for (int64_t j = 0; j < n_ids; j++) {
+    const size_t q = (size_t)ids[j];
+    if (!c.running[q]) { c.running[q] = 1; c.n_running++; }
+    c.start_seq[q] = c.adv_seq;
+  }
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_advance(mi_osqp_batch *h, int64_t n_segments) {
+  CallTimer timer_("batch_advance");
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (n_segments <= 0) return MI_OSQP_ERR_INVALID_DATA;
+  DevGuard guard(h->device);
+  int rc;
+  if ((rc = cont_enter(h))) return rc;
+  mi_osqp_batch::Cont &c = h->cont;
+  if (c.adv_seq - c.polled_seq >= 2) { g_last_error = "advance: two advances are waiting for poll()"; return MI_OSQP_ERR_INVALID_DATA; }
+  const int BT = h->BT, nslots = h->ntiles * BT;
+  KernelArgs a = make_args(h);
+  a.x_out = c.xh; a.y_out = c.yh;
+  for (int64_t sgm = 0; sgm < n_segments; sgm++) {
+    a.iter_begin = c.tick; a.iter_end = c.tick + c.L; a.info_at_end = 1;
+    c.tick += c.L;
+    HIPCHK(launch_iterate(a, BT, h->ntiles, h->threads, h->lds, h->stream));
+    HIPCHK(launch_check(a, BT, h->ntiles, h->threads, h->lds, h->stream));
+    if (h->st.adaptive_rho) {
+      // row E13 without the host: the slots whose rho changed are listed on the device, refactored, and the ones whose
+      // new factor lost its inertia end as kNonConvex
+      HIPCHK(launch_worklist(h->iscal.p, c.work.p, nslots, BT, h->stream));
+      if ((rc = enqueue_refactor_list(h, c.work.p, nslots))) return rc;
+      HIPCHK(launch_fail_flagged(a, nslots, BT, h->stream));
+    }
+  }
+  const int par = (int)(c.adv_seq & 1);
+  const size_t icnt = (size_t)h->ntiles * IS_COUNT * BT, dcnt = (size_t)h->ntiles * DS_COUNT * BT;
+  HIPCHK(hipMemcpyAsync(c.h_is[par], h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(c.h_ds[par], h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipEventRecord(c.ev[par], h->stream));
+  c.adv_seq++;
+  c.seq_of[par] = c.adv_seq;
+  h->host_rho_stale = true;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_poll(mi_osqp_batch *h, int64_t wait, int64_t *n_finished, int64_t *ids_out, int64_t capacity) {
+  CallTimer timer_("batch_poll");
+  if (!h || !n_finished) return MI_OSQP_ERR_NULL;
+  *n_finished = 0;
+  mi_osqp_batch::Cont &c = h->cont;
+  if (!c.on || c.polled_seq >= c.adv_seq) return MI_OSQP_OK;      // nothing enqueued
+  DevGuard guard(h->device);
+  const int64_t seq = c.polled_seq + 1;
+  const int par = (int)((seq - 1) & 1);
+  if (!wait) {
+    hipError_t e = hipEventQuery(c.ev[par]);
+    if (e == hipErrorNotReady) { *n_finished = -1; return MI_OSQP_OK; }
+    HIPCHK(e);
+  } else HIPCHK(hipEventSynchronize(c.ev[par]));
+  const int BT = h->BT;
+  int64_t nf = 0;
+  // (the caller's buffer must take every finished QP of this advance: with less room nothing is consumed)
+  int64_t would = 0;
+  for (int q = 0; q < h->B; q++)
+    if (c.running[q] && c.start_seq[q] < seq && c.h_is[par][(size_t)(q / BT) * IS_COUNT * BT + IS_DONE * BT + q % BT]) would++;
+  if (would > capacity || (would > 0 && !ids_out)) { *n_finished = would; g_last_error = "poll: ids_out too small"; return MI_OSQP_ERR_INVALID_DATA; }
+  for (int q = 0; q < h->B; q++) {
+    if (!c.running[q] || c.start_seq[q] >= seq) continue;
+    const int *ti = c.h_is[par] + (size_t)(q / BT) * IS_COUNT * BT;
+    const int b = q % BT;
+    if (!ti[IS_DONE * BT + b]) continue;
+    const double *td = c.h_ds[par] + (size_t)(q / BT) * DS_COUNT * BT;
+    mi_osqp_info &I = c.info[(size_t)q];
+    I.iter = ti[IS_ITER * BT + b]; I.status_val = ti[IS_STATUS * BT + b]; I.exit_code = exit_code_of((int)I.status_val);
+    I.obj_val = td[DS_OBJ * BT + b]; I.pri_res = td[DS_PRI_RES * BT + b]; I.dua_res = td[DS_DUA_RES * BT + b];
+    I.rho_updates = ti[IS_RHO_UPDATES * BT + b]; I.rho_estimate = td[DS_RHO_EST * BT + b]; I.rho = td[DS_RHO * BT + b];
+    if (ti[IS_NEED_REFACTOR * BT + b] < 0) h->failed[(size_t)q] = 1;
+    c.running[q] = 0; c.n_running--;
+    ids_out[nf++] = q;
+  }
+  c.polled_seq = seq;
+  *n_finished = nf;
+  return MI_OSQP_OK;
+}
+
+int mi_osqp_batch_get_primal_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, double *x_out) {
+  if (!h || (n_ids > 0 && (!ids || !x_out))) return MI_OSQP_ERR_NULL;
+  if (!h->cont.on) return MI_OSQP_ERR_INVALID_DATA;
+  const size_t n = (size_t)(*h->anp).n;
+  for (int64_t j = 0; j < n_ids; j++) {
+    if (ids[j] < 0 || ids[j] >= h->B) return MI_OSQP_ERR_INVALID_DATA;
+    memcpy(x_out + (size_t)j * n, h->cont.xh + (size_t)ids[j] * n, n * sizeof(double));
+  }
+  return MI_OSQP_OK;
+}
+int mi_osqp_batch_get_dual_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, double *y_out) {
+  if (!h || (n_ids > 0 && (!ids || !y_out))) return MI_OSQP_ERR_NULL;
+  if (!h->cont.on) return MI_OSQP_ERR_INVALID_DATA;
+  const size_t m = (size_t)(*h->anp).m;
+  for (int64_t j = 0; j < n_ids; j++) {
+    if (ids[j] < 0 || ids[j] >= h->B) return MI_OSQP_ERR_INVALID_DATA;
+    memcpy(y_out + (size_t)j * m, h->cont.yh + (size_t)ids[j] * m, m * sizeof(double));
+  }
+  return MI_OSQP_OK;
+}
+int mi_osqp_batch_get_info_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, mi_osqp_info *info) {
+  if (!h || (n_ids > 0 && (!ids || !info))) return MI_OSQP_ERR_NULL;
+  if (!h->cont.on) return MI_OSQP_ERR_INVALID_DATA;
+  for (int64_t j = 0; j < n_ids; j++) {
+    if (ids[j] < 0 || ids[j] >= h->B) return MI_OSQP_ERR_INVALID_DATA;
+    info[j] = h->cont.info[(size_t)ids[j]];
+  }
+  return MI_OSQP_OK;
+}
+int64_t mi_osqp_batch_running(mi_osqp_batch *h) { return h && h->cont.on ? h->cont.n_running : 0; }
+
+}  // extern "C"
+
+extern "C" {
 
 // ------------------------------------------------------------------ single QP
 
