@@ -26,7 +26,11 @@
 #include <optional>
 #include <tuple>
 #include <utility>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -590,6 +594,262 @@ class BatchGOMPSolver {
   template <class F>
   static void parallel_for_(size_t count, F &&body) {
     const size_t nt = std::min<size_t>({count, 16, std::max(1u, std::thread::hardware_concurrency())});
+    if (nt <= 1) { for (size_t k = 0; k < count; ++k) body(k); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t k = t; k < count; k += nt) body(k); });
+    for (auto &x : th) x.join();
+  }
+
+  // initConstraints of GOMPSolver ([REF] src/gomp-solver.h:98-110) without its last call (the obstacle rows), normalised
+  ConstraintBuilder<N_DIM> jointSpaceTemplate(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, size_t waypoints) const {
+    ConstraintBuilder<N_DIM> b{waypoints, mappers, obstacles};
+    b.position(0, constraints::equal<N_DIM>(start_pos))
+        .positions(1, waypoints - 2, pos_con)
+        .position(waypoints - 3, constraints::equal<N_DIM>(end_pos))
+        .velocities(0, waypoints - 4, vel_con)
+        .velocity(waypoints - 3, constraints::eqZero<N_DIM>())
+        .accelerations(0, waypoints - 4, acc_con)
+        .acceleration(waypoints - 3, constraints::eqZero<N_DIM>())
+        .normalised();
+    return b;
+  }
+
+  bool isSolutionOK(const QPVector &q_trajectory) const {
+    bool res = true;
+    for (const RobotBall &ball : mappers) {
+      const QPVector xyz = mapJointTrajectoryToXYZ<N_DIM>(q_trajectory, ball.fk);
+      const int waypoints = (int)xyz.size() / 3;
+      for (int w = 0; w < waypoints; ++w) {
+        const Point p{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]};
+        if (ball.is_gripper) {
+          for (Axis axis : XYZ_AXES) {
+            const double lo = con_3d.first ? (*con_3d.first)[axis] : -INF;
+            const double up = con_3d.second ? (*con_3d.second)[axis] : INF;
+            if (!(lo - ERROR <= p[axis] - ball.radius && p[axis] + ball.radius <= up + ERROR)) res = false;
+          }
+        }
+        for (const HorizontalLine &line : obstacles)
+          if (line.hasCollision(w, xyz, ball) && !line.isAbove(p, ball)) res = false;
+      }
+    }
+    return res;
+  }
+};
+
+// ------------------------------------------------- continuous driver (SURVEY 8(f) rank 1 without the lock-step)
+// The reference's loop is per trajectory: solve -> check -> re-linearise -> update -> solve again, one horizon after the
+// other ([REF] src/gomp-solver.h:38-91).  BatchGOMPSolver advances B trajectories in lock-step and waits for the slowest
+// QP of every round; here every trajectory walks through GOMPSolver::run on its own.  The ten horizons are ten STAGES:
+// one ContinuousQPSolver (B slots, slot = trajectory) and one host thread each.  A trajectory entering a stage gets a
+// freshly constructed QP in its slot (reinit: what [REF] src/gomp-solver.h:61-65 does), is warm-started and begun; the
+// stage thread advances whatever is iterating in its solver, and as soon as ONE QP has finished its trajectory is
+// checked, re-linearised and updated ([REF] :70-88) or handed to the next stage - while the other QPs keep iterating
+// and the other stages run side by side on their own streams.  Every trajectory takes exactly the decisions of a
+// sequential GOMPSolver::run: same QPs, same updates, same accepted solutions (tests/cpp/gomp_parity.cpp `cont`).
+template <size_t N_DIM, class ContSolverT = ContinuousQPSolver>
+class ContinuousGOMPSolver {
+ public:
+  ContinuousGOMPSolver(size_t waypoints, double time_step, const Constraint<N_DIM> &pos_con, const Constraint<N_DIM> &vel_con,
+                       const Constraint<N_DIM> &acc_con, const Constraint<3> &con_3d, std::vector<HorizontalLine> obstacles,
+                       std::vector<RobotBall> m, bool verbose = false)
+      : max_waypoints(waypoints), time_step(time_step), pos_con(pos_con),
+        vel_con(constraints::scaled<N_DIM>(vel_con, time_step)),
+        acc_con(constraints::scaled<N_DIM>(acc_con, time_step * time_step)), con_3d(con_3d),
+        obstacles(std::move(obstacles)), mappers(std::move(m)), verbose(verbose) {
+    assert(max_waypoints >= 4);
+  }
+
+  std::vector<std::pair<ExitCode, QPVector>> run(const std::vector<Ctrl<N_DIM>> &starts, const std::vector<Ctrl<N_DIM>> &ends) {
+    const size_t B = starts.size();
+    assert(ends.size() == B && B > 0);
+    starts_ = &starts; ends_ = &ends;
+    traj_.clear(); traj_.resize(B);
+    segments_run.assign(B, 0); qp_solves.assign(B, 0); qp_updates.assign(B, 0);
+    advances = 0; solver_reuses = 0;
+    for (size_t b = 0; b < B; ++b) {
+      traj_[b].last_solution = linspace<N_DIM>(starts[b], ends[b], max_waypoints);      // joint-space line, zero velocities
+      traj_[b].last_solution.resize(2 * max_waypoints * N_DIM, 0.0);
+      traj_[b].builder = std::make_unique<ConstraintBuilder<N_DIM>>(4, std::vector<RobotBall>{}, std::vector<HorizontalLine>{});
+    }
+    for (int s = 0; s < SEGMENTS; ++s) {
+      stages_[s].waypoints = max_waypoints * (size_t)(SEGMENTS - s) / SEGMENTS;
+      stages_[s].inbox.clear();
+      stages_[s].first_admission = true;
+      stages_[s].seconds_admit = stages_[s].seconds_wait = stages_[s].seconds_process = stages_[s].seconds_idle = 0.0;
+      stages_[s].n_advances = 0;
+    }
+    for (size_t b = 0; b < B; ++b) stages_[0].inbox.push_back(b);
+    finished_ = 0; failed_ = false;
+    std::vector<std::thread> th;
+    for (int s = 0; s < SEGMENTS; ++s) th.emplace_back([this, s, B] { stageLoop(s, B); });
+    for (auto &t : th) t.join();
+    std::vector<std::pair<ExitCode, QPVector>> out(B);
+    for (size_t b = 0; b < B; ++b) {
+      QPVector &x = traj_[b].last_solution;
+      for (size_t t = x.size() / 2; t < x.size(); ++t) x[t] /= time_step;
+      out[b] = {traj_[b].last_code, x};
+    }
+    return out;
+  }
+
+  // per-trajectory counters (comparable with GOMPSolver's)
+  std::vector<int> segments_run, qp_solves, qp_updates;
+  std::atomic<long> advances{0};       // advance() calls of all stages
+  std::atomic<int> solver_reuses{0};   // stages whose solver was kept from the previous run()
+  int pipeline_depth = 1;              // 2: a stage enqueues its next advance before it looks at the previous one's results
+  // per stage: {waypoints, advances, seconds admitting, waiting for the device, processing finished QPs, idle}
+  std::vector<std::array<double, 6>> stageProfile() const {
+    std::vector<std::array<double, 6>> r;
+    for (const Stage &st : stages_) r.push_back({(double)st.waypoints, (double)st.n_advances, st.seconds_admit, st.seconds_wait, st.seconds_process, st.seconds_idle});
+    return r;
+  }
+
+ private:
+  const size_t max_waypoints;
+  const double time_step;
+  const Constraint<N_DIM> pos_con, vel_con, acc_con;
+  const Constraint<3> con_3d;
+  const std::vector<HorizontalLine> obstacles;
+  const std::vector<RobotBall> mappers;
+  const bool verbose;
+
+  struct Traj {
+    QPVector last_solution, warm, seg_solution;
+    ExitCode last_code = ExitCode::kUnknown, seg_code = ExitCode::kUnknown;
+    std::unique_ptr<ConstraintBuilder<N_DIM>> builder;
+    QPConstraints cons;
+    int sqp_it = 0;
+  };
+  struct Stage {
+    size_t waypoints = 0;
+    std::unique_ptr<ContSolverT> qp;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<size_t> inbox;                       // trajectories that have reached this horizon
+    bool first_admission = true;
+    // where the stage thread's time went in the last run(): preparing + admitting arrivals, waiting for the device in
+    // poll(), checking / re-linearising / updating finished QPs, waiting for arrivals
+    double seconds_admit = 0.0, seconds_wait = 0.0, seconds_process = 0.0, seconds_idle = 0.0;
+    long n_advances = 0;
+  };
+  std::vector<Traj> traj_;
+  std::array<Stage, SEGMENTS> stages_;
+  const std::vector<Ctrl<N_DIM>> *starts_ = nullptr, *ends_ = nullptr;
+  std::atomic<size_t> finished_{0};
+  std::atomic<bool> failed_{false};
+
+  void wakeAll() { for (Stage &st : stages_) { std::lock_guard<std::mutex> lk(st.mu); st.cv.notify_all(); } }
+
+  void stageLoop(int s, size_t B) {
+    Stage &st = stages_[(size_t)s];
+    const size_t W = st.waypoints;
+    const QPMatrixSparse P = triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * W), (int)(W * N_DIM), (int)N_DIM);
+    const ConstraintBuilder<N_DIM> tmpl = jointSpaceTemplate((*starts_)[0], (*ends_)[0], W);
+    int in_flight = 0;                               // advances enqueued and not polled
+    std::vector<size_t> arrivals;
+    using clk_ = std::chrono::steady_clock;
+    auto lap = [t = clk_::now()](double &acc) mutable { const auto now = clk_::now(); acc += std::chrono::duration<double>(now - t).count(); t = now; };
+    double other = 0.0;
+    while (finished_.load() < B && !failed_.load()) {
+      // ---- trajectories that have reached this horizon: a freshly constructed QP each ([REF] src/gomp-solver.h:57-65)
+      arrivals.clear();
+      {
+        std::unique_lock<std::mutex> lk(st.mu);
+        const bool idle = in_flight == 0 && (!st.qp || st.qp->running() == 0);
+        lap(other);
+        if (idle) st.cv.wait(lk, [&] { return !st.inbox.empty() || finished_.load() >= B || failed_.load(); });
+        lap(st.seconds_idle);
+        while (!st.inbox.empty()) { arrivals.push_back(st.inbox.front()); st.inbox.pop_front(); }
+      }
+      if (!arrivals.empty()) { admit(st, P, tmpl, arrivals, B); lap(st.seconds_admit); }
+      if (!st.qp) continue;
+      // ---- one segment for everything that iterates here; the finished QPs decide the next step of their trajectories
+      if (st.qp->running() > 0 && in_flight < pipeline_depth) {
+        if (!st.qp->advance(1)) { failed_ = true; wakeAll(); break; }
+        ++in_flight; ++advances; ++st.n_advances;
+      }
+      if (in_flight == 0) continue;
+      if (in_flight < pipeline_depth && st.qp->running() > 0) continue;       // (fill the pipeline first)
+      lap(other);
+      const std::vector<long long> done = st.qp->poll();
+      lap(st.seconds_wait);
+      --in_flight;
+      if (!done.empty()) { process(s, st, done, B); lap(st.seconds_process); }
+    }
+    // leave nothing enqueued behind
+    while (st.qp && in_flight-- > 0) (void)st.qp->poll();
+  }
+
+  void admit(Stage &st, const QPMatrixSparse &P, const ConstraintBuilder<N_DIM> &tmpl, const std::vector<size_t> &arrivals, size_t B) {
+    const size_t W = st.waypoints;
+    auto prepare = [&](size_t k) {
+      Traj &T = traj_[arrivals[k]];
+      const QPVector &prev = T.last_solution;
+      T.warm.resize(W * N_DIM * 2);
+      for (size_t t = 0; t < W * N_DIM; ++t) {               // same slicing as GOMPSolver::run
+        T.warm[t] = prev[t];
+        T.warm[W * N_DIM + t] = prev[W * N_DIM + t];
+      }
+      *T.builder = tmpl;
+      T.builder->position(0, constraints::equal<N_DIM>((*starts_)[arrivals[k]]))
+          .position(W - 3, constraints::equal<N_DIM>((*ends_)[arrivals[k]]))
+          .withObstacles(con_3d, T.warm);
+      T.cons = T.builder->build();
+      T.seg_solution = T.warm; T.seg_code = ExitCode::kUnknown; T.sqp_it = 0;
+    };
+    parallelFor(arrivals.size(), prepare);
+    if (st.qp && !st.qp->compatible((long long)B, traj_[arrivals[0]].cons, P)) st.qp.reset();
+    if (st.qp) { if (st.first_admission) ++solver_reuses; }                       // (kept from the previous run(): every slot is re-initialised on arrival)
+    else st.qp = std::make_unique<ContSolverT>((long long)B, traj_[arrivals[0]].cons, P, verbose);
+    st.first_admission = false;
+    std::vector<long long> ids;
+    std::vector<const QPConstraints *> cs;
+    std::vector<const QPVector *> xs;
+    for (size_t b : arrivals) { ids.push_back((long long)b); cs.push_back(&traj_[b].cons); xs.push_back(&traj_[b].warm); }
+    st.qp->reinit(ids, cs);
+    st.qp->setWarmStart(ids, xs);
+    st.qp->begin(ids);
+  }
+
+  void process(int s, Stage &st, const std::vector<long long> &done, size_t B) {
+    std::vector<long long> again;
+    std::vector<const QPConstraints *> cs;
+    std::vector<size_t> leaving;
+    for (long long id : done) {
+      const size_t b = (size_t)id;
+      Traj &T = traj_[b];
+      auto [exit_code, solution] = st.qp->result(id);
+      ++qp_solves[b];
+      bool ends_here = true;
+      if (exit_code != ExitCode::kOptimal) T.seg_solution = std::move(solution);                          // there are no solutions
+      else if (isSolutionOK(solution)) { T.seg_solution = std::move(solution); T.seg_code = ExitCode::kOptimal; }
+      else {
+        // (the reference re-linearises and updates also in the last of its MAX_ITERATIONS rounds; that update has no reader)
+        ++qp_updates[b];
+        if (++T.sqp_it < MAX_ITERATIONS) {
+          T.cons = T.builder->withObstacles(con_3d, solution).build();
+          again.push_back(id); cs.push_back(&T.cons);
+          ends_here = false;
+        }
+      }
+      if (ends_here) leaving.push_back(b);
+    }
+    if (!again.empty()) { st.qp->update(again, cs); st.qp->begin(again); }
+    for (size_t b : leaving) {
+      Traj &T = traj_[b];
+      ++segments_run[b];
+      if (T.seg_code == ExitCode::kOptimal) { T.last_code = ExitCode::kOptimal; T.last_solution = T.seg_solution; }
+      if (s + 1 < SEGMENTS) {
+        Stage &nx = stages_[(size_t)s + 1];
+        { std::lock_guard<std::mutex> lk(nx.mu); nx.inbox.push_back(b); }
+        nx.cv.notify_one();
+      } else if (finished_.fetch_add(1) + 1 >= B) wakeAll();
+    }
+  }
+
+  template <class F>
+  static void parallelFor(size_t count, F &&body) {
+    const size_t nt = std::min<size_t>({count / 8, 8, std::max(1u, std::thread::hardware_concurrency())});
     if (nt <= 1) { for (size_t k = 0; k < count; ++k) body(k); return; }
     std::vector<std::thread> th;
     for (size_t t = 0; t < nt; ++t) th.emplace_back([&, t] { for (size_t k = t; k < count; k += nt) body(k); });

@@ -6,6 +6,7 @@
 //                         include/mi_osqp/gomp.hpp.  Expected numbers are the reference's data.
 //   ./gomp_parity ur5e    CPU: UR5e kinematics header + the scenario of examples/gomp_example.cpp on the oracle.
 //   ./gomp_parity batch   GPU: BatchGOMPSolver (lock-step on the batch API) vs sequential drivers.
+//   ./gomp_parity cont    GPU: ContinuousGOMPSolver (per-QP entry points, one stage per horizon) vs sequential drivers.
 //   ./gomp_parity parity  GPU: runs GOMPSolver<3> twice on the same inputs -- once on the MI355X
 //                         QPSolver, once on an oracle-backed twin -- and compares trajectories.
 #include <chrono>
@@ -256,6 +257,69 @@ static int run_batch(int seed = 0) {
   return fails ? 1 : 0;
 }
 
+// GPU: the continuous driver (one stage per horizon, every trajectory on its own schedule) vs one sequential GOMPSolver per
+// trajectory on the GPU QPSolver and on the oracle twin: same exit codes, same per-trajectory counters, same trajectories.
+static int run_cont(int seed = 0) {
+  const double pi = 3.14159265358979323846;
+  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}};
+  std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
+  auto pos = constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi));
+  auto vel = constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi));
+  auto acc = constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180));
+  auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF});
+  std::vector<Ctrl<3>> starts, ends;
+  for (int b = 0; b < 5; ++b) {
+    starts.push_back({-0.8 + 0.1 * b, 0.3 + 0.02 * b, 0.4 - 0.03 * b});
+    ends.push_back({0.8 - 0.05 * b, 0.3, 0.4 + 0.02 * b});
+  }
+  starts.push_back({0.2, 0.5, 0.3}); ends.push_back({0.5, 0.6, 0.2});          // never comes near the line
+  if (seed) {
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    starts.clear(); ends.clear();
+    for (int b = 0; b < 9; ++b) {
+      starts.push_back({-0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+      ends.push_back({0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+    }
+  }
+  for (int depth = 1; depth <= 2; ++depth) {
+    ContinuousGOMPSolver<3> cg(40, 0.1, pos, vel, acc, c3d, lines, balls);
+    cg.pipeline_depth = depth;
+    auto rc = cg.run(starts, ends);
+    const std::vector<int> solves1 = cg.qp_solves, updates1 = cg.qp_updates;
+    auto rc2 = cg.run(starts, ends);                 // the stage solvers are kept: every slot is re-initialised, nothing is rebuilt
+    CHECK(cg.solver_reuses == SEGMENTS);
+    CHECK(cg.qp_solves == solves1 && cg.qp_updates == updates1);
+    for (size_t b = 0; b < starts.size(); ++b) { CHECK(rc2[b].first == rc[b].first); CHECK(rc2[b].second == rc[b].second); }
+    int total_updates = 0;
+    for (size_t b = 0; b < starts.size(); ++b) {
+      GOMPSolver<3, QPSolver> g(40, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+      auto [code_g, x_g] = g.run(starts[b], ends[b]);
+      GOMPSolver<3, OracleQPSolver> o(40, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+      auto [code_o, x_o] = o.run(starts[b], ends[b]);
+      double md_g = 0.0, md_o = 0.0;
+      CHECK(rc[b].second.size() == x_g.size() && x_g.size() == x_o.size());
+      for (size_t k = 0; k < x_g.size() && k < rc[b].second.size(); ++k) {
+        md_g = std::fmax(md_g, std::fabs(rc[b].second[k] - x_g[k]));
+        md_o = std::fmax(md_o, std::fabs(rc[b].second[k] - x_o[k]));
+      }
+      std::printf("depth %d traj %zu continuous: %s segments %d solves %d updates %d | sequential gpu: %s %d %d %d | oracle: %s %d %d %d | max|dx| gpu %.3e oracle %.3e\n",
+                  depth, b, ToString(rc[b].first).c_str(), cg.segments_run[b], cg.qp_solves[b], cg.qp_updates[b], ToString(code_g).c_str(),
+                  g.segments_run, g.qp_solves, g.qp_updates, ToString(code_o).c_str(), o.segments_run, o.qp_solves, o.qp_updates, md_g, md_o);
+      CHECK(rc[b].first == code_g && code_g == code_o);
+      CHECK(cg.segments_run[b] == g.segments_run && cg.qp_solves[b] == g.qp_solves && cg.qp_updates[b] == g.qp_updates);
+      CHECK(g.qp_solves == o.qp_solves && g.qp_updates == o.qp_updates);
+      CHECK(md_g <= 1e-9);
+      CHECK(md_o <= 1e-6);
+      total_updates += cg.qp_updates[b];
+    }
+    if (!seed) CHECK(total_updates > 0);
+    std::printf("depth %d: %ld advances for %zu trajectories\n", depth, cg.advances.load(), starts.size());
+  }
+  std::printf(fails ? "CONT FAILED (%d)\n" : "CONT OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 // GPU: BASELINE config 4 as an end-to-end workload: B joint-space trajectories (7-DOF, W = 100, limits as
 // [REF] examples/solver-example.cpp:44-46 replicated to 7 joints) through the batched driver, timed against
 // the sequential driver on the oracle backend for a sample of them.   usage: gomp_parity bench [B] [W] [sample]
@@ -400,6 +464,39 @@ static int run_obstacle_bench(int B, int W, int sample) {
               B, W, t1, t2, B / t2, solves, updates, bg.batch_solves, ok);
   std::printf("  of which: building constraints %.3f s, QP setup %.3f s, batched solves %.3f s, checks + re-linearisation + updates %.3f s\n",
               bg.seconds_build, bg.seconds_setup, bg.seconds_solve, bg.seconds_update);
+  {     // the continuous driver on the same scene: every trajectory on its own schedule, nobody waits for the slowest QP
+    const int depth = getenv("GOMP_PIPELINE_DEPTH") ? std::atoi(getenv("GOMP_PIPELINE_DEPTH")) : 1;
+    ContinuousGOMPSolver<3> cg((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls);
+    cg.pipeline_depth = depth;
+    t0 = clk::now();
+    auto c1 = cg.run(starts, ends);
+    const double tc1 = std::chrono::duration<double>(clk::now() - t0).count();
+    double best = 1e30;
+    std::vector<std::pair<ExitCode, QPVector>> c2;
+    for (int rep = 0; rep < 3; ++rep) {
+      t0 = clk::now();
+      c2 = cg.run(starts, ends);
+      best = std::fmin(best, std::chrono::duration<double>(clk::now() - t0).count());
+    }
+    int cok = 0, csolves = 0, cupdates = 0, same_bits = 0;
+    double mdl = 0.0;
+    for (int b = 0; b < B; ++b) {
+      cok += c2[b].first == ExitCode::kOptimal; csolves += cg.qp_solves[b]; cupdates += cg.qp_updates[b];
+      CHECK(c2[b].first == c1[b].first); CHECK(c2[b].second == c1[b].second);
+      CHECK(c2[b].first == r2[b].first); CHECK(cg.qp_solves[b] == bg.qp_solves[b]);
+      CHECK(cg.qp_updates[b] == bg.qp_updates[b] || cg.qp_solves[b] >= MAX_ITERATIONS);
+      same_bits += c2[b].second == r2[b].second;
+      if (c2[b].second.size() == r2[b].second.size()) for (size_t k = 0; k < c2[b].second.size(); ++k) mdl = std::fmax(mdl, std::fabs(c2[b].second[k] - r2[b].second[k]));
+    }
+    CHECK(mdl <= 1e-9);
+    std::printf("continuous driver with an obstacle (pipeline depth %d): %d trajectories (D=3, W=%d): first run %.3f s, later runs %.3f s = %.1f trajectories/s; %d QP solves, %d updates, %ld advances, %d optimal; "
+                "%d of %d trajectories bitwise equal to the lock-step driver's, max|dx| %.2e\n",
+                depth, B, W, tc1, best, B / best, csolves, cupdates, cg.advances.load(), cok, same_bits, B, mdl);
+    if (getenv("GOMP_STAGE_PROFILE"))
+      for (const auto &sp : cg.stageProfile())
+        std::printf("  stage W=%3.0f: %4.0f advances; admitting %.3f s, waiting for the device %.3f s, checks + re-linearisation + updates %.3f s, idle %.3f s\n",
+                    sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
+  }
   sample = std::min(sample, B);
   t0 = clk::now();
   double md = 0.0;
@@ -463,6 +560,7 @@ int main(int argc, char **argv) {
   if (argc > 1 && !std::strcmp(argv[1], "bench"))
     return run_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "batch")) return run_batch(argc > 2 ? std::atoi(argv[2]) : 0);
+  if (argc > 1 && !std::strcmp(argv[1], "cont")) return run_cont(argc > 2 ? std::atoi(argv[2]) : 0);
   if (argc > 1 && !std::strcmp(argv[1], "parity")) return run_parity();
   if (argc > 1 && !std::strcmp(argv[1], "oracle")) {          // CPU only: the driver on the oracle backend
     for (int obst = 0; obst < 2; ++obst) {

@@ -55,6 +55,15 @@ def test_batched_gomp_driver_matches_sequential_drivers(exe):
     assert r.returncode == 0 and "BATCH OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+def test_continuous_gomp_driver_matches_sequential_drivers(exe):
+    """SURVEY 8(f) rank 1 as the reference runs it - per trajectory ([REF] src/gomp-solver.h:70-88): the continuous driver
+    (per-QP entry points, one stage per horizon, pipeline depths 1 and 2) takes exactly the decisions of sequential
+    GOMPSolver runs: exit codes, segment / solve / update counters, trajectories (1e-9 vs GPU, 1e-6 vs the oracle twin)."""
+    r = subprocess.run([exe, "cont"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "CONT OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_ur5e_kinematics_and_example_scenario_on_oracle(exe):
     """own UR5e FK / Jacobians (published DH parameters; the reference's kinematics library is
     absent) -- zero-pose position, Jacobians vs central differences, IK round trip -- and the scenario of
