@@ -19,7 +19,10 @@ roofline = iterate_kernel: the MINIMAL bytes of the algorithm the kernel impleme
            all of L) stays as frac_survey_8d.  kernels[] holds the refactorisation kernels.
 cpu_baseline = the oracle (CPU restatement, kind "port") on a bounded sample of the
            same workload on this box's host cores.
-secondary = BASELINE configs 2, 4, 5 measured outside the headline timing (rank 0, N=1).
+secondary = BASELINE configs 2, 4, 5 and the GOMP obstacle scene (continuous driver) measured outside the headline
+           timing (rank 0, N=1).
+value_pcie_inclusive = the same step through the host-pointer boundary (H2D bounds, D2H solutions); roofline carries
+           measured_copy_GBps / measured_triad_GBps of this box next to the nominal peak.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]       (N>1: starts the N ranks itself)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -178,6 +181,24 @@ def main():
         avg_ms, launches = solver.kernel_time()
         peak = solver.refactor_peak()
         f_ms, d_ms, r_launches, r_qps = solver.refactor_time()
+        # the same step through the HOST-pointer boundary (BASELINE.md section 2 / SURVEY 8(d): "incl. H2D bounds and D2H
+        # solutions"): bounds from host memory, solutions back to host memory.  Reported beside `value`, never as it.
+        pcie = None
+        if rank == 0 and mode == args.scaling:
+            ksteps = max(2, min(steps, 5))
+            solver.reset(); solver.update_bounds(pr["l"], pr["u"]); solver.solve(); solver.primal()      # (pinned staging allocated)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(ksteps):
+                solver.reset()
+                solver.update_bounds(pr["l"], pr["u"])
+                solver.solve()
+                xh = solver.primal()
+            tp = time.perf_counter() - tp
+            pcie = {"value": B * ksteps / tp, "unit": "QPs/s", "ms_per_step": 1e3 * tp / ksteps, "steps": ksteps,
+                    "bytes_per_step": 8 * B * (2 * st["m"] + st["n"]),
+                    "same_solutions": bool(np.array_equal(xh, d_x.cpu().numpy()))}
+            solver.kernel_time(); solver.refactor_time()
         iters = d_iters.cpu().numpy().astype(np.int64)
         status = d_status.cpu().numpy()
         tot = torch.tensor([float(B), float(iters.sum()), float(np.all(status == 1))], device=dev, dtype=torch.float64)
@@ -190,7 +211,7 @@ def main():
                     total_qps=int(tot[0]), total_iters=float(tot[1]), all_solved=bool(tot[2] == world),
                     avg_ms=avg_ms, launches=launches, f_ms=f_ms, d_ms=d_ms, r_launches=r_launches, r_qps=r_qps, peak=peak,
                     iters=iters, status=status, d_x=d_x, ls=solver.last_solve_stats(), dev_s=dev_s, ref_s=ref_s, cmp_s=cmp_s,
-                    gathered_ok=gathered_ok)
+                    gathered_ok=gathered_ok, pcie=pcie)
 
     r = run_mode(args.scaling, args.steps, args.warmup)
     other = None
@@ -222,6 +243,11 @@ def main():
                               "compaction": 1e3 * r["cmp_s"] / steps,
                               "refactors_per_step": r["ls"]["refactors"], "launches_per_step": r["ls"]["launches"]},
     }
+    if r.get("pcie"):
+        out["value_pcie_inclusive"] = r["pcie"]["value"]
+        out["pcie_inclusive"] = dict(r["pcie"], note="the same step with bounds taken from host memory (mi_osqp_batch_update_bounds) and solutions "
+                                                      "returned to host memory (mi_osqp_batch_get_primal): the unit BASELINE.md section 2 states; "
+                                                      "`value` keeps inputs and outputs resident in HBM")
     if dist is not None:
         out["gather"] = {"collective": "all_gather_into_tensor (RCCL), static counts", "round_trip_ok": r["gathered_ok"]}
     if other is not None:
@@ -250,6 +276,7 @@ def main():
                     "tail undercuts; streamed_* = the padded streams the kernel reads; traffic = PMC bytes per launch of the "
                     "committed profile (profiles/hbm_traffic.json)",
         }
+        out["roofline"].update(measure_stream_bandwidth(torch, dev))
         rb = refactor_bytes(st)
         kern = []
         pk_qps, pk_f, pk_t = r["peak"]                     # the largest refactorisation of the timed steps (605 QPs at the headline batch)
@@ -305,6 +332,52 @@ def main():
         dist.destroy_process_group()
 
 
+def measure_stream_bandwidth(torch, dev):
+    """What this box's HBM delivers to plain streaming kernels, measured in the same run (report it beside the
+    8 TB/s nominal): a device-to-device copy (read + write) and a triad a = b + s c (two reads + one write) over 1 GiB
+    operands, best of 5, timed with events."""
+    nel = 1 << 27                                   # 1 GiB of doubles per operand
+    a = torch.empty(nel, dtype=torch.float64, device=dev); b = torch.ones_like(a); c = torch.ones_like(a)
+    res = {}
+    for name, fn, nbytes in (("measured_copy_GBps", lambda: a.copy_(b), 2 * 8 * nel),
+                             ("measured_triad_GBps", lambda: torch.add(b, c, alpha=0.5, out=a), 3 * 8 * nel)):
+        best = 1e30
+        for _ in range(6):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        res[name] = nbytes / best / 1e9
+    del a, b, c
+    torch.cuda.empty_cache()
+    return res
+
+
+def obstacle_scene_entry(with_cpu):
+    """The reference's real workload - SQP loops that re-linearise per trajectory ([REF] src/gomp-solver.h:70-88) - through the
+    continuous driver (ContinuousGOMPSolver on the per-QP entry points): 256 trajectories of a 3-link arm that must pass a
+    bar, 100 waypoints.  Runs the C++ bench program built by __graft_entry__.build() as a child process (it initialises its
+    own HIP context); the sequential driver on the oracle (one thread) is timed beside it on a sample."""
+    exe = os.path.join(ROOT, "osqp-solver_amd", "gomp_parity_test")
+    if not os.path.exists(exe):
+        return {"config": "GOMP obstacle scene, continuous driver", "error": "osqp-solver_amd/gomp_parity_test not built"}
+    r = subprocess.run([exe, "contbench", "256", "100", "8" if with_cpu else "0"], capture_output=True, text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CONTBENCH trajectories")]
+    if r.returncode != 0 or not line:
+        return {"config": "GOMP obstacle scene, continuous driver", "error": (r.stdout + r.stderr)[-500:]}
+    tok = line[0].split()
+    kv = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)}
+    e = {"config": "GOMP obstacle scene (3-link arm, one collision ball, a bar to pass above, a floor): 256 trajectories x 100 waypoints, "
+                   "10 horizons, SQP re-linearisation per trajectory; continuous driver (per-QP entry points, one stage per horizon)",
+         "value": kv["trajectories_per_s"], "unit": "trajectories/s", "ms": 1e3 * kv["run_s"], "first_run_ms": 1e3 * kv["first_run_s"],
+         "qp_solves": int(kv["qp_solves"]), "qp_updates": int(kv["qp_updates"]), "advances": int(kv["advances"]),
+         "all_optimal": int(kv["optimal"]) == int(kv["trajectories"])}
+    if with_cpu and kv.get("oracle_sample", 0) > 0:
+        e["cpu_baseline"] = {"value": kv["oracle_trajectories_per_s"], "unit": "trajectories/s", "cores": 1, "kind": "port",
+                             "sample": "the first %d trajectories, sequential GOMPSolver on the oracle, one thread; same exit codes and "
+                                       "solve / update counts, max |dx| %.1e" % (int(kv["oracle_sample"]), kv["max_dx"])}
+    return e
+
+
 def secondary(M, PR, torch, with_cpu):
     """BASELINE configs 2, 4, 5 (outside the headline timing; each a few seconds)."""
     import numpy as np
@@ -342,16 +415,29 @@ def secondary(M, PR, torch, with_cpu):
                                      "sample": "the same QP, same warm start, oracle solve phase on one thread"}
                 res.append(e); s.close()
                 continue
-            rc = O.batch_solve(pr["P"], pr["Px"][:nb], None, pr["A"], pr["Ax"][:nb], pr["l"][:nb], pr["u"][:nb],
-                               threads=min(cores, nb), native=True)
-            e["cpu_baseline"] = {"value": nb / rc["solve_s"], "unit": "QPs/s", "cores": min(cores, nb), "kind": "port",
-                                 "sample": f"{nb} QPs, oracle cold start (the GPU numbers are warm-started like the reference's driver)"}
+            # like for like: every QP gets the warm start the GPU got; setup outside the timed region, the solves on a
+            # pool of `cores` threads (the oracle's C functions run without the interpreter lock)
+            from concurrent.futures import ThreadPoolExecutor
+            objs = []
+            for b in range(nb):
+                Pm, Am = PR.qp_matrices(pr, b)
+                o = O.OracleQPSolver(Pm, None, Am, pr["l"][b], pr["u"][b]); o.set_warm_start(pr["warm"][b])
+                objs.append(o)
+            nthreads = min(cores, nb)
+            with ThreadPoolExecutor(nthreads) as pool:
+                t = time.perf_counter(); sts = list(pool.map(lambda o: o.solve()[0], objs)); t2 = time.perf_counter() - t
+            oit = np.array([o.info().iter for o in objs])
+            e["cpu_baseline"] = {"value": nb / t2, "unit": "QPs/s", "cores": nthreads, "kind": "port", "iters_mean": float(oit.mean()),
+                                 "same_iteration_counts": bool(np.array_equal(oit, its[:nb])),
+                                 "sample": f"the first {nb} QPs with the same warm starts as the GPU, oracle solve phase on {nthreads} threads"}
+            del objs
         res.append(e)
         s.close()
     # ---- config 5: single large sparse QP (structured: 2-D grid, see problems.grid_qp); literal size n = 99 856, m = 298 936
     # (the oracle's exact minimum degree is quadratic in the fill: it is timed beside the GPU at the reduced size only)
     for g in sorted({150, int(os.environ.get("MI_OSQP_BENCH_GRID", "316"))}):
         res.append(_grid_entry(M, PR, torch, O, g))
+    res.append(obstacle_scene_entry(with_cpu))
     return res
 
 

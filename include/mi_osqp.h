@@ -99,6 +99,7 @@ typedef struct {
   int64_t dense_tail_rows, dense_tail_slots;   /* trailing rows served by the inverted Schur complement (0 = none), its stream slots */
   double  setup_seconds_host, setup_seconds_factor, setup_seconds_upload;
   int64_t nnz_L_before_tail;   /* entries of L in the columns before the dense tail (= nnz_L without one): what the two sweeps stream */
+  int64_t solve_groups, solve_group_threads;   /* large single QP: workgroups x threads that share its sweeps (0 = one workgroup); never more than the device keeps resident */
 } mi_osqp_stats;
 
 typedef struct mi_osqp_solver mi_osqp_solver; /* one QP  */

@@ -52,7 +52,7 @@ class Stats(C.Structure):
                  "n_supernodes", "n_blocks", "fwd_levels", "bwd_levels", "fwd_slots", "bwd_slots",
                  "chk_slots", "lds_bytes", "threads_per_block", "dense_tail_rows", "dense_tail_slots")] + \
                [(k, C.c_double) for k in ("setup_seconds_host", "setup_seconds_factor", "setup_seconds_upload")] + \
-               [("nnz_L_before_tail", C.c_int64)]
+               [("nnz_L_before_tail", C.c_int64), ("solve_groups", C.c_int64), ("solve_group_threads", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -71,11 +71,14 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libmi_osqp.so")
-        try:
-            path = _build.build()
-        except Exception as e:  # hipcc missing on this machine: use the shipped .so or fail
-            if not os.path.exists(path):
-                raise ImportError(f"libmi_osqp.so missing and could not be built: {e}") from e
+        if os.environ.get("MI_OSQP_LIBRARY"):      # (tests: the diagnostic twin of the library, build.build_debug)
+            path = os.environ["MI_OSQP_LIBRARY"]
+        else:
+            try:
+                path = _build.build()
+            except Exception as e:  # hipcc missing on this machine: use the shipped .so or fail
+                if not os.path.exists(path):
+                    raise ImportError(f"libmi_osqp.so missing and could not be built: {e}") from e
         L = C.CDLL(path)
         ip, dp, vp = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p
         L.mi_osqp_default_settings.argtypes = [C.POINTER(Settings)]

@@ -115,6 +115,8 @@ hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds_asm, size_t lds,
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
 
+int max_coresident_groups(int threads, size_t lds, int n_cus);
+int max_coresident_factor_groups(int threads, int n_cus);
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -38,6 +39,12 @@ namespace miosqp {
 // (MI_OSQP_CXXFLAGS=-DMI_OSQP_DEBUG_BUILD, scripts/profile_factor.py); the product binary has no such switch.
 #ifdef MI_OSQP_DEBUG_BUILD
 #define MI_DBG_SKIP(a) ((a).debug_skip)
+// fault injection (diagnostic build): MI_OSQP_DEBUG_DROP_GROUP names the launch that loses a workgroup of its grid
+// (iterate / check / kkt / factor; "1" = iterate)
+static bool debug_drop_group(const char *which) {
+  const char *e = getenv("MI_OSQP_DEBUG_DROP_GROUP");
+  return e && (!strcmp(e, which) || (!strcmp(e, "1") && !strcmp(which, "iterate")));
+}
 #else
 #define MI_DBG_SKIP(a) 0
 #endif
@@ -1799,6 +1806,9 @@ template <int BT>
 static hipError_t launch_factor_t(const FactorArgs &a, int tiles, int threads, hipStream_t st) {
   const size_t lds = factor_lds_bytes(BT, threads);
   if (a.mw_groups > 1) { if (BT != 1 || !a.mw_bar) return hipErrorInvalidValue; tiles *= a.mw_groups; }
+#ifdef MI_OSQP_DEBUG_BUILD
+  if (a.mw_groups > 1 && debug_drop_group("factor")) tiles--;       // fault injection: a workgroup of the last group never shows up
+#endif
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<BT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -2652,16 +2662,45 @@ hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
     return go(&KERNEL<4, 512, false>);                                                             \
   } while (0)
 
+// Workgroups of `threads` threads and `lds` bytes of dynamic LDS the device keeps resident at once for EVERY kernel that
+// spins on the grid of a dataflow handle (iterate / check / kkt_solve, wide index words, one QP): the grid barrier and the
+// "not yet" waits of those kernels only make progress when the whole grid is resident.  0: the query failed.
+int max_coresident_groups(int threads, size_t lds, int n_cus) {
+  int best = 1 << 30;
+  auto q = [&](auto kern) {
+    int nb = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { best = 0; return; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), threads, lds) != hipSuccess) { best = 0; return; }
+    best = std::min(best, nb * n_cus);
+  };
+  q(&iterate_kernel<1, 512, true, true>);
+  q(&check_kernel<1, 512, true, true>);
+  q(&kkt_solve_kernel<1, 512, true, true>);
+  (void)hipGetLastError();
+  return best == (1 << 30) ? 0 : best;
+}
+// the same for the grouped refactorisation (factor_kernel<1> shared by G workgroups per QP)
+int max_coresident_factor_groups(int threads, int n_cus) {
+  int nb = 0;
+  const size_t lds = factor_lds_bytes(1, threads);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&factor_kernel<1>), threads, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return nb * n_cus;
+}
+
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
   if (getenv("MI_OSQP_DEBUG_HIP")) fprintf(stderr, "[mi_osqp] launch_iterate: df %d wide %d xs_global %p BT %d tiles %d threads %d lds %zu groups %d bar %p\n", a.df, a.wide, (void *)a.xs_global, BT, tiles, threads, lds, a.mw_groups, (void *)a.mw_bar);
   if (a.df) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || a.mw_groups < 1) return hipErrorInvalidValue; tiles = a.mw_groups; }
 #ifdef MI_OSQP_DEBUG_BUILD
-  if (a.df && getenv("MI_OSQP_DEBUG_DROP_GROUP") && tiles > 1) tiles--;       // fault injection: a workgroup of the grid never shows up
+  if (a.df && debug_drop_group("iterate") && tiles > 1) tiles--;       // fault injection: a workgroup of the grid never shows up
 #endif
   MI_DISPATCH(iterate_kernel, a);
 }
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {
   if (a.df && a.mw_groups > 1) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || !a.mw_scratch) return hipErrorInvalidValue; tiles = a.mw_groups; }
+#ifdef MI_OSQP_DEBUG_BUILD
+  if (a.df && a.mw_groups > 1 && debug_drop_group("check") && tiles > 1) tiles--;
+#endif
   MI_DISPATCH(check_kernel, a);
 }
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
@@ -2671,6 +2710,9 @@ hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size
 hipError_t launch_kkt_solve(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                             const double *rhs, double *sol) {
   if (a.df) { if (tiles != 1 || BT != 1 || !a.xs_global || !a.wide || !a.mw_bar || a.mw_groups < 1) return hipErrorInvalidValue; tiles = a.mw_groups; }
+#ifdef MI_OSQP_DEBUG_BUILD
+  if (a.df && debug_drop_group("kkt") && tiles > 1) tiles--;
+#endif
   MI_DISPATCH(kkt_solve_kernel, a, rhs, sol);
 }
 hipError_t launch_kkt_trace(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,

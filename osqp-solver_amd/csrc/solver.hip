@@ -659,6 +659,15 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
 }
 
 static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
+// Kernels that spin on their own grid (the dataflow sweeps and grid barriers of a large single QP, the grouped
+// refactorisation) need every workgroup of the grid resident.  The grids are clamped to what the device keeps resident
+// (max_coresident_groups); two such grids on one device could still starve each other, so their launches - from any
+// handle and host thread of the process - take turns per device, from the launch to its completion.
+static std::mutex &spin_mutex(int device) {
+  static std::mutex mu[64];
+  return mu[(unsigned)device % 64u];
+}
+static int restore_snapshot(mi_osqp_batch *h);
 static int cont_leave(mi_osqp_batch *h);      // (a blocking call ends the continuous mode of a handle: section "continuous")
 
 // multi-workgroup mode: a grid barrier that gave up waiting (a workgroup of the grid was not resident) leaves its error
@@ -732,6 +741,17 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     h->mw_groups = eg ? std::max(0, std::min(256, atoi(eg))) : 128;
     h->mw_threads = ew ? std::max(64, std::min(512, atoi(ew) / 64 * 64)) : 128;
     if (h->mw_groups * (h->mw_threads / 64) > 2048) h->mw_groups = 2048 / (h->mw_threads / 64);
+    // never more workgroups than the device keeps resident at once (their waits are for each other): the schedules are
+    // built for the clamped grid; a device that cannot hold two of them gets the barrier form in one workgroup
+    int dev = (int)device, cus = 0;
+    if ((dev >= 0 || hipGetDevice(&dev) == hipSuccess) && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+      DevGuard guard(dev);
+      { const char *ec = getenv("MI_OSQP_ASSUME_CUS"); if (ec && atoi(ec) > 0) cus = std::min(cus, atoi(ec)); }      // (tests: the clamp on a device with fewer CUs)
+      const int cap = max_coresident_groups(h->mw_threads, lds_bytes(0, 1, h->threads), cus);
+      if (cap > 0 && h->mw_groups > cap) h->mw_groups = cap;
+      if (h->mw_groups == 1) h->mw_groups = 0;
+    }
+    (void)hipGetLastError();
   }
   int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), h->anp);
   const double t_analysis = now_s() - ta0;
@@ -942,6 +962,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   s.dense_tail_rows = an.dt.k; s.dense_tail_slots = (int64_t)an.dt.n_steps * 64;
   s.setup_seconds_host = t1 - t0; s.setup_seconds_factor = t_factor; s.setup_seconds_upload = t_upload;
   s.nnz_L_before_tail = an.dt.k ? an.Lp[an.dt.s] : an.nnzL();
+  s.solve_groups = h->mw_groups; s.solve_group_threads = h->mw_groups > 0 ? h->mw_threads : 0;
   if (getenv("MI_OSQP_DEBUG_TIMING"))
     fprintf(stderr, "[mi_osqp] setup B=%d N=%d: analysis+alloc %.1f ms (analysis %.1f), numeric %.1f ms, upload %.1f ms, rest %.1f ms\n", (int)B, an.N,
             1e3 * (t1 - t0), 1e3 * t_analysis, 1e3 * t_factor, 1e3 * t_upload, 1e3 * (now_s() - t1 - t_factor - t_upload));
@@ -991,8 +1012,12 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
     const int cap = h->B == 1 ? std::max(4, std::min(64, (*h->anp).N / 600)) : 8;
     int G = eg ? std::max(1, std::min(256, atoi(eg))) : cap;
     G = std::min(G, std::max(1, h->n_cus / wtiles));
+    static const int resident = max_coresident_factor_groups(factor_threads(), 1);      // workgroups of factor_kernel per CU
+    if (resident > 0) G = std::min(G, std::max(1, resident * h->n_cus / wtiles));
     fa.mw_groups = G > 1 ? G : 0;
   }
+  std::unique_lock<std::mutex> spin_lock(spin_mutex(h->device), std::defer_lock);
+  if (fa.mw_groups > 1) spin_lock.lock();
   HIPCHK(hipEventRecord(h->evf0, h->stream));
   if (fa.mw_groups > 1) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t) * (size_t)wtiles, h->stream));
   HIPCHK(launch_factor(fa, kbt, wtiles, factor_threads(), h->stream));
@@ -1026,11 +1051,17 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   HIPCHK(hipEventRecord(h->evf2, h->stream));
   HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)h->ntiles * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (spin_lock.owns_lock()) spin_lock.unlock();
   if (fa.mw_groups > 1) {
     std::vector<uint32_t> w(4 * (size_t)wtiles, 0u);
     HIPCHK(hipMemcpy(w.data(), h->mw_bar.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int t = 0; t < wtiles; t++)
-      if (w[4 * (size_t)t + 2]) { g_last_error = "refactorisation on several workgroups: a barrier of the group timed out"; return MI_OSQP_ERR_DEVICE; }
+      if (w[4 * (size_t)t + 2]) {
+        // a workgroup of a group never showed up: the streams of the listed QPs hold a half-written factor.  Every listed
+        // QP is without a valid factor (kNonConvex on every solve) until a later refactorisation of it succeeds.
+        for (int sl : work) if (sl >= 0 && sl < h->B) h->failed[(size_t)sl] = 1;
+        g_last_error = "refactorisation on several workgroups: a barrier of the group timed out"; return MI_OSQP_ERR_DEVICE;
+      }
   }
   {
     float f = 0.f, d = 0.f;
@@ -1122,14 +1153,25 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
       if (S.adaptive_rho && S.adaptive_rho_interval > 0)
         seg_end = std::min<int64_t>(seg_end, (iter / S.adaptive_rho_interval + 1) * S.adaptive_rho_interval);
       a.iter_begin = iter; a.iter_end = seg_end; a.info_at_end = 1;
-      HIPCHK(hipEventRecord(h->ev0, h->stream));
-      if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
-      HIPCHK(launch_iterate(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
-      HIPCHK(hipEventRecord(h->ev1, h->stream));
-      HIPCHK(launch_check(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
-      HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIPCHK(hipStreamSynchronize(h->stream));
-      if ((rc = mw_barrier_ok(h))) return rc;
+      {
+        std::unique_lock<std::mutex> spin_lock(spin_mutex(h->device), std::defer_lock);
+        if (h->mw_groups > 0) spin_lock.lock();
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
+        HIPCHK(launch_iterate(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        HIPCHK(launch_check(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+      }
+      if ((rc = mw_barrier_ok(h))) {
+        // waves that gave up waiting have consumed "not yet" patterns: x, y, z (and with them every later warm start) are
+        // garbage.  Back to the last good state: the factor / rho of the snapshot, cold iterates.
+        const std::string why = g_last_error;
+        (void)restore_snapshot(h);
+        g_last_error = why + " (the handle is back in the state of its last setup / update, cold-started)";
+        return rc;
+      }
       float ms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
       h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; h->kernel_launches++; h->last_launches++;
@@ -1397,6 +1439,11 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
   if (!h) return MI_OSQP_ERR_NULL;
   DevGuard guard(h->device);
   { const int rc_ = cont_leave(h); if (rc_) return rc_; }
+  return restore_snapshot(h);
+}
+}  // extern "C"
+// the state right after setup / the last update that refactored: factor, rho vectors and scalars of the snapshot, cold iterates
+static int restore_snapshot(mi_osqp_batch *h) {
   h->clear_rho_updates = true;
   auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
     if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -1412,6 +1459,7 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
   h->host_rho_stale = true;
   return MI_OSQP_OK;
 }
+extern "C" {
 
 int mi_osqp_batch_warm_start_x(mi_osqp_batch *h, const double *x) {
   CallTimer timer_("batch_warm_start_x");
@@ -1702,9 +1750,13 @@ int mi_osqp_batch_kkt_solve(mi_osqp_batch *h, const double *d_rhs, double *d_sol
   DevGuard guard(h->device);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   KernelArgs a = make_args(h);
-  if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), s));
-  HIPCHK(launch_kkt_solve(a, h->BT, h->ntiles, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, s, d_rhs, d_sol));
-  HIPCHK(hipStreamSynchronize(s));
+  {
+    std::unique_lock<std::mutex> spin_lock(spin_mutex(h->device), std::defer_lock);
+    if (h->mw_groups > 0) spin_lock.lock();
+    if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), s));
+    HIPCHK(launch_kkt_solve(a, h->BT, h->ntiles, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, s, d_rhs, d_sol));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   return mw_barrier_ok(h);
 }
 

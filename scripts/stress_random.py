@@ -12,10 +12,11 @@ bad = 0
 cases = 0
 for trial in range(int(os.environ.get("TRIALS", "24"))):
     NMAX = int(os.environ.get("NMAX", "220"))
-    # (nnz >= 2 per row of G: with one entry per row and more rows than variables many rows coincide, the duals are not unique,
-    #  the dual residual sits at round-off at the first rho update and rho_new = rho sqrt(r_prim / r_dual) is decided by noise -
-    #  two correct implementations then part ways: DESIGN.md section 6)
-    n = int(rng.integers(3, NMAX)); mg = int(rng.integers(1, NMAX + 40)); nnz = int(rng.integers(2, min(n, 12) + 1))
+    # (nnz = 1 per row of G is a class of its own: with more rows than variables many rows coincide, the duals are not unique,
+    #  the dual residual can sit at round-off at a rho update and rho_new = rho sqrt(r_prim / r_dual) is then decided by
+    #  noise - two correct implementations part ways in their iteration counts.  The class stays in
+    #  the sweep with the check that still means something for it: same exit code, both optimal, x within 1e-3.)
+    n = int(rng.integers(3, NMAX)); mg = int(rng.integers(1, NMAX + 40)); nnz = int(rng.integers(1, min(n, 12) + 1))
     B = int(rng.integers(1, 7))
     tile = int(rng.choice([1, 2, 4])); thr = int(rng.choice([0, 128, 256, 512, 1024]))      # 0: the default thread count
     if thr == 1024 and tile == 4: thr = 512
@@ -52,10 +53,14 @@ for trial in range(int(os.environ.get("TRIALS", "24"))):
         tol = 1e-3 if st == -2 else 1e-6          # max_iter: thousands of non-converging iterations amplify round-off
         okk = info[b].exit_code == ST2EXIT[st] and info[b].iter == io.iter and (np.all(np.isnan(xo)) or np.max(np.abs(x[b] - xo)) <= tol)
         cases += 1
+        if not okk and nnz == 1 and info[b].exit_code == ST2EXIT[st] == 0 and np.max(np.abs(x[b] - xo)) <= 1e-3:
+            noise = globals().get("noise", 0) + 1
+            print("trial", trial, "qp", b, "one entry per row: iteration counts", info[b].iter, "/", io.iter, "(rho decided by round-off), both optimal, dx", float(np.max(np.abs(x[b] - xo))))
+            continue
         if not okk:
             bad += 1
             print("trial", trial, "MISMATCH qp", b, dict(n=n, mg=mg, nnz=nnz, B=B, tile=tile, thr=thr, eps=eps, gx=os.environ.get("MI_OSQP_GLOBAL_XS")),
                   "gpu", info[b].exit_code, info[b].iter, "oracle", ST2EXIT[st], io.iter, "dx", float(np.nanmax(np.abs(x[b] - xo))))
     s.close()
-print(f"{cases} QPs compared, {bad} problems, {globals().get('dt_cases', 0)} batches with a dense tail")
+print(f"{cases} QPs compared, {bad} problems, {globals().get('dt_cases', 0)} batches with a dense tail, {globals().get('noise', 0)} one-entry-per-row QPs with noise-decided rho (same exit code, x within 1e-3)")
 sys.exit(1 if bad else 0)

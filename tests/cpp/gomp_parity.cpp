@@ -513,6 +513,60 @@ static int run_obstacle_bench(int B, int W, int sample) {
   return fails ? 1 : 0;
 }
 
+// The continuous driver alone on the obstacle scene of obstbench, with the sequential driver on the oracle (one thread) beside
+// it for a sample of the trajectories: what bench.py reports as its obstacle-scene entry.   gomp_parity contbench [trajectories] [waypoints] [sample]
+static int run_cont_bench(int B, int W, int sample) {
+  const double pi = 3.14159265358979323846;
+  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}};
+  std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
+  auto pos = constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi));
+  auto vel = constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi));
+  auto acc = constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180));
+  auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF});
+  std::vector<Ctrl<3>> starts, ends;
+  std::mt19937_64 rng(4242);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  for (int b = 0; b < B; ++b) {
+    starts.push_back({-0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+    ends.push_back({0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+  }
+  using clk = std::chrono::steady_clock;
+  ContinuousGOMPSolver<3> cg((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls);
+  if (getenv("GOMP_PIPELINE_DEPTH")) cg.pipeline_depth = std::atoi(getenv("GOMP_PIPELINE_DEPTH"));
+  auto t0 = clk::now();
+  auto c1 = cg.run(starts, ends);
+  const double tc1 = std::chrono::duration<double>(clk::now() - t0).count();
+  double best = 1e30;
+  std::vector<std::pair<ExitCode, QPVector>> c2;
+  for (int rep = 0; rep < 3; ++rep) {
+    t0 = clk::now();
+    c2 = cg.run(starts, ends);
+    best = std::fmin(best, std::chrono::duration<double>(clk::now() - t0).count());
+  }
+  int cok = 0, csolves = 0, cupdates = 0;
+  for (int b = 0; b < B; ++b) {
+    cok += c2[b].first == ExitCode::kOptimal; csolves += cg.qp_solves[b]; cupdates += cg.qp_updates[b];
+    CHECK(c2[b].first == c1[b].first); CHECK(c2[b].second == c1[b].second);
+  }
+  sample = std::min(sample, B);
+  t0 = clk::now();
+  double md = 0.0;
+  for (int b = 0; b < sample; ++b) {
+    GOMPSolver<3, OracleQPSolver> o((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+    auto [code, x] = o.run(starts[b], ends[b]);
+    CHECK(code == c2[b].first); CHECK(o.qp_solves == cg.qp_solves[b] && o.qp_updates == cg.qp_updates[b]);
+    if (x.size() == c2[b].second.size()) for (size_t k = 0; k < x.size(); ++k) md = std::fmax(md, std::fabs(x[k] - c2[b].second[k]));
+  }
+  const double to = std::chrono::duration<double>(clk::now() - t0).count();
+  CHECK(md <= 1e-6);
+  // (one machine-readable line for bench.py)
+  std::printf("CONTBENCH trajectories %d waypoints %d first_run_s %.4f run_s %.4f trajectories_per_s %.2f qp_solves %d qp_updates %d advances %ld optimal %d "
+              "oracle_sample %d oracle_s %.4f oracle_trajectories_per_s %.2f max_dx %.3e\n",
+              B, W, tc1, best, B / best, csolves, cupdates, cg.advances.load(), cok, sample, to, sample / to, md);
+  std::printf(fails ? "CONTBENCH FAILED (%d)\n" : "CONTBENCH OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 // The reference's example program ([REF] examples/solver-example.cpp:12-16,44-70: UR5e, joint 1 by pi, two balls, y >= -0.4)
 // as its sequential driver runs it - one trajectory, one QP at a time - on the GPU QPSolver and on the oracle backend
 // (one CPU thread): wall time of run() and the difference of the trajectories.   gomp_parity example [waypoints]
@@ -561,6 +615,8 @@ int main(int argc, char **argv) {
     return run_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "batch")) return run_batch(argc > 2 ? std::atoi(argv[2]) : 0);
   if (argc > 1 && !std::strcmp(argv[1], "cont")) return run_cont(argc > 2 ? std::atoi(argv[2]) : 0);
+  if (argc > 1 && !std::strcmp(argv[1], "contbench"))
+    return run_cont_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "parity")) return run_parity();
   if (argc > 1 && !std::strcmp(argv[1], "oracle")) {          // CPU only: the driver on the oracle backend
     for (int obst = 0; obst < 2; ++obst) {

@@ -134,3 +134,65 @@ def test_max_iter_on_a_rho_iteration_that_is_not_a_check_iteration(check):
             assert np.max(np.abs(x[b] - xo)) <= tol
             seen_update = seen_update or io.rho_updates > 0
     assert seen_update                                       # the corner is really exercised
+
+
+# ---------------------------------------------------------------- co-residency of the grid-spinning kernels
+def _grid_parity(pr, s):
+    from oracle import oracle as O
+    info = s.solve()
+    P, A = PR.qp_matrices(pr, 0)
+    o = O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0])
+    st, xo = o.solve()
+    assert info[0].status_val == st and info[0].iter == o.info().iter, (info[0].status_val, st, info[0].iter, o.info().iter)
+    assert np.max(np.abs(s.primal()[0] - xo)) <= 1e-6
+
+
+def test_oversized_group_grid_is_clamped_to_what_stays_resident(monkeypatch):
+    """The dataflow sweeps of a large single QP wait for each other's workgroups: the grid is clamped at setup to what the
+    device keeps resident (occupancy of the spinning kernels x CUs).  On 256 CUs every legal grid fits, so the test lets
+    the clamp assume a 4-CU device: 256 requested workgroups of 512 threads must come down, and the solve must be right."""
+    monkeypatch.setenv("MI_OSQP_GROUPS", "256")
+    monkeypatch.setenv("MI_OSQP_GROUP_THREADS", "512")
+    monkeypatch.setenv("MI_OSQP_ASSUME_CUS", "4")
+    pr = PR.grid_qp(90)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    st = s.stats()
+    assert 2 <= st["solve_groups"] <= 4 * 4 and st["solve_group_threads"] == 512, st      # (at most 4 workgroups of 512 threads per CU)
+    _grid_parity(pr, s)
+    monkeypatch.delenv("MI_OSQP_ASSUME_CUS")
+    s2 = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    assert s2.stats()["solve_groups"] == 256
+
+
+def test_two_dataflow_handles_on_one_device_take_turns():
+    """Two large single QPs on ONE device - as two shards of the device-list API and from two host threads: their
+    grid-spinning launches are serialised per device, so neither starves the other; both match the oracle."""
+    import threading
+    pr = PR.grid_qp(90)
+    pr2 = {k: (np.concatenate([v, v]) if isinstance(v, np.ndarray) and v.ndim == 2 else v) for k, v in pr.items()}
+    pr2["l"] = pr2["l"].copy(); pr2["l"][1] *= 0.9
+    ms = M.MultiBatchSolver(pr2["P"], pr2["Px"], pr2["q"], pr2["A"], pr2["Ax"], pr2["l"], pr2["u"], devices=(0, 0))
+    assert [(b, e) for _, b, e in ms.shards()] == [(0, 1), (1, 2)]
+    info = ms.solve()
+    x = ms.primal()
+    from oracle import oracle as O
+    for b in range(2):
+        P, A = PR.qp_matrices(pr2, b)
+        o = O.OracleQPSolver(P, pr2["q"][b], A, pr2["l"][b], pr2["u"][b])
+        st, xo = o.solve()
+        assert info[b].status_val == st and info[b].iter == o.info().iter and np.max(np.abs(x[b] - xo)) <= 1e-6
+    solvers = [M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"]) for _ in range(2)]
+    assert all(s.stats()["solve_groups"] > 1 for s in solvers)
+    errs = []
+
+    def work(s):
+        try:
+            for _ in range(3):
+                s.reset()
+                _grid_parity(pr, s)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(s,)) for s in solvers]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    assert np.array_equal(solvers[0].primal(), solvers[1].primal())
