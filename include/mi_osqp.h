@@ -240,7 +240,7 @@ int64_t mi_osqp_batch_running(mi_osqp_batch *h);      /* QPs whose solve has bee
  * The batch is the shard axis across the GPUs of a node (the runs of a planner are independent,
  * [REF] src/gomp-solver.h:38-55): the B QPs are cut into n_devices contiguous blocks (the first B % n_devices one QP
  * longer), block k lives on HIP device devices[k] (devices == NULL: 0 .. n_devices-1; a device may be listed more than
- * once - two shards then share it), every call fans out over one host thread + stream per shard and joins.  There is
+ * once - two shards then share it), every call fans out over one long-lived worker thread + stream per shard and joins.  There is
  * no data-path collective; results come back QP-major in the order of the whole batch.  Arguments as for
  * mi_osqp_batch_*; the return value is the first shard error (0 = ok). */
 typedef struct mi_osqp_multi mi_osqp_multi;
@@ -256,6 +256,11 @@ int mi_osqp_multi_batch_update_A_bounds(mi_osqp_multi *h, const int64_t *A_colpt
                                         const double *l, const double *u);
 int mi_osqp_multi_batch_warm_start_x(mi_osqp_multi *h, const double *x);
 int mi_osqp_multi_batch_solve(mi_osqp_multi *h);
+/* The same without waiting (every shard has one long-lived worker thread; all calls of this section run on them): solve_async
+ * returns once the shards have their job, wait() joins them and returns the first shard error.  Any other multi-batch call
+ * joins a pending solve first. */
+int mi_osqp_multi_batch_solve_async(mi_osqp_multi *h);
+int mi_osqp_multi_batch_wait(mi_osqp_multi *h);
 int mi_osqp_multi_batch_get_primal(mi_osqp_multi *h, double *x_out /*[B][n]*/);
 int mi_osqp_multi_batch_get_dual(mi_osqp_multi *h, double *y_out /*[B][m]*/);
 int mi_osqp_multi_batch_get_info(mi_osqp_multi *h, mi_osqp_info *info /*[B]*/);

@@ -23,6 +23,7 @@
 #define MI_OSQP_OSQPPP_SHIM_H_
 
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <utility>
 #include <vector>
@@ -158,11 +159,18 @@ class OsqpSolver {
   // osqp_solve + the copy-out of the solution; never throws ([REF] osqp-wrapper.h:51-54)
   OsqpExitCode Solve() {
     if (!h_) return OsqpExitCode::kUnknown;
-    if (mi_osqp_solve(h_, &info_) != MI_OSQP_OK) return OsqpExitCode::kUnknown;
+    last_error_ = mi_osqp_solve(h_, &info_);
+    if (last_error_ != MI_OSQP_OK) {
+      // osqp-cpp turns a failing osqp_solve into kUnknown, which the reference's driver reads as "not converged, go on"
+      // ([REF] src/gomp-solver.h:44-51): a device fault must not pass as that silently
+      std::fprintf(stderr, "OsqpSolver::Solve: %s (%s)\n", mi_osqp_error_name(last_error_), mi_osqp_last_error());
+      return last_error_ == MI_OSQP_ERR_NONCONVEX ? OsqpExitCode::kNonConvex : OsqpExitCode::kUnknown;
+    }
     mi_osqp_get_primal(h_, x_.data());
     if (m_) mi_osqp_get_dual(h_, y_.data());
     return static_cast<OsqpExitCode>(info_.exit_code);
   }
+  int last_error() const { return last_error_; }        // mi_osqp_error of the last Solve() (not part of osqp-cpp)
   c_int iterations() const { return info_.iter; }
   double objective_value() const { return info_.obj_val; }
   Eigen::Map<const Eigen::VectorXd> primal_solution() const { return Eigen::Map<const Eigen::VectorXd>(x_.data(), n_); }
@@ -211,6 +219,7 @@ class OsqpSolver {
   c_int n_ = 0, m_ = 0;
   std::vector<double> x_, y_;
   mi_osqp_info info_{};
+  int last_error_ = 0;
 };
 
 }  // namespace osqp

@@ -134,6 +134,8 @@ def lib():
         L.mi_osqp_multi_batch_update_A_bounds.argtypes = [vp, ip, ip, dp, dp, dp]
         L.mi_osqp_multi_batch_warm_start_x.argtypes = [vp, dp]
         L.mi_osqp_multi_batch_solve.argtypes = [vp]
+        L.mi_osqp_multi_batch_solve_async.argtypes = [vp]
+        L.mi_osqp_multi_batch_wait.argtypes = [vp]
         L.mi_osqp_multi_batch_get_primal.argtypes = [vp, dp]
         L.mi_osqp_multi_batch_get_dual.argtypes = [vp, dp]
         L.mi_osqp_multi_batch_get_info.argtypes = [vp, C.POINTER(Info)]
@@ -448,6 +450,13 @@ class MultiBatchSolver:
 
     def solve(self):
         _chk(lib().mi_osqp_multi_batch_solve(self._h), "mi_osqp_multi_batch_solve")
+        return self.info()
+
+    def solve_async(self):
+        _chk(lib().mi_osqp_multi_batch_solve_async(self._h), "mi_osqp_multi_batch_solve_async")
+
+    def wait(self):
+        _chk(lib().mi_osqp_multi_batch_wait(self._h), "mi_osqp_multi_batch_wait")
         return self.info()
 
     def info(self):

@@ -12,6 +12,8 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -2215,29 +2217,86 @@ int mi_osqp_get_stats(mi_osqp_solver *h, mi_osqp_stats *st) { return h ? mi_osqp
 
 }  // extern "C"
 
+// One long-lived worker thread per shard (a planner calls update / warm start / solve / get_* several times per SQP step:
+// creating and joining a thread per shard and call cost ~0.1 ms of host time each).  A job is posted to every worker; the
+// caller waits for all of them - or, for solve_async, comes back later (wait).
+struct ShardWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, busy = false, quit = false;
+  int rc = 0;
+  std::string err;
+  void start() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        std::function<int()> f = std::move(job);
+        has_job = false;
+        lk.unlock();
+        const int r = f();
+        const std::string e = r ? g_last_error : std::string();
+        lk.lock();
+        rc = r; err = e; busy = false;
+        cv.notify_all();
+      }
+    });
+  }
+  void post(std::function<int()> f) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return !busy; });
+    job = std::move(f); has_job = true; busy = true; rc = 0; err.clear();
+    cv.notify_all();
+  }
+  int wait(std::string &e) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return !busy; });
+    e = err;
+    return rc;
+  }
+  ~ShardWorker() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+};
+
 struct mi_osqp_multi {
   int64_t B = 0, n = 0, m = 0;
   std::vector<int64_t> dev, begin;                 // begin has one entry more than there are shards
   std::vector<mi_osqp_batch *> shard;
-  ~mi_osqp_multi() { for (mi_osqp_batch *b : shard) delete b; }
+  std::vector<std::unique_ptr<ShardWorker>> worker;
+  bool async_pending = false;                      // a solve_async whose wait() has not been called
+  ~mi_osqp_multi() { worker.clear(); for (mi_osqp_batch *b : shard) delete b; }      // (the workers finish their jobs first)
   size_t count() const { return shard.size(); }
 };
 
-// run fn(shard index) on one host thread per shard; first error wins, its text becomes this thread's last error
+// wait for the jobs posted to the workers; first error wins, its text becomes this thread's last error
+static int multi_join(mi_osqp_multi *h) {
+  int rc = MI_OSQP_OK;
+  for (size_t k = 0; k < h->worker.size(); k++) {
+    std::string e;
+    const int r = h->worker[k]->wait(e);
+    if (r && !rc) { rc = r; g_last_error = "shard " + std::to_string(k) + ": " + e; }
+  }
+  h->async_pending = false;
+  return rc;
+}
+// run fn(shard index) on the shard's worker thread and wait for all of them
 template <class F>
 static int multi_fan_out(mi_osqp_multi *h, F &&fn) {
   const size_t ns = h->count();
-  std::vector<int> rcs(ns, 0);
-  std::vector<std::string> errs(ns);
-  auto body = [&](size_t k) { rcs[k] = fn(k); if (rcs[k]) errs[k] = g_last_error; };
-  if (ns == 1) body(0);
-  else {
-    std::vector<std::thread> th;
-    for (size_t k = 0; k < ns; k++) th.emplace_back(body, k);
-    for (auto &t : th) t.join();
+  if (h->async_pending) { const int rc0 = multi_join(h); if (rc0) return rc0; }
+  if (ns == 1) { const int rc = fn(0); if (rc) g_last_error = "shard 0: " + g_last_error; return rc; }
+  if (h->worker.size() != ns) {
+    h->worker.clear();
+    for (size_t k = 0; k < ns; k++) { h->worker.emplace_back(new ShardWorker()); h->worker.back()->start(); }
   }
-  for (size_t k = 0; k < ns; k++) if (rcs[k]) { g_last_error = "shard " + std::to_string(k) + ": " + errs[k]; return rcs[k]; }
-  return MI_OSQP_OK;
+  for (size_t k = 0; k < ns; k++) h->worker[k]->post([&fn, k]() -> int { return fn(k); });
+  return multi_join(h);
 }
 
 extern "C" {
@@ -2305,6 +2364,24 @@ int mi_osqp_multi_batch_warm_start_x(mi_osqp_multi *h, const double *x) {
 int mi_osqp_multi_batch_solve(mi_osqp_multi *h) {
   if (!h) return MI_OSQP_ERR_NULL;
   return multi_fan_out(h, [&](size_t k) { return mi_osqp_batch_solve(h->shard[k]); });
+}
+// solve on every shard without waiting: the call returns once the jobs are with the shard workers; wait() joins them and
+// reports the first error.  Any other multi-batch call joins a pending solve first.
+int mi_osqp_multi_batch_solve_async(mi_osqp_multi *h) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  if (h->async_pending) { const int rc0 = multi_join(h); if (rc0) return rc0; }
+  const size_t ns = h->count();
+  if (h->worker.size() != ns) {
+    h->worker.clear();
+    for (size_t k = 0; k < ns; k++) { h->worker.emplace_back(new ShardWorker()); h->worker.back()->start(); }
+  }
+  for (size_t k = 0; k < ns; k++) { mi_osqp_batch *b = h->shard[k]; h->worker[k]->post([b]() -> int { return mi_osqp_batch_solve(b); }); }
+  h->async_pending = true;
+  return MI_OSQP_OK;
+}
+int mi_osqp_multi_batch_wait(mi_osqp_multi *h) {
+  if (!h) return MI_OSQP_ERR_NULL;
+  return h->async_pending ? multi_join(h) : (int)MI_OSQP_OK;
 }
 int mi_osqp_multi_batch_get_primal(mi_osqp_multi *h, double *x) {
   if (!h || !x) return MI_OSQP_ERR_NULL;

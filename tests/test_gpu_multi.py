@@ -74,6 +74,14 @@ def test_multi_device_abi_two_shards_match_single_handle_and_oracle():
     multi.update_A_bounds(Ax2, pr["l"] * 0.7, pr["u"] * 0.7); one.update_A_bounds(Ax2, pr["l"] * 0.7, pr["u"] * 0.7)
     k2 = multi.solve(); k1 = one.solve()
     assert [(i.status_val, i.iter) for i in k1] == [(i.status_val, i.iter) for i in k2] and np.array_equal(one.primal(), multi.primal())
+    # solve_async / wait on the shards' long-lived workers: the same solve, the caller free in between; a getter joins too
+    multi.update_bounds(pr["l"] * 0.6, pr["u"] * 0.6); one.update_bounds(pr["l"] * 0.6, pr["u"] * 0.6)
+    multi.solve_async()
+    m1 = one.solve()
+    m2 = multi.wait()
+    assert [(i.status_val, i.iter) for i in m1] == [(i.status_val, i.iter) for i in m2] and np.array_equal(one.primal(), multi.primal())
+    multi.solve_async(); one.solve()
+    assert np.array_equal(one.primal(), multi.primal())     # (get_primal joins the pending solve first)
 
 
 def test_one_nonconvex_qp_is_isolated_from_the_batch():
