@@ -184,12 +184,15 @@ void nd_rec(NDCtx &c, std::vector<int> nodes) {
 }
 }  // namespace
 
-static void nested_dissection(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, std::vector<int> &perm) {
+// leaf: subgraphs of at most that many nodes are ordered by minimum degree.  Small leaves = a deeper dissection = fewer
+// dependent chunk levels on chain-like graphs (a GOMP KKT of 60 waypoints: 72 phases per iteration with leaves of 48 nodes, 43
+// with leaves of 8, about the same fill); analyze() tries several sizes and keeps the cheapest by its cost model.
+static void nested_dissection(int N, const std::vector<int> &Kp, const std::vector<int> &Ki, std::vector<int> &perm, int leaf = 48) {
   std::vector<std::vector<int>> adj(N);
   for (int j = 0; j < N; j++)
     for (int k = Kp[j]; k < Kp[j + 1]; k++) { int i = Ki[k]; if (i != j) { adj[i].push_back(j); adj[j].push_back(i); } }
   for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-  NDCtx c{adj, std::vector<int>(N, 0), std::vector<int>(N, 0), 0, {}, 48};
+  NDCtx c{adj, std::vector<int>(N, 0), std::vector<int>(N, 0), 0, {}, leaf};
   std::vector<int> all(N);
   std::iota(all.begin(), all.end(), 0);
   nd_rec(c, all);
@@ -1128,31 +1131,38 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     cost = (2.0 * phases + (an.dt.k ? an.dt.k / 128 + 3 : 0)) * 0.4e-6 + 8.0 * bt * 1.15 * stream / 40e9;
   };
   {
-    std::vector<int> p_md, p_nd;
-    double c_md = 0.0, c_nd = 0.0;
     const bool dbg_t = getenv("MI_OSQP_DEBUG_ORDER") != nullptr;
     auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tt = now_();
     const char *force = getenv("MI_OSQP_ORDERING");       // "md" / "nd": experiments
-    // minimum degree works on the explicit elimination graph (quadratic on big meshes: 0.9 s at N = 160 k, where nested
-    // dissection takes 0.2 s and wins anyway): beyond 60 k rows it is a candidate only on request
-    const bool try_md = N <= 60000 || (force && force[0] == 'm');
-    if (try_md) min_degree(N, an.Kp, an.Ki, p_md);
+    // Candidates: minimum degree (works on the explicit elimination graph - quadratic on big meshes: 0.9 s at N = 160 k, where
+    // nested dissection takes 0.2 s and wins anyway - so beyond 60 k rows only on request) and nested dissections with
+    // several leaf sizes (all of them while the pattern is small enough for that to cost milliseconds; MI_OSQP_ND_LEAF
+    // forces one size).  The cheapest by the modelled time of one KKT solve wins; ties go to the earlier candidate.
+    struct Cand { std::vector<int> perm; double cost = 0.0; int leaf = 0; };      // leaf 0 = minimum degree
+    std::vector<Cand> cands;
+    const bool try_md = (N <= 60000 && !(force && force[0] == 'n')) || (force && force[0] == 'm');
+    if (try_md) { cands.emplace_back(); min_degree(N, an.Kp, an.Ki, cands.back().perm); }
     if (dbg_t) { fprintf(stderr, "[mi_osqp] min_degree %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
-    nested_dissection(N, an.Kp, an.Ki, p_nd);
-    if (dbg_t) { fprintf(stderr, "[mi_osqp] nested_dissection %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
-    finalize(p_nd, c_nd);
-    if (dbg_t) { fprintf(stderr, "[mi_osqp] finalize(nd) %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
-    bool use_nd = true;
-    if (try_md) {
-      finalize(p_md, c_md);
-      if (dbg_t) { fprintf(stderr, "[mi_osqp] finalize(md) %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
-      use_nd = c_nd < c_md;
-      if (getenv("MI_OSQP_DEBUG_ORDER")) fprintf(stderr, "[mi_osqp] ordering cost md %.3e nd %.3e\n", c_md, c_nd);
-      if (force) use_nd = force[0] == 'n';
-      if (use_nd) finalize(p_nd, c_nd);
+    if (!(force && force[0] == 'm')) {
+      std::vector<int> leaves;
+      const char *el = getenv("MI_OSQP_ND_LEAF");
+      if (el && atoi(el) >= 2) leaves = {atoi(el)};
+      else if (N <= 8000) leaves = {48, 24, 12, 8, 4};
+      else if (N <= 60000) leaves = {48, 12};
+      else leaves = {48};
+      for (int lf : leaves) { cands.emplace_back(); cands.back().leaf = lf; nested_dissection(N, an.Kp, an.Ki, cands.back().perm, lf); }
+      if (dbg_t) { fprintf(stderr, "[mi_osqp] nested_dissection x %zu %.1f ms\n", leaves.size(), 1e3 * (now_() - tt)); tt = now_(); }
     }
-    an.ordering = use_nd ? 1 : 0;
+    size_t best = 0;
+    for (size_t c = 0; c < cands.size(); c++) {
+      finalize(cands[c].perm, cands[c].cost);
+      if (dbg_t) fprintf(stderr, "[mi_osqp] ordering candidate %s leaf %d: modelled solve %.3e s, nnz(L) %d\n", cands[c].leaf ? "nd" : "md", cands[c].leaf, cands[c].cost, an.Lp[N]);
+      if (cands[c].cost < cands[best].cost) best = c;
+    }
+    if (dbg_t) { fprintf(stderr, "[mi_osqp] finalize x %zu %.1f ms\n", cands.size(), 1e3 * (now_() - tt)); tt = now_(); }
+    if (best + 1 != cands.size()) finalize(cands[best].perm, cands[best].cost);
+    an.ordering = cands[best].leaf ? 1 : 0;
   }
   if (tri_waves > 0 && (bt != 1 || an.dt.k)) return MI_OSQP_ERR_INVALID_SETTINGS;
   build_tri_schedules(an, tri_waves > 0 ? tri_waves : nwaves, bt, tri_waves > 0);

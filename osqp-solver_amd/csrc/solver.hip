@@ -631,7 +631,7 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
   const bool use = !(off && atoi(off) == 0) && n > 0 && m >= 0 && Pp && Ap && Pp[0] == 0 && Ap[0] == 0 && Pp[n] >= 0 && Ap[n] >= 0 &&
                    Pp[n] < ((int64_t)1 << 30) && Ap[n] < ((int64_t)1 << 30);
   std::string env;                              // the knobs analyze() reads
-  for (const char *k : {"MI_OSQP_DENSE_TAIL", "MI_OSQP_ORDERING"}) { const char *v = getenv(k); env += v ? v : "-"; env += ';'; }
+  for (const char *k : {"MI_OSQP_DENSE_TAIL", "MI_OSQP_ORDERING", "MI_OSQP_ND_LEAF"}) { const char *v = getenv(k); env += v ? v : "-"; env += ';'; }
   uint64_t hsh = 1469598103934665603ull;
   if (use) {
     hsh = ancache::fnv(hsh, Pp, (size_t)(n + 1) * 8); hsh = ancache::fnv(hsh, Pi, (size_t)Pp[n] * 8);
