@@ -205,10 +205,15 @@ int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64
  *
  *     reinit_some / update_A_bounds_some / warm_start_x_some   new data for QPs that are not iterating
  *     solve_begin_some                                         Solve() entry of those QPs (own iteration count from 0)
- *     advance(n_segments)                                      enqueue: every iterating QP runs n_segments x L iterations, L =
+ *     advance(n_segments)                                      enqueue ONE launch in which every iterating QP runs up to
+ *                                                              n_segments segments of L iterations + check, L =
  *                                                              gcd(check_termination, adaptive_rho_interval, max_iter) = 25 by
- *                                                              default, with the checks / rho updates / refactorisations a
- *                                                              blocking solve of its own would see at those iterations
+ *                                                              default - with the checks / rho updates a blocking solve of
+ *                                                              its own would see at those iterations.  With n_segments > 1 the
+ *                                                              launch ends at the first segment boundary after ANY QP of the
+ *                                                              handle has finished (so that the caller can react to it), and
+ *                                                              a QP whose rho changes pauses until the refactorisation that
+ *                                                              follows the launch in stream order
  *     poll(wait, ...)                                          which QPs finished in the oldest advance not polled yet
  *     get_primal_some / get_dual_some / get_info_some          results of finished QPs (host memory, no device access)
  *

@@ -697,6 +697,7 @@ class ContinuousGOMPSolver {
   std::atomic<long> advances{0};       // advance() calls of all stages
   std::atomic<int> solver_reuses{0};   // stages whose solver was kept from the previous run()
   int pipeline_depth = 1;              // 2: a stage enqueues its next advance before it looks at the previous one's results
+  int segments_per_advance = 4;        // a launch runs on until a QP of the stage finishes, at most that many segments
   // per stage: {waypoints, advances, seconds admitting, waiting for the device, processing finished QPs, idle}
   std::vector<std::array<double, 6>> stageProfile() const {
     std::vector<std::array<double, 6>> r;
@@ -765,7 +766,7 @@ class ContinuousGOMPSolver {
       if (!st.qp) continue;
       // ---- one segment for everything that iterates here; the finished QPs decide the next step of their trajectories
       if (st.qp->running() > 0 && in_flight < pipeline_depth) {
-        if (!st.qp->advance(1)) { failed_ = true; wakeAll(); break; }
+        if (!st.qp->advance(segments_per_advance)) { failed_ = true; wakeAll(); break; }
         ++in_flight; ++advances; ++st.n_advances;
       }
       if (in_flight == 0) continue;

@@ -27,9 +27,13 @@ struct DenseTailDev {
 // per-QP double scalars, laid out [tile][DS_COUNT][BT]
 enum { DS_C = 0, DS_CINV, DS_RHO, DS_RHO_EST, DS_PRI_RES, DS_DUA_RES, DS_OBJ, DS_COUNT };
 // per-QP int scalars, laid out [tile][IS_COUNT][BT]
-// (IS_ITER0: the launch iteration count at which the QP's current solve began - 0 in a blocking solve; the continuous
-//  entry points start QPs at different launches, and every QP counts its iterations from its own start)
-enum { IS_STATUS = 0, IS_ITER, IS_RHO_UPDATES, IS_DONE, IS_NEED_REFACTOR, IS_ITER0, IS_COUNT };
+// (IS_CUR: iterations of the QP's current solve so far, kept by check_kernel - the continuous entry points begin the solves
+//  of a batch at different launches, and every QP counts its own iterations; IS_ITER: the count at which it finished)
+// (continuous batching: the per-QP calls prepare a QP on a second stream while the others iterate.  IS_PENDING = 1: a solve
+//  has been begun and joins the first advance launch that sees the mark; 2: the solve is paused for its refactorisation
+//  (IS_NEED_REFACTOR = 1 until factor_kernel has run).  A pending / paused slot reads IS_DONE = 1, so every kernel leaves it
+//  alone.  IS_EPOCH counts the solves begun in the slot: the host tells a finished solve from the previous one by it.)
+enum { IS_STATUS = 0, IS_ITER, IS_RHO_UPDATES, IS_DONE, IS_NEED_REFACTOR, IS_CUR, IS_PENDING, IS_EPOCH, IS_COUNT };
 
 struct KernelArgs {
   int n, m, N, B;
@@ -119,6 +123,11 @@ int max_coresident_groups(int threads, size_t lds, int n_cus);
 int max_coresident_factor_groups(int threads, int n_cus);
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
 hipError_t launch_check(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st);
+// up to max_segments segments of seg_len iterations + check per tile in one launch (advance_kernel; LDS-resident tiles only);
+// flags / solutions of the tiles it touched go to the pinned host images host_is / host_ds
+// (counter: device word the tiles count themselves out on; host_done: pinned word that receives seq when the last tile has left)
+hipError_t launch_advance(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st, int max_segments, int seg_len,
+                          int *host_is, double *host_ds, unsigned *stop, unsigned seq, unsigned *counter, unsigned *host_done);
 hipError_t launch_spmv(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st,
                        const double *x, const double *y, double *Px, double *Aty, double *Ax);
 // fused P x / A'y / A x (spmv_fused_kernel): the compact P and A values of a tile staged in LDS once and used for all
@@ -166,15 +175,16 @@ struct RuizArgs {
 };
 hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st);
 // ---- per-QP entry points (continuous batching; solver.hip "continuous")
-// begin a solve of the listed slots: status unsolved, own iteration count 0 from launch iteration `tick` on; slots whose factor
-// is invalid (IS_NEED_REFACTOR < 0) end at once as kNonConvex.  clear[j] != 0: the count of rho updates restarts at 0.
-hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int tick, int cold, hipStream_t st);
+// begin a solve of the listed slots: status unsolved, own iteration count 0, next epoch, pending until an advance launch
+// activates it; slots whose factor is invalid (IS_NEED_REFACTOR < 0) end at once as kNonConvex.
+// clear[j] != 0: the count of rho updates restarts at 0.
+hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int cold, hipStream_t st);
 // the state a fresh setup leaves in the listed slots: zero iterates, rho = rho0, no rho updates, idle
 hipError_t launch_fresh_slots(const KernelArgs &a, const int *slots, int nslots, int BT, double rho0, hipStream_t st);
-// work[0 .. nslots) = the slots whose IS_NEED_REFACTOR flag is 1 (any order), then -1
+// work[0 .. nslots) = the slots paused for their refactorisation (IS_NEED_REFACTOR = 1; any order), then -1
 hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipStream_t st);
-// slots still iterating whose refactorisation lost the inertia (flag -1): kNonConvex at own iteration iter_end - IS_ITER0
-hipError_t launch_fail_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st);
+// paused slots: resume (flag 0) or, when the refactorisation lost the inertia (flag -1), kNonConvex at their own iteration count
+hipError_t launch_resume_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st);
 // dst[slot] = src[slot] for the listed slots: [slot][per] streams / [tile][len][BT] interleaved arrays
 hipError_t launch_copy_slot_streams(double *dst, const double *src, const int *slots, int nslots, size_t per, hipStream_t st);
 hipError_t launch_copy_slot_rows(double *dst, const double *src, const int *slots, int nslots, int len, int BT, hipStream_t st);

@@ -861,9 +861,9 @@ __device__ __forceinline__ void kkt_solve_lds(const KernelArgs &a, const TilePtr
 // E6-E10 for iterations (iter_begin, iter_end] of one tile.  Lean on purpose: the
 // residual / termination / rho logic lives in check_kernel, so this kernel needs
 // little beyond the register ring of the step streams.
+// (n_iter iterations; a device function so that advance_kernel can run it segment after segment)
 template <int BT, int NT, bool GX, bool WIDE = false>
-__global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
-  extern __shared__ double smem[];
+__device__ __forceinline__ void iterate_body(const KernelArgs &a, double *smem, int n_iter) {
   // multi-workgroup mode (global vector, one QP): the grid is ONE tile; thread / wave numbers run over the grid and the
   // barriers between phases are grid barriers
   const Mw mw{a.mw_bar, GX && BT == 1 && a.mw_groups > 1 ? (unsigned)a.mw_groups : 1u};
@@ -894,8 +894,8 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   }
   if (df && tid == 0) st_sc1(xs + 2 * (size_t)sh, 0.0);            // the entry padding slots gather
   if constexpr (GX) wg_or_grid_barrier(mw); else __syncthreads();
-  for (int iter = a.iter_begin + 1; iter <= a.iter_end; iter++) {
-    const bool do_info = a.info_at_end && iter == a.iter_end;     // delta_x / delta_y are only needed by check_kernel
+  for (int iter = 1; iter <= n_iter; iter++) {
+    const bool do_info = a.info_at_end && iter == n_iter;     // delta_x / delta_y are only needed by check_kernel
     // ---- E7
     kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
     // ---- E8-E10 fused with E6 of the next iteration (run_tri ends with a barrier): every thread replaces the
@@ -963,12 +963,18 @@ __global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
     if constexpr (GX) wg_or_grid_barrier(mw); else __syncthreads();
   }
 }
-
-// E11-E14 at iteration iter_end: residuals, termination and infeasibility tests,
-// rho estimate / update request, solution store.  Runs once per segment.
 template <int BT, int NT, bool GX, bool WIDE = false>
-__global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
+__global__ __launch_bounds__(NT) void iterate_kernel(KernelArgs a) {
   extern __shared__ double smem[];
+  iterate_body<BT, NT, GX, WIDE>(a, smem, a.iter_end - a.iter_begin);
+}
+
+// E11-E14 after a segment of n_iter iterations: residuals, termination and infeasibility tests, rho estimate / update
+// request, solution store.  Every QP counts its iterations itself (IS_CUR: iterations of its current solve so far): QPs
+// of a continuous batch begin their solves at different launches.  Returns (to every thread of the workgroup) bit 0: a
+// QP of the tile finished in this check, bit 1: a QP of the tile asks for its refactorisation.
+template <int BT, int NT, bool GX, bool WIDE = false>
+__device__ __forceinline__ int check_body(const KernelArgs &a, double *smem, int n_iter) {
   // one QP shared by the grid (single large QPs, see iterate_kernel): tid / nthr / wave run over the grid, ltid / lwave /
   // lnw over the workgroup (block reductions); barriers between phases that exchange data are grid barriers and every
   // block reduction is followed by a reduction over the workgroups
@@ -990,9 +996,8 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
   // compacted into the leading tiles (solver.hip), so the id comes from a table
   const int qp = a.qp_of_slot[tile * BT + b];
   int done = p.iscal[IS_DONE * BT + b];
-  if (__syncthreads_and(done)) return;
-  // the QP's own iteration count: QPs of a continuous batch (solver.hip) start at different launches
-  const int iter = a.iter_end - p.iscal[IS_ITER0 * BT + b];
+  if (__syncthreads_and(done)) return 0;
+  const int iter = p.iscal[IS_CUR * BT + b] + n_iter;
   int status = p.iscal[IS_STATUS * BT + b];
   int rho_updates = p.iscal[IS_RHO_UPDATES * BT + b];
   double rho = p.dscal[DS_RHO * BT + b];
@@ -1175,13 +1180,92 @@ __global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
     }
   }
   sync();
+  const bool was_done = done && !just_done;          // idle before this check: its flags (a failed factor's -1) stay
   if (tid < BT) {
     p.iscal[IS_DONE * BT + b] = done; p.iscal[IS_STATUS * BT + b] = status;
     p.iscal[IS_RHO_UPDATES * BT + b] = rho_updates;
-    p.iscal[IS_NEED_REFACTOR * BT + b] = need_refactor;
+    if (!was_done) { p.iscal[IS_NEED_REFACTOR * BT + b] = need_refactor; p.iscal[IS_CUR * BT + b] = iter; }
     p.dscal[DS_RHO * BT + b] = rho;
   }
+  int ev = (just_done ? 1 : 0) | (need_refactor ? 2 : 0);
+  if constexpr (BT > 1) ev = (__syncthreads_or(ev & 1) ? 1 : 0) | (__syncthreads_or(ev & 2) ? 2 : 0);
+  return ev;
+}
+template <int BT, int NT, bool GX, bool WIDE = false>
+__global__ __launch_bounds__(NT) void check_kernel(KernelArgs a) {
+  extern __shared__ double smem[];
+  (void)check_body<BT, NT, GX, WIDE>(a, smem, a.iter_end - a.iter_begin);
+}
 
+// ---- segments back to back in ONE launch (LDS-resident tiles) -------------------------------------------------------------
+// The host round trip per segment (two launches, a copy of the flags, a synchronisation: 0.1-0.25 ms) is what a lone small
+// QP and a continuous batch spend most of their time on.  Here a tile runs up to max_segments segments - seg_len iterations +
+// the check - by itself and leaves early
+//   * when all of its QPs have finished,
+//   * when one of its QPs asks for a refactorisation (the refactorisation kernels follow in stream order),
+//   * with a stop word: at the first segment boundary after ANY QP of the launch has finished - the caller wants to react
+//     to that QP (re-linearise, update, begin again) while the others are not held up for long.
+// On its way out a tile publishes its flags - and check_body the solutions of finished QPs - in host memory (pinned,
+// zero-copy): no copy follows the launch, the host reads them once the launch is over.
+struct AdvanceArgs {
+  int max_segments, seg_len;
+  int *host_is;            // [tile][IS_COUNT][BT] image of the int scalars in pinned host memory, or null
+  double *host_ds;         // [tile][DS_COUNT][BT] image of the double scalars, or null
+  unsigned *stop;          // device word holding the sequence number of the last launch in which a QP finished, or null
+  unsigned seq;            // this launch's sequence number (> 0)
+  unsigned *counter;       // device words: [0] tiles that have left this launch, [1] tiles that iterated in it (the last tile resets both)
+  unsigned *host_done;     // pinned words: [0] receives seq when every tile has left and published, [1] the tiles that iterated
+};
+template <int BT, int NT>
+__global__ __launch_bounds__(NT) void advance_kernel(KernelArgs a, AdvanceArgs v) {
+  extern __shared__ double smem[];
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  int *is = a.iscal + (size_t)tile * IS_COUNT * BT;
+  // solves begun (or resumed after their refactorisation) on the handle's second stream join the first launch that sees them
+  if (tid < BT && __hip_atomic_load(&is[IS_PENDING * BT + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 1) {
+    is[IS_PENDING * BT + tid] = 0; is[IS_DONE * BT + tid] = 0;
+  }
+  __syncthreads();
+  bool iterated = false;
+  for (int sgm = 0; sgm < v.max_segments; sgm++) {
+    const int done = tid < BT ? is[IS_DONE * BT + tid] : 1;
+    if (__syncthreads_and(done)) break;
+    iterated = true;
+    iterate_body<BT, NT, false>(a, smem, v.seg_len);
+    const int ev = check_body<BT, NT, false>(a, smem, v.seg_len);
+    if ((ev & 1) && v.stop && tid == 0) __hip_atomic_store(v.stop, v.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ev & 2) {
+      // a QP whose rho changed pauses (reads "done") until the refactorisation kernels, which follow on the second stream,
+      // have given it its new factor: the other QPs of the tile and of the launch go on
+      __syncthreads();
+      if (tid < BT && is[IS_NEED_REFACTOR * BT + tid] == 1 && !is[IS_DONE * BT + tid]) { is[IS_DONE * BT + tid] = 1; is[IS_PENDING * BT + tid] = 2; }
+    }
+    if (v.stop && sgm + 1 < v.max_segments) {
+      const unsigned sw = __hip_atomic_load(v.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a tile that misses it runs one more segment)
+      if (__syncthreads_or(sw == v.seq)) break;
+    }
+    __syncthreads();
+  }
+  if (!v.host_is) return;
+  // flags of this tile -> host (after the solutions check_body stored: system-scope fence in between), then the tile counts
+  // itself out; the last one tells the host that the launch is over
+  __syncthreads();
+  if (tid < IS_COUNT * BT) v.host_is[(size_t)tile * IS_COUNT * BT + tid] = is[tid];
+  if (v.host_ds && tid < DS_COUNT * BT) v.host_ds[(size_t)tile * DS_COUNT * BT + tid] = a.dscal[(size_t)tile * DS_COUNT * BT + tid];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0 && v.counter) {
+    if (iterated) __hip_atomic_fetch_add(v.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned left = __hip_atomic_fetch_add(v.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (left == gridDim.x) {
+      const unsigned active = __hip_atomic_load(v.counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(v.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(v.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v.host_done[1] = active;
+      __threadfence_system();
+      __hip_atomic_store(v.host_done, v.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---------------------------------------------------------- standalone ops
@@ -1799,6 +1883,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     for (int e = tid; e < N * BT; e += nthr) a.dinv[H(N, e / BT)] = dnew[e];
   }
   sync();
+  __threadfence();          // (continuous batching: an advance launch on another stream may read the flag)
   if (tid < BT && slot >= 0) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = bad_inertia ? -1 : 0;   // -1: the new factor has the wrong inertia
 }
 
@@ -2392,25 +2477,39 @@ __device__ __forceinline__ void fail_one_slot(const KernelArgs &a, int slot, int
 }
 // Solve() entry of the listed QPs ([EXT] osqp_solve: status unsolved, iteration count 0; warm_start off: cold iterates).
 // A QP without a valid factor (the last refactorisation of its KKT matrix lost the inertia) ends at once as kNonConvex.
-__global__ void start_slots_kernel(KernelArgs a, const int *__restrict__ slots, const int *__restrict__ clear, int BT, int tick, int cold) {
+__global__ void start_slots_kernel(KernelArgs a, const int *__restrict__ slots, const int *__restrict__ clear, int BT, int cold) {
   const int slot = slots[blockIdx.x], tid = threadIdx.x, nthr = blockDim.x;
   if (slot < 0) return;
   const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
   int *is = a.iscal + tile * IS_COUNT * BT;
-  if (is[IS_NEED_REFACTOR * BT + b] < 0) { fail_one_slot(a, slot, BT, 0, tid, nthr); return; }
+  if (is[IS_NEED_REFACTOR * BT + b] < 0) {
+    fail_one_slot(a, slot, BT, 0, tid, nthr);
+    __syncthreads();
+    if (tid == 0) { is[IS_PENDING * BT + b] = 0; __threadfence_system(); is[IS_EPOCH * BT + b] += 1; }      // (the epoch last: it validates the rest)
+    return;
+  }
   if (cold) {
     for (int i = tid; i < a.n; i += nthr) a.x[(tile * a.n + i) * BT + b] = 0.0;
     for (int j = tid; j < a.m; j += nthr) { a.z[(tile * a.m + j) * BT + b] = 0.0; a.y[(tile * a.m + j) * BT + b] = 0.0; }
   }
+  __syncthreads();
   if (tid == 0) {
-    is[IS_STATUS * BT + b] = -10; is[IS_ITER * BT + b] = 0; is[IS_DONE * BT + b] = 0; is[IS_NEED_REFACTOR * BT + b] = 0;
-    is[IS_ITER0 * BT + b] = tick;
+    // the slot stays idle (IS_DONE) until an advance launch activates it: this kernel may run next to an advance launch
+    // that must not pick the QP up half-prepared.  Everything else first, the pending mark last.
+    // (An advance launch that publishes this slot's flags in between must not make the host take the slot's previous,
+    //  finished solve for the new one: the pending mark is up before the epoch moves.)
+    is[IS_STATUS * BT + b] = -10; is[IS_ITER * BT + b] = 0; is[IS_NEED_REFACTOR * BT + b] = 0;
+    is[IS_CUR * BT + b] = 0;
     if (clear[blockIdx.x]) is[IS_RHO_UPDATES * BT + b] = 0;
+    __threadfence();
+    __hip_atomic_store(&is[IS_PENDING * BT + b], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    is[IS_EPOCH * BT + b] += 1;
   }
 }
-hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int tick, int cold, hipStream_t st) {
+hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int cold, hipStream_t st) {
   if (!nslots) return hipSuccess;
-  hipLaunchKernelGGL(start_slots_kernel, dim3(nslots), dim3(256), 0, st, a, slots, clear, BT, tick, cold);
+  hipLaunchKernelGGL(start_slots_kernel, dim3(nslots), dim3(256), 0, st, a, slots, clear, BT, cold);
   return hipGetLastError();
 }
 // The iterates and scalars a fresh setup leaves (batch_setup_impl: zero x, y, z; rho = rho estimate = settings.rho; no rho
@@ -2424,7 +2523,7 @@ __global__ void fresh_slots_kernel(KernelArgs a, const int *__restrict__ slots, 
   if (tid == 0) {
     int *is = a.iscal + tile * IS_COUNT * BT;
     is[IS_STATUS * BT + b] = -10; is[IS_ITER * BT + b] = 0; is[IS_RHO_UPDATES * BT + b] = 0; is[IS_DONE * BT + b] = 1;
-    is[IS_NEED_REFACTOR * BT + b] = 0; is[IS_ITER0 * BT + b] = 0;
+    is[IS_NEED_REFACTOR * BT + b] = 0; is[IS_CUR * BT + b] = 0; is[IS_PENDING * BT + b] = 0;
     double *ds = a.dscal + tile * DS_COUNT * BT;
     ds[DS_RHO * BT + b] = rho0; ds[DS_RHO_EST * BT + b] = rho0; ds[DS_PRI_RES * BT + b] = 0.0; ds[DS_DUA_RES * BT + b] = 0.0; ds[DS_OBJ * BT + b] = 0.0;
   }
@@ -2442,24 +2541,31 @@ __global__ __launch_bounds__(1024) void worklist_kernel(const int *__restrict__ 
   for (int s = threadIdx.x; s < nslots; s += blockDim.x) work[s] = -1;
   __syncthreads();
   for (int s = threadIdx.x; s < nslots; s += blockDim.x)
-    if (iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] == 1) work[atomicAdd(&s_cnt, 1)] = s;
+    if (iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] == 1 &&
+        iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_PENDING * BT + s % BT] == 2) work[atomicAdd(&s_cnt, 1)] = s;
 }
 hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipStream_t st) {
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, st, iscal, work, nslots, BT);
   return hipGetLastError();
 }
-// After the refactorisations of a launch: a QP still iterating whose new factor lost the inertia ends as kNonConvex
-// ([EXT] osqp_solve: adapt_rho fails -> OSQP_NON_CVX); the flag stays -1 until a refactorisation of that QP succeeds.
-__global__ void fail_flagged_kernel(KernelArgs a, int BT) {
+// After the refactorisations of the paused slots: flag 0 - the solve goes on with the next advance launch (pending mark 1);
+// flag -1 - the new factor lost the inertia: the QP ends as kNonConvex ([EXT] osqp_solve: adapt_rho fails -> OSQP_NON_CVX)
+// and keeps the flag until a refactorisation of it succeeds.
+__global__ void resume_flagged_kernel(KernelArgs a, int BT) {
   const int slot = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const size_t tile = (size_t)slot / BT, b = (size_t)slot % BT;
-  const int *is = a.iscal + tile * IS_COUNT * BT;
-  if (is[IS_NEED_REFACTOR * BT + b] >= 0 || is[IS_DONE * BT + b]) return;
-  fail_one_slot(a, slot, BT, a.iter_end - is[IS_ITER0 * BT + b], tid, nthr);
+  int *is = a.iscal + tile * IS_COUNT * BT;
+  if (is[IS_PENDING * BT + b] != 2) return;
+  const int flag = is[IS_NEED_REFACTOR * BT + b];
+  if (flag == 1) return;                                 // (its refactorisation has not run yet)
+  if (flag < 0) fail_one_slot(a, slot, BT, is[IS_CUR * BT + b], tid, nthr);
+  __syncthreads();
+  __threadfence();
+  if (tid == 0) __hip_atomic_store(&is[IS_PENDING * BT + b], flag < 0 ? 0 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-hipError_t launch_fail_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st) {
+hipError_t launch_resume_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st) {
   if (!nslots) return hipSuccess;
-  hipLaunchKernelGGL(fail_flagged_kernel, dim3(nslots), dim3(64), 0, st, a, BT);
+  hipLaunchKernelGGL(resume_flagged_kernel, dim3(nslots), dim3(64), 0, st, a, BT);
   return hipGetLastError();
 }
 __global__ void copy_slot_streams_kernel(double *dst, const double *__restrict__ src, const int *__restrict__ slots, size_t per) {
@@ -2686,6 +2792,22 @@ int max_coresident_factor_groups(int threads, int n_cus) {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(&factor_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&factor_kernel<1>), threads, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return nb * n_cus;
+}
+
+hipError_t launch_advance(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st, int max_segments, int seg_len,
+                          int *host_is, double *host_ds, unsigned *stop, unsigned seq, unsigned *counter, unsigned *host_done) {
+  if (a.xs_global || a.wide || a.df || threads > 1024 || (threads > 512 && BT > 2)) return hipErrorInvalidValue;
+  AdvanceArgs v{max_segments, seg_len, host_is, host_ds, stop, seq, counter, host_done};
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, a, v);
+    return hipGetLastError();
+  };
+  if (threads > 512) return BT == 1 ? go(&advance_kernel<1, 1024>) : go(&advance_kernel<2, 1024>);
+  if (BT == 1) return go(&advance_kernel<1, 512>);
+  if (BT == 2) return go(&advance_kernel<2, 512>);
+  return go(&advance_kernel<4, 512>);
 }
 
 hipError_t launch_iterate(const KernelArgs &a, int BT, int tiles, int threads, size_t lds, hipStream_t st) {

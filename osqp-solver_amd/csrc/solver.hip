@@ -7,6 +7,7 @@
 // There is NO CPU solve path: without a gfx950 device setup returns
 // MI_OSQP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -326,10 +327,11 @@ struct mi_osqp_batch {
   // ---- continuous batching (the per-QP entry points + advance / poll; section "continuous" below)
   struct Cont {
     bool on = false;
-    int tick = 0, L = 25;                    // launch iteration count; iterations per segment (gcd of the check / rho / max_iter periods)
+    int L = 25;                              // iterations per segment (gcd of the check / rho / max_iter periods)
+    unsigned launch_seq = 0;                 // sequence number of the last advance launch (the stop word's currency)
+    DevBuf<unsigned> stop;                   // device word: launch in which a QP last finished (advance_kernel)
     int64_t adv_seq = 0, polled_seq = 0;     // segments enqueued / segments whose flags the host has read
     std::vector<char> running, clear_rho;    // per QP: a solve is in flight; its next solve counts rho updates from 0
-    std::vector<int64_t> start_seq;          // per QP: adv_seq when its solve was begun (older flag copies do not concern it)
     std::vector<mi_osqp_info> info;          // per QP: result of its last finished solve
     int n_running = 0;
     // flag copies of the last two advances (pinned): iscal / dscal images + the event behind them
@@ -342,12 +344,30 @@ struct mi_osqp_batch {
     char *ring_h = nullptr; size_t ring_cap = 0, ring_h_cap = 0, ring_head = 0;
     DevBuf<char> ring_d;
     DevBuf<int> work;                        // device-built refactorisation work list of an advance
+    // The per-QP calls (new data, equilibration, refactorisation, warm start, begin) and the refactorisations after rho
+    // updates run on a second stream next to the advance launches: a QP that iterates through hundreds of segments must not
+    // wait for the other QPs' updates.  Nothing orders the two streams: a begun solve carries a pending mark that the next
+    // advance launch to see it takes up (IS_PENDING), a QP whose rho changed pauses until its refactorisation has run, and
+    // the host tells a finished solve from the slot's previous one by its epoch (IS_EPOCH).
+    hipStream_t ustream = nullptr;
+    bool own_ustream = false;
+    hipEvent_t ev_adv = nullptr;             // behind the last advance launch (the refactorisation kernels wait for it)
+    std::vector<int> epoch;                  // per QP: solves begun so far (what IS_EPOCH reads once the begin has run)
+    DevBuf<double> rz_scratch;               // equilibration scratch of that stream (not the check kernels': they may be running)
+    DevBuf<unsigned> counter;                // tiles that have left the advance launch in flight
+    unsigned *h_done = nullptr; size_t h_done_cap = 0;      // pinned: [0] sequence number of the last advance launch that is over, [1] tiles that iterated in it
+    unsigned last_active = 0;                // tiles that iterated in the last launch polled
+    hipEvent_t ev_u = nullptr;               // end of the second stream's queue (a launch after an idle one waits for it)
   } cont;
   ~mi_osqp_batch() {
     DevGuard guard(device);
     if (stream) (void)hipStreamSynchronize(stream);      // (the buffers go back to their pools right after: DevBuf remembers its device)
     for (int k = 0; k < 2; k++) { hostpool::give(cont.h_is[k], cont.h_is_cap[k]); hostpool::give(cont.h_ds[k], cont.h_ds_cap[k]); if (cont.ev[k]) (void)hipEventDestroy(cont.ev[k]); }
     hostpool::give(cont.xh, cont.xh_cap); hostpool::give(cont.yh, cont.yh_cap); hostpool::give(cont.ring_h, cont.ring_h_cap);
+    if (cont.ustream && cont.own_ustream) { (void)hipStreamSynchronize(cont.ustream); (void)hipStreamDestroy(cont.ustream); }
+    if (cont.ev_adv) (void)hipEventDestroy(cont.ev_adv);
+    if (cont.ev_u) (void)hipEventDestroy(cont.ev_u);
+    hostpool::give(cont.h_done, cont.h_done_cap);
     hostpool::give(h_iscal, h_iscal_cap); hostpool::give(h_dscal, h_dscal_cap); hostpool::give(pin, pin_cap); hostpool::give(h_npos, h_npos_cap);
     if (stream && ev0 && ev1 && evf0 && evf1 && evf2) streampool::give({device, stream, {ev0, ev1, evf0, evf1, evf2}});
     else {
@@ -1797,7 +1817,7 @@ int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double 
 // for each other.  A QP's solve is begun with solve_begin_some, advance() enqueues one segment (L iterations + check +
 // the refactorisations the check asks for) for every QP that is iterating, poll() reports the QPs that finished, and the
 // caller updates / warm-starts / begins them again while the rest keeps iterating.  Every QP counts its iterations from
-// its own begin (IS_ITER0), so it takes exactly the iterations, rho updates and checks of a blocking solve of its own:
+// its own begin (IS_CUR), so it takes exactly the iterations, rho updates and checks of a blocking solve of its own:
 // results are those of mi_osqp_batch_solve bit for bit.  Nothing in these calls waits for the device except poll().
 
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
@@ -1813,9 +1833,9 @@ static int cont_enter(mi_osqp_batch *h) {
   if (S.check_termination > 0) L = gcd_i(L, (int)S.check_termination);
   if (S.adaptive_rho && S.adaptive_rho_interval > 0) L = gcd_i(L, (int)S.adaptive_rho_interval);
   c.L = std::max(1, L);
-  c.running.assign((size_t)B, 0); c.clear_rho.assign((size_t)B, 0); c.start_seq.assign((size_t)B, 0);
+  c.running.assign((size_t)B, 0); c.clear_rho.assign((size_t)B, 0); c.epoch.assign((size_t)B, 0);
   c.info.assign((size_t)B, mi_osqp_info{});
-  c.n_running = 0; c.tick = 0; c.adv_seq = c.polled_seq = 0;
+  c.n_running = 0; c.adv_seq = c.polled_seq = 0; c.launch_seq = 0;
   const size_t icnt = (size_t)h->ntiles * IS_COUNT * BT, dcnt = (size_t)h->ntiles * DS_COUNT * BT;
   for (int k = 0; k < 2; k++) {
     if (!c.h_is[k]) HIPCHK(hostpool::alloc((void **)&c.h_is[k], icnt * sizeof(int), &c.h_is_cap[k]));
@@ -1837,17 +1857,35 @@ static int cont_enter(mi_osqp_batch *h) {
   }
   int rc;
   if (c.work.n < (size_t)nslots + 4 && (rc = c.work.alloc((size_t)nslots + 4))) return rc;
+  if (!c.ustream) {
+    // By default the preparation and the refactorisations share the handle's stream with the advance launches (in order):
+    // measured on the GOMP obstacle scene (ten handles driven by ten host threads) a second stream per handle LOSES - 20
+    // streams on the runtime's 4-10 hardware queues wait for each other's kernels (900 against 620 trajectories/s,
+    // profiles/r03).  MI_OSQP_CONT_STREAMS=2 gives every handle its second stream; the protocol is the same either way.
+    { const char *e = getenv("MI_OSQP_CONT_STREAMS"); c.own_ustream = e && atoi(e) == 2; }
+    if (c.own_ustream) HIPCHK(hipStreamCreateWithFlags(&c.ustream, hipStreamNonBlocking));
+    else c.ustream = h->stream;
+    HIPCHK(hipEventCreateWithFlags(&c.ev_adv, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c.ev_u, hipEventDisableTiming));
+    if ((rc = c.rz_scratch.alloc((size_t)B * (n + m) + 1)) || (rc = c.counter.alloc(4))) return rc;
+    HIPCHK(hostpool::alloc((void **)&c.h_done, 64, &c.h_done_cap));
+  }
+  if ((rc = c.counter.zero(h->stream))) return rc;
+  c.h_done[0] = c.h_done[1] = 0; c.last_active = 0;
   // the state of the last blocking solve, if any, stays valid; every slot is idle until its solve is begun
   HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
   for (int t = 0; t < h->ntiles; t++)
     for (int b = 0; b < BT; b++) {
       int *p = h->h_iscal + (size_t)t * IS_COUNT * BT;
-      p[IS_DONE * BT + b] = 1; p[IS_ITER0 * BT + b] = 0;
+      p[IS_DONE * BT + b] = 1; p[IS_CUR * BT + b] = 0; p[IS_PENDING * BT + b] = 0; p[IS_EPOCH * BT + b] = 0;
       if (h->clear_rho_updates) p[IS_RHO_UPDATES * BT + b] = 0;
       if (t * BT + b < B && h->failed[(size_t)t * BT + b]) p[IS_NEED_REFACTOR * BT + b] = -1;
     }
   h->clear_rho_updates = false;
   HIPCHK(hipMemcpyAsync(h->iscal.p, h->h_iscal, icnt * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  memcpy(c.h_is[0], h->h_iscal, icnt * sizeof(int)); memcpy(c.h_is[1], h->h_iscal, icnt * sizeof(int));      // the host images advance_kernel writes
+  if (!c.stop.p && (rc = c.stop.alloc(4))) return rc;
+  if ((rc = c.stop.zero(h->stream))) return rc;
   std::vector<int> ident((size_t)nslots);
   for (int sl = 0; sl < nslots; sl++) ident[sl] = sl < B ? sl : -1;
   HIPCHK(hipMemcpyAsync(h->qp_of_slot.p, ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1860,6 +1898,7 @@ static int cont_enter(mi_osqp_batch *h) {
 static int cont_leave(mi_osqp_batch *h) {
   mi_osqp_batch::Cont &c = h->cont;
   if (!c.on) return MI_OSQP_OK;
+  if (c.ustream) HIPCHK(hipStreamSynchronize(c.ustream));
   HIPCHK(hipStreamSynchronize(h->stream));
   const size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT;
   HIPCHK(hipMemcpy(h->h_iscal, h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost));
@@ -1881,13 +1920,13 @@ static int ring_take(mi_osqp_batch *h, size_t bytes, RingSpan &out) {
   mi_osqp_batch::Cont &c = h->cont;
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes > c.ring_cap) { g_last_error = "per-QP call larger than the staging ring"; return MI_OSQP_ERR_ALLOC; }
-  if (c.ring_head + bytes > c.ring_cap) { HIPCHK(hipStreamSynchronize(h->stream)); c.ring_head = 0; }      // everything handed out so far has been consumed
+  if (c.ring_head + bytes > c.ring_cap) { HIPCHK(hipStreamSynchronize(c.ustream)); HIPCHK(hipStreamSynchronize(h->stream)); c.ring_head = 0; }      // everything handed out so far has been consumed
   out.host = c.ring_h + c.ring_head; out.dev = c.ring_d.p + c.ring_head;
   c.ring_head += bytes;
   return MI_OSQP_OK;
 }
 static int ring_upload(mi_osqp_batch *h, const RingSpan &sp, size_t bytes) {
-  if (bytes) HIPCHK(hipMemcpyAsync(sp.dev, sp.host, bytes, hipMemcpyHostToDevice, h->stream));
+  if (bytes) HIPCHK(hipMemcpyAsync(sp.dev, sp.host, bytes, hipMemcpyHostToDevice, h->cont.ustream));
   return MI_OSQP_OK;
 }
 
@@ -1920,9 +1959,8 @@ static int cont_stage_ids(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, i
 }
 
 // the listed slots' share of the setup snapshot (mi_osqp_batch_reset restores it)
-static int snapshot_some(mi_osqp_batch *h, const int *d_ids, int nq) {
+static int snapshot_some(mi_osqp_batch *h, const int *d_ids, int nq, hipStream_t st) {
   const Analysis &an = (*h->anp);
-  hipStream_t st = h->stream;
   HIPCHK(launch_copy_slot_streams(h->fwd_val0.p, h->fwd_val.p, d_ids, nq, (size_t)an.fwd.phys_steps() * 64, st));
   HIPCHK(launch_copy_slot_streams(h->bwd_val0.p, h->bwd_val.p, d_ids, nq, (size_t)an.bwd.phys_steps() * 64, st));
   if (an.dt.k) HIPCHK(launch_copy_slot_streams(h->dt_val0.p, h->dt_val.p, d_ids, nq, (size_t)an.dt.n_steps * 64, st));
@@ -1938,9 +1976,10 @@ static int snapshot_some(mi_osqp_batch *h, const int *d_ids, int nq) {
 static int enqueue_refactor_list(mi_osqp_batch *h, const int *d_work, int count) {
   if (count <= 0) return MI_OSQP_OK;
   const Analysis &an = (*h->anp);
+  hipStream_t st = h->cont.ustream;         // (every refactorisation of the continuous mode: one stream, one scratch)
   FactorArgs fa = make_factor_args(h, 0);
   fa.work = d_work; fa.mw_groups = 0;
-  HIPCHK(launch_factor(fa, 1, count, factor_threads(), h->stream));
+  HIPCHK(launch_factor(fa, 1, count, factor_threads(), st));
   if (an.dt.k) {
     const DenseTail &dt = an.dt;
     TailArgs da{};
@@ -1950,9 +1989,9 @@ static int enqueue_refactor_list(mi_osqp_batch *h, const int *d_work, int count)
     da.lt_pos = h->dt_lt_pos.p; da.ltcol_col = h->dt_ltcol_col.p; da.tile_tab = h->dt_tile_tab.p; da.wave_tiles = h->dt_wave_tiles.p;
     da.dt_task = h->dt_task.p; da.dt_task_step = h->dt_task_step.p; da.n_tasks = (uint32_t)(dt.task.size() / 4);
     da.asm_q64 = h->dt_asm_q64.p; da.diag_tile = h->dt_diag_tile.p; da.src_tile = h->dt_src_tile.p;
-    da.Lblk = h->Lblk.p; da.Dl = h->Dl.p; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
+    da.Lblk = fa.Lblk; da.Dl = fa.Dl; da.Sd = h->dt_Sd.p; da.dt_val = h->dt_val.p; da.dinv = h->dinv.p; da.npos = h->npos.p; da.iscal = h->iscal.p;
     da.trace = nullptr;
-    HIPCHK(launch_tail(da, count, h->dt_lds_asm, h->dt_lds, h->stream));
+    HIPCHK(launch_tail(da, count, h->dt_lds_asm, h->dt_lds, st));
   }
   return MI_OSQP_OK;
 }
@@ -1972,8 +2011,9 @@ static int cont_new_data(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, co
   double *hin = (double *)in.host, *din = (double *)in.dev;
   memcpy(hin, Av, cA * sizeof(double)); memcpy(hin + cA, l, cb * sizeof(double)); memcpy(hin + cA + cb, u, cb * sizeof(double));
   if ((rc = ring_upload(h, in, (cA + 2 * cb) * sizeof(double)))) return rc;
+  hipStream_t us = h->cont.ustream;
   KernelArgs ka = make_args(h);
-  if (fresh) HIPCHK(launch_fresh_slots(ka, d_ids, nq, h->BT, h->st.rho, h->stream));
+  if (fresh) HIPCHK(launch_fresh_slots(ka, d_ids, nq, h->BT, h->st.rho, us));
   RuizArgs r{};
   r.n = n; r.m = m; r.nnzP = nnzP; r.nnzA = nnzA; r.B = nq; r.BT = h->BT; r.iters = (int)h->st.scaling;
   r.ids = d_ids; r.fresh = fresh ? 1 : 0; r.rawP = h->rawP.p; r.rawq = h->rawq.p;
@@ -1981,12 +2021,12 @@ static int cont_new_data(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, co
   r.rawA = din; r.rawl = din + cA; r.rawu = din + cA + cb;
   r.pa_val = h->pa_val.p; r.q = h->q.p; r.Dsc = h->Dsc.p; r.Dsc_inv = h->Dsc_inv.p; r.Esc = h->Esc.p; r.Esc_inv = h->Esc_inv.p;
   r.l = h->l.p; r.u = h->u.p; r.dscal = h->dscal.p;
-  r.dn = h->out1.p; r.en = h->out1.p + (size_t)h->B * n;
+  r.dn = h->cont.rz_scratch.p; r.en = h->cont.rz_scratch.p + (size_t)h->B * n;        // (not the check kernels' scratch: they may be running)
   r.pa_out = (double *)out.dev;
-  HIPCHK(launch_ruiz(r, h->stream));
-  HIPCHK(launch_scatter(r.pa_out, h->chk_val.p, h->chk.src.p, d_ids, nq, pa_len, h->chk.view(an.chk), h->BT, h->stream));
+  HIPCHK(launch_ruiz(r, us));
+  HIPCHK(launch_scatter(r.pa_out, h->chk_val.p, h->chk.src.p, d_ids, nq, pa_len, h->chk.view(an.chk), h->BT, us));
   if ((rc = enqueue_refactor_list(h, d_ids, nq))) return rc;
-  if ((rc = snapshot_some(h, d_ids, nq))) return rc;
+  if ((rc = snapshot_some(h, d_ids, nq, us))) return rc;
   for (int64_t j = 0; j < n_ids; j++) { h->cont.clear_rho[(size_t)ids[j]] = 1; h->failed[(size_t)ids[j]] = 0; }
   h->host_scaling_stale = true; h->host_bounds_stale = true; h->host_rho_stale = true;
   return MI_OSQP_OK;
@@ -2030,7 +2070,7 @@ int mi_osqp_batch_warm_start_x_some(mi_osqp_batch *h, int64_t n_ids, const int64
   if ((rc = ring_upload(h, sp, cnt * sizeof(double)))) return rc;
   KernelArgs a = make_args(h);
   a.sel = d_sel;
-  HIPCHK(launch_warm_start(a, h->BT, h->ntiles, h->threads, h->lds, h->stream, (const double *)sp.dev));
+  HIPCHK(launch_warm_start(a, h->BT, h->ntiles, h->threads, h->lds, h->cont.ustream, (const double *)sp.dev));
   return MI_OSQP_OK;
 }
 
@@ -2042,7 +2082,6 @@ int mi_osqp_batch_solve_begin_some(mi_osqp_batch *h, int64_t n_ids, const int64_
   if ((rc = cont_enter(h)) || (rc = cont_check_ids(h, n_ids, ids, true))) return rc;
   if (!n_ids) return MI_OSQP_OK;
   mi_osqp_batch::Cont &c = h->cont;
-  if (c.n_running == 0) c.tick = 0;           // (launches already enqueued carry their own iteration numbers)
   RingSpan sp;
   if ((rc = ring_take(h, 2 * (size_t)n_ids * sizeof(int), sp))) return rc;
   int *hi = (int *)sp.host;
@@ -2055,11 +2094,11 @@ int mi_osqp_batch_solve_begin_some(mi_osqp_batch *h, int64_t n_ids, const int64_
   KernelArgs a = make_args(h);
   a.x_out = c.xh; a.y_out = c.yh;
   // (a QP whose last refactorisation lost the inertia carries flag -1 on the device: start_slots_kernel ends it as kNonConvex)
-  HIPCHK(launch_start_slots(a, (const int *)sp.dev, (const int *)sp.dev + n_ids, (int)n_ids, h->BT, c.tick, h->st.warm_start ? 0 : 1, h->stream));
+  HIPCHK(launch_start_slots(a, (const int *)sp.dev, (const int *)sp.dev + n_ids, (int)n_ids, h->BT, h->st.warm_start ? 0 : 1, c.ustream));
   for (int64_t j = 0; j < n_ids; j++) {
     const size_t q = (size_t)ids[j];
     if (!c.running[q]) { c.running[q] = 1; c.n_running++; }
-    c.start_seq[q] = c.adv_seq;
+    c.epoch[q]++;
   }
   return MI_OSQP_OK;
 }
@@ -2076,24 +2115,30 @@ int mi_osqp_batch_advance(mi_osqp_batch *h, int64_t n_segments) {
   const int BT = h->BT, nslots = h->ntiles * BT;
   KernelArgs a = make_args(h);
   a.x_out = c.xh; a.y_out = c.yh;
-  for (int64_t sgm = 0; sgm < n_segments; sgm++) {
-    a.iter_begin = c.tick; a.iter_end = c.tick + c.L; a.info_at_end = 1;
-    c.tick += c.L;
-    HIPCHK(launch_iterate(a, BT, h->ntiles, h->threads, h->lds, h->stream));
-    HIPCHK(launch_check(a, BT, h->ntiles, h->threads, h->lds, h->stream));
-    if (h->st.adaptive_rho) {
-      // row E13 without the host: the slots whose rho changed are listed on the device, refactored, and the ones whose
-      // new factor lost its inertia end as kNonConvex
-      HIPCHK(launch_worklist(h->iscal.p, c.work.p, nslots, BT, h->stream));
-      if ((rc = enqueue_refactor_list(h, c.work.p, nslots))) return rc;
-      HIPCHK(launch_fail_flagged(a, nslots, BT, h->stream));
-    }
+  // ONE launch: every tile runs up to n_segments segments (L iterations + check each) and publishes its flags and the
+  // solutions of finished QPs in pinned host memory; with several segments the launch ends early for everybody once a QP
+  // has finished (the caller wants to react to it), and for a tile whose QP asks for a refactorisation
+  a.info_at_end = 1;
+  // Nothing orders the two streams - unless the last launch found nothing to iterate: then whatever is running waits for
+  // its preparation / refactorisation on the second stream, and launching again at once would only spin.  Such a launch
+  // waits for the second stream's queue.
+  if (c.last_active == 0) {
+    HIPCHK(hipEventRecord(c.ev_u, c.ustream));
+    HIPCHK(hipStreamWaitEvent(h->stream, c.ev_u, 0));
   }
+  c.launch_seq++;
   const int par = (int)(c.adv_seq & 1);
-  const size_t icnt = (size_t)h->ntiles * IS_COUNT * BT, dcnt = (size_t)h->ntiles * DS_COUNT * BT;
-  HIPCHK(hipMemcpyAsync(c.h_is[par], h->iscal.p, icnt * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(c.h_ds[par], h->dscal.p, dcnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(launch_advance(a, BT, h->ntiles, h->threads, h->lds, h->stream, (int)std::min<int64_t>(n_segments, 1 << 20), c.L, c.h_is[par], c.h_ds[par],
+                        n_segments > 1 ? c.stop.p : nullptr, c.launch_seq, c.counter.p, c.h_done));
   HIPCHK(hipEventRecord(c.ev[par], h->stream));
+  if (h->st.adaptive_rho) {
+    // row E13 without the host, next to the following launches: the QPs this launch paused (their rho changed) are listed on
+    // the device, refactored and marked to resume - or ended as kNonConvex when the new factor lost its inertia
+    HIPCHK(hipStreamWaitEvent(c.ustream, c.ev[par], 0));
+    HIPCHK(launch_worklist(h->iscal.p, c.work.p, nslots, BT, c.ustream));
+    if ((rc = enqueue_refactor_list(h, c.work.p, nslots))) return rc;
+    HIPCHK(launch_resume_flagged(a, nslots, BT, c.ustream));
+  }
   c.adv_seq++;
   c.seq_of[par] = c.adv_seq;
   h->host_rho_stale = true;
@@ -2109,23 +2154,36 @@ int mi_osqp_batch_poll(mi_osqp_batch *h, int64_t wait, int64_t *n_finished, int6
   DevGuard guard(h->device);
   const int64_t seq = c.polled_seq + 1;
   const int par = (int)((seq - 1) & 1);
-  if (!wait) {
-    hipError_t e = hipEventQuery(c.ev[par]);
-    if (e == hipErrorNotReady) { *n_finished = -1; return MI_OSQP_OK; }
-    HIPCHK(e);
-  } else HIPCHK(hipEventSynchronize(c.ev[par]));
+  // the launch is over when its last tile has written the sequence number into pinned memory (no runtime call in the way:
+  // waking up from hipEventSynchronize costs up to milliseconds when several host threads wait on several streams)
+  auto over = [&]() { return __atomic_load_n(c.h_done, __ATOMIC_ACQUIRE) >= (unsigned)seq; };
+  if (!over()) {
+    if (!wait) { *n_finished = -1; return MI_OSQP_OK; }
+    const double t0 = now_s();
+    for (int spin = 0; !over(); spin++) {
+      if (spin < 2000) { __builtin_ia32_pause(); continue; }
+      struct timespec ts{0, 20000};                      // 20 us
+      nanosleep(&ts, nullptr);
+      if ((spin & 1023) == 0 && now_s() - t0 > 5.0) { HIPCHK(hipEventSynchronize(c.ev[par])); if (!over()) { g_last_error = "advance launch ended without reporting"; return MI_OSQP_ERR_DEVICE; } }
+    }
+  }
+  c.last_active = c.h_done[1];
   const int BT = h->BT;
   int64_t nf = 0;
-  // (the caller's buffer must take every finished QP of this advance: with less room nothing is consumed)
-  int64_t would = 0;
-  for (int q = 0; q < h->B; q++)
-    if (c.running[q] && c.start_seq[q] < seq && c.h_is[par][(size_t)(q / BT) * IS_COUNT * BT + IS_DONE * BT + q % BT]) would++;
-  if (would > capacity || (would > 0 && !ids_out)) { *n_finished = would; g_last_error = "poll: ids_out too small"; return MI_OSQP_ERR_INVALID_DATA; }
-  for (int q = 0; q < h->B; q++) {
-    if (!c.running[q] || c.start_seq[q] >= seq) continue;
+  auto finished = [&](int q) {
+    if (!c.running[q]) return false;
     const int *ti = c.h_is[par] + (size_t)(q / BT) * IS_COUNT * BT;
     const int b = q % BT;
-    if (!ti[IS_DONE * BT + b]) continue;
+    return ti[IS_DONE * BT + b] != 0 && ti[IS_PENDING * BT + b] == 0 && ti[IS_EPOCH * BT + b] == c.epoch[(size_t)q];
+  };
+  // (the caller's buffer must take every finished QP of this advance: with less room nothing is consumed)
+  int64_t would = 0;
+  for (int q = 0; q < h->B; q++) would += finished(q) ? 1 : 0;
+  if (would > capacity || (would > 0 && !ids_out)) { *n_finished = would; g_last_error = "poll: ids_out too small"; return MI_OSQP_ERR_INVALID_DATA; }
+  for (int q = 0; q < h->B; q++) {
+    if (!finished(q)) continue;
+    const int *ti = c.h_is[par] + (size_t)(q / BT) * IS_COUNT * BT;
+    const int b = q % BT;
     const double *td = c.h_ds[par] + (size_t)(q / BT) * DS_COUNT * BT;
     mi_osqp_info &I = c.info[(size_t)q];
     I.iter = ti[IS_ITER * BT + b]; I.status_val = ti[IS_STATUS * BT + b]; I.exit_code = exit_code_of((int)I.status_val);
