@@ -452,13 +452,33 @@ def _grid_entry(M, PR, torch, O, g):
     e = {"config": f"config 5{'' if g == 316 else ' at reduced size'}: single large sparse QP ({g} x {g} grid), n={st['n']} m={st['m']}", "value": info[0].iter / t1,
          "unit": "ADMM iterations/s", "ms": 1e3 * t1, "iterations_timed": int(info[0].iter), "ms_per_iteration": 1e3 * t1 / max(1, info[0].iter),
          "setup_seconds": setup_s, "N": st["N"], "nnz_L": st["nnz_L"], "phases": [st["fwd_levels"], st["bwd_levels"]]}
+    perm = s.ordering()
     s.close()
-    if O is not None and g <= 160:
+    if g == 316:
+        # roofline of the dataflow iterate kernel at the literal size: SURVEY 8(d) bytes per iteration against the launch time
+        # (25 iterations per launch) and the PMC traffic of the committed profile (profiles/config5_traffic.json,
+        # scripts/profile_config5_pmc.sh: FETCH_SIZE x 1.84 + WRITE_SIZE, median launch)
+        alg = 2 * 8 * st["nnz_L"] + 40 * st["N"] + 8 * (5 * st["n"] + 9 * st["m"])
+        e["roofline"] = {"bound": "hbm", "kernel": "iterate_kernel<1,512,true,true> (dataflow form, %d x %d threads)" % (st["solve_groups"], st["solve_group_threads"]),
+                         "algorithmic_bytes_per_iteration": alg, "achieved": alg / (1e-3 * e["ms_per_iteration"]) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": alg / (1e-3 * e["ms_per_iteration"]) / 8e12}
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "config5_traffic.json")))["kernels"]
+            k = [v for kk, v in tr.items() if "iterate_kernel" in kk][0]
+            per_launch = 1.84 * k["fetch_raw_bytes_median_launch"] + k["write_bytes_median_launch"]
+            e["roofline"].update({"traffic": per_launch, "traffic_per_iteration": per_launch / 25.0, "traffic_over_algorithmic": per_launch / 25.0 / alg,
+                                  "profiled_launch_ms": k["avg_ns"] * 1e-6})
+        except Exception:
+            e["roofline"]["traffic"] = None
+    if O is not None:
+        # (the oracle's own exact minimum degree is quadratic in the fill - minutes at the literal size: it factors with the
+        #  elimination order the product chose; the ordering changes round-off only)
         P, A = PR.qp_matrices(pr, 0)
-        o = O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0], max_iter=200)
+        o = O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0], kkt_perm=perm, max_iter=200)
         t = time.perf_counter(); o.solve(); t2 = time.perf_counter() - t
         e["cpu_baseline"] = {"value": o.info().iter / t2, "unit": "ADMM iterations/s", "cores": 1, "kind": "port", "ms_per_iteration": 1e3 * t2 / max(1, o.info().iter),
-                             "sample": "same QP, 200 iterations, oracle solve phase on one thread"}
+                             "same_iteration_count": bool(o.info().iter == info[0].iter),
+                             "sample": "same QP, 200 iterations, oracle solve phase on one thread (factor in the product's elimination order)"}
     return e
 
 

@@ -169,6 +169,10 @@ int mi_osqp_batch_get_primal(mi_osqp_batch *h, double *x_out /*[B][n]*/);
 int mi_osqp_batch_get_dual(mi_osqp_batch *h, double *y_out /*[B][m]*/);
 int mi_osqp_batch_get_info(mi_osqp_batch *h, mi_osqp_info *info /*[B]*/);
 int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st);
+/* the elimination order the analysis chose for the KKT matrix [[P + sigma I, A'], [A, -1/rho]]: kkt_perm[k] = natural index
+ * (0 .. n-1 variables, n .. n+m-1 constraint rows) eliminated k-th; n + m entries.  (Lets a CPU checker factor the same
+ * large KKT matrix without a minimum-degree ordering of its own.) */
+int mi_osqp_batch_get_ordering(mi_osqp_batch *h, int64_t *kkt_perm);
 void mi_osqp_batch_free(mi_osqp_batch *h);
 /* Freed handles leave their device buffers (at most 8 GiB), pinned host buffers (at most 1 GiB) and stream / event sets in
  * process-wide caches for the next setup - the GOMP drivers build one solver per horizon segment; this returns them to

@@ -68,6 +68,8 @@ def _bind(lib):
     lib.oq_default_settings.argtypes = [C.POINTER(Settings)]
     lib.oq_setup.restype = C.c_void_p
     lib.oq_setup.argtypes = [C.c_longlong, C.c_longlong, ip, ip, dp, dp, ip, ip, dp, dp, dp, C.POINTER(Settings), ip]
+    lib.oq_setup_ordered.restype = C.c_void_p
+    lib.oq_setup_ordered.argtypes = [C.c_longlong, C.c_longlong, ip, ip, dp, dp, ip, ip, dp, dp, dp, C.POINTER(Settings), ip, ip]
     lib.oq_solve.restype = C.c_longlong
     lib.oq_solve.argtypes = [C.c_void_p]
     lib.oq_get_solution.argtypes = [C.c_void_p, dp, dp]
@@ -139,7 +141,7 @@ class OracleQPSolver:
     """CPU twin of the reference QPSolver.  P, A are scipy CSC matrices (any
     triangles of P; the upper one is used, as osqp-cpp does [EXT])."""
 
-    def __init__(self, P, q, A, l, u, **settings):
+    def __init__(self, P, q, A, l, u, kkt_perm=None, **settings):
         import scipy.sparse as sp
         P = sp.csc_matrix(P); A = sp.csc_matrix(A)
         P.sort_indices(); A.sort_indices()
@@ -152,9 +154,15 @@ class OracleQPSolver:
         lv, uv = _f64(l), _f64(u)
         self.settings = default_settings(**settings)
         err = C.c_longlong(0)
-        self._h = self._L.oq_setup(self.n, self.m, _ip(Pp), _ip(Pi), _dp(Px), _dp(qv),
-                                   _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(lv), _dp(uv),
-                                   C.byref(self.settings), C.byref(err))
+        if kkt_perm is None:
+            self._h = self._L.oq_setup(self.n, self.m, _ip(Pp), _ip(Pi), _dp(Px), _dp(qv),
+                                       _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(lv), _dp(uv),
+                                       C.byref(self.settings), C.byref(err))
+        else:       # a caller-supplied elimination order (the exact minimum degree is quadratic in the fill)
+            pm = _i64(kkt_perm)
+            self._h = self._L.oq_setup_ordered(self.n, self.m, _ip(Pp), _ip(Pi), _dp(Px), _dp(qv),
+                                               _ip(self._Ap), _ip(self._Ai), _dp(Ax), _dp(lv), _dp(uv),
+                                               C.byref(self.settings), _ip(pm), C.byref(err))
         if not self._h:
             raise ValueError(f"oracle setup failed, err={err.value}")
 

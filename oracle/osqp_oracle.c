@@ -481,12 +481,21 @@ static oq_int refactor(oq_work *w) {
   return 0;
 }
 
-static oq_int init_linsys(oq_work *w) {
+/* given_perm: a fill-reducing ordering supplied by the caller (perm[k] = natural KKT index eliminated k-th) instead of the
+ * exact minimum degree below, whose cost is quadratic in the fill - the only way to set this checker up for a 4 10^5-row KKT
+ * matrix in seconds.  Any permutation yields the same KKT solutions up to round-off ([EXT]: upstream takes AMD's). */
+static oq_int init_linsys(oq_work *w, const oq_int *given_perm) {
   oq_int N = w->N = w->n + w->m;
   if (form_KKT(w)) return 1;
   w->perm = (oq_int *)xcalloc((size_t)N, sizeof(oq_int));
   w->pinv = (oq_int *)xcalloc((size_t)N, sizeof(oq_int));
-  order_min_degree(N, &w->K, w->perm);
+  if (given_perm) {
+    for (oq_int k = 0; k < N; k++) w->pinv[k] = -1;
+    for (oq_int k = 0; k < N; k++) {
+      if (given_perm[k] < 0 || given_perm[k] >= N || w->pinv[given_perm[k]] >= 0) return 1;      /* not a permutation */
+      w->perm[k] = given_perm[k]; w->pinv[given_perm[k]] = k;
+    }
+  } else order_min_degree(N, &w->K, w->perm);
   for (oq_int k = 0; k < N; k++) w->pinv[w->perm[k]] = k;
   if (permute_KKT(w)) return 1;
   w->etree = (oq_int *)xcalloc((size_t)N, sizeof(oq_int));
@@ -562,6 +571,15 @@ oq_work *oq_setup(oq_int n, oq_int m,
                   const oq_int *Ap, const oq_int *Ai, const oq_float *Ax,
                   const oq_float *l, const oq_float *u,
                   const oq_settings *settings, oq_int *err) {
+  return oq_setup_ordered(n, m, Pp, Pi, Px, q, Ap, Ai, Ax, l, u, settings, NULL, err);
+}
+
+oq_work *oq_setup_ordered(oq_int n, oq_int m,
+                          const oq_int *Pp, const oq_int *Pi, const oq_float *Px,
+                          const oq_float *q,
+                          const oq_int *Ap, const oq_int *Ai, const oq_float *Ax,
+                          const oq_float *l, const oq_float *u,
+                          const oq_settings *settings, const oq_int *kkt_perm, oq_int *err) {
   oq_int e_dummy; if (!err) err = &e_dummy; *err = 0;
   /* E1: validation ([EXT] osqp-cpp Init + validate_data) */
   if (n <= 0 || m < 0 || !Pp || !Ap || !settings) { *err = 1; return NULL; }
@@ -608,7 +626,7 @@ oq_work *oq_setup(oq_int n, oq_int m,
   w->c = w->cinv = 1.0;
   if (w->settings.scaling) scale_data(w);
   set_rho_vec(w);
-  oq_int rc = init_linsys(w);
+  oq_int rc = init_linsys(w, kkt_perm);
   if (rc) { *err = rc; oq_cleanup(w); return NULL; }
   w->info.status_val = OQ_UNSOLVED; w->info.iter = 0; w->info.rho_updates = 0;
   w->info.rho_estimate = w->settings.rho;

@@ -94,6 +94,16 @@ oq_work *oq_setup(oq_int n, oq_int m,
                   const oq_float *l, const oq_float *u,
                   const oq_settings *settings, oq_int *err);
 
+/* The same with a caller-supplied elimination order of the KKT matrix [[P + sigma I, A'], [A, -1/rho]] (kkt_perm[k] = natural
+ * index, 0 .. n+m-1, eliminated k-th; NULL = the exact minimum degree of oq_setup): test infrastructure for problems whose
+ * minimum-degree ordering would take minutes (BASELINE config 5 at its literal size).  The ordering changes round-off only. */
+oq_work *oq_setup_ordered(oq_int n, oq_int m,
+                          const oq_int *Pp, const oq_int *Pi, const oq_float *Px,
+                          const oq_float *q,
+                          const oq_int *Ap, const oq_int *Ai, const oq_float *Ax,
+                          const oq_float *l, const oq_float *u,
+                          const oq_settings *settings, const oq_int *kkt_perm, oq_int *err);
+
 /* OsqpSolver::Solve ([REF] src/osqp-wrapper.h:52). Returns status_val. */
 oq_int oq_solve(oq_work *w);
 

@@ -97,6 +97,7 @@ def lib():
         L.mi_osqp_batch_get_dual.argtypes = [vp, dp]
         L.mi_osqp_batch_get_info.argtypes = [vp, C.POINTER(Info)]
         L.mi_osqp_batch_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mi_osqp_batch_get_ordering.argtypes = [vp, ip]
         L.mi_osqp_batch_free.argtypes = [vp]; L.mi_osqp_batch_free.restype = None
         L.mi_osqp_batch_update_bounds_device.argtypes = [vp, vp, vp, vp]
         L.mi_osqp_batch_solve_device.argtypes = [vp, vp, vp, vp, vp]
@@ -268,6 +269,12 @@ class BatchSolver:
         s = Stats()
         _chk(lib().mi_osqp_batch_get_stats(self._h, C.byref(s)), "get_stats")
         return s.as_dict()
+
+    def ordering(self):
+        """Elimination order of the KKT matrix chosen by the analysis (natural index eliminated k-th)."""
+        perm = np.empty(self.n + self.m, dtype=np.int64)
+        _chk(lib().mi_osqp_batch_get_ordering(self._h, _ip(perm)), "get_ordering")
+        return perm
 
     def update_A(self, Ax, A_pattern=None):
         Ax = _f64(Ax).reshape(self.B, -1)

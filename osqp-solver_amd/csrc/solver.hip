@@ -1417,6 +1417,13 @@ int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st) {
   return MI_OSQP_OK;
 }
 
+int mi_osqp_batch_get_ordering(mi_osqp_batch *h, int64_t *kkt_perm) {
+  if (!h || !kkt_perm) return MI_OSQP_ERR_NULL;
+  const Analysis &an = (*h->anp);
+  for (int k = 0; k < an.N; k++) kkt_perm[k] = an.perm[(size_t)k];
+  return MI_OSQP_OK;
+}
+
 int mi_osqp_batch_last_solve_stats(mi_osqp_batch *h, int64_t *total_iters, int64_t *kernel_launches, double *device_seconds,
                                    double *refactor_seconds, int64_t *refactor_count, double *compact_seconds) {
   if (h && compact_seconds) *compact_seconds = h->last_compact_s;

@@ -539,6 +539,12 @@ def test_config5_literal_size_solves():
     assert abs(info.pri_res - pri) <= 1e-6 + 1e-2 * pri or info.pri_res <= eps_pri
     r = kkt_residuals(P, pr["q"][0], A, pr["l"][0], pr["u"][0], x, y)
     assert r["prim"] < 5e-3 and r["stat"] < 5e-2 and r["dual_sign"] < 1e-9
+    # oracle parity at the literal size: the oracle factors in the product's elimination order (its own exact minimum degree
+    # would take minutes here; the ordering changes round-off only) - same exit code, iteration count, rho updates, x to 1e-6
+    o = O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0], kkt_perm=s.ordering())
+    sto, xo = o.solve()
+    assert ST2EXIT[sto] == info.exit_code and o.info().iter == info.iter and o.info().rho_updates == info.rho_updates
+    assert np.max(np.abs(x - xo)) <= TOL_X
 
 
 def test_global_solve_vector_mode_small(monkeypatch):

@@ -130,3 +130,22 @@ def test_batch_driver_matches_single():
         st, x = s.solve()
         assert st == r["status"][b] and s.info().iter == r["iters"][b]
         np.testing.assert_array_equal(x, r["x"][b])
+
+
+def test_oracle_with_a_caller_supplied_ordering_gives_the_same_solution():
+    """oq_setup_ordered (test infrastructure for KKT matrices whose exact minimum-degree ordering takes minutes): any
+    elimination order yields the same iterates up to round-off; a non-permutation is rejected."""
+    from osqp_solver_amd import problems as PR
+    pr = PR.random_box_qp(1, n=40, mg=30, nnz_per_row=4)
+    P, A = PR.qp_matrices(pr, 0)
+    ref = O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0])
+    st0, x0 = ref.solve()
+    N = 40 + 70
+    rng = np.random.default_rng(5)
+    for perm in (np.arange(N), np.arange(N)[::-1].copy(), rng.permutation(N)):
+        o = O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0], kkt_perm=perm)
+        st, x = o.solve()
+        assert st == st0 and o.info().iter == ref.info().iter and np.max(np.abs(x - x0)) < 1e-9
+    bad = np.arange(N); bad[3] = bad[4]
+    with pytest.raises(ValueError):
+        O.OracleQPSolver(P, pr["q"][0], A, pr["l"][0], pr["u"][0], kkt_perm=bad)
