@@ -681,6 +681,7 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
 }
 
 static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
+static bool host_ruiz(const mi_osqp_batch *h);
 // Kernels that spin on their own grid (the dataflow sweeps and grid barriers of a large single QP, the grouped
 // refactorisation) need every workgroup of the grid resident.  The grids are clamped to what the device keeps resident
 // (max_coresident_groups); two such grids on one device could still starve each other, so their launches - from any
@@ -913,6 +914,10 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   int nnzPin = (int)Pp[n], nnzA = (int)Ap[n];
   const int CH = 128;
   double t_factor = 0.0, t_upload = 0.0;
+  // Row E2 (Ruiz equilibration) of a batch runs on the device (ruiz_kernel from the raw data: bit for bit what scale_qp
+  // computes), like every later update of the handle; a handful of large QPs keeps the host threads (host_ruiz()).  The
+  // host mirrors of the scaled problem are then fetched only if a host path ever needs them (ensure_mirrors).
+  const bool dev_ruiz = !host_ruiz(h);
   for (int c0 = 0; c0 < B; c0 += CH) {
     int c1 = (int)std::min<int64_t>(B, c0 + CH);
     double ta = now_s();
@@ -920,7 +925,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     // equilibration.  The numeric factorisation itself happens on the device, below.
     std::vector<char> dup(c1 - c0, 0);
     std::vector<double> raw_pq((size_t)(c1 - c0) * (an.Pp[n] + n));
-    for (int k = 1; k < c1 - c0; k++) {
+    for (int k = 1; k < c1 - c0 && !dev_ruiz; k++) {
       const int qi = c0 + k;
       dup[k] = !memcmp(Pv + (size_t)qi * nnzPin, Pv + (size_t)c0 * nnzPin, sizeof(double) * nnzPin) &&
                !memcmp(Av + (size_t)qi * nnzA, Av + (size_t)c0 * nnzA, sizeof(double) * nnzA) &&
@@ -934,8 +939,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
               l + (size_t)qi * m, u + (size_t)qi * m, Q);
       std::copy(Q.Pv.begin(), Q.Pv.end(), raw_pq.begin() + (size_t)k * (an.Pp[n] + n));          // (before the equilibration)
       std::copy(Q.q.begin(), Q.q.end(), raw_pq.begin() + (size_t)k * (an.Pp[n] + n) + an.Pp[n]);
-      if (h->st.scaling) { if (second_pass) scale_like(an, h->qp[c0], Q); else scale_qp(an, h->st, Q); }
-      set_rho_vec(an, h->st, Q);
+      if (!dev_ruiz && h->st.scaling) { if (second_pass) scale_like(an, h->qp[c0], Q); else scale_qp(an, h->st, Q); }
+      set_rho_vec(an, h->st, Q);          // (device equilibration: sized here, refreshed with the mirrors)
     };
     parallel_for(c1 - c0, [&](int k, int) { numeric(k, false); });
     parallel_for(c1 - c0, [&](int k, int) { numeric(k, true); });
@@ -943,8 +948,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     t_factor += tb - ta;
     std::vector<int> ids(c1 - c0);
     for (int k = 0; k < c1 - c0; k++) ids[k] = c0 + k;
-    if ((rc = upload_rho(h, ids)) || (rc = upload_problem(h, ids, true))) return rc;
-    {     // raw triu(P) and q of the chunk, QP-major (mi_osqp_batch_reinit_some)
+    if (!dev_ruiz && ((rc = upload_rho(h, ids)) || (rc = upload_problem(h, ids, true)))) return rc;
+    {     // raw triu(P) and q of the chunk, QP-major (mi_osqp_batch_reinit_some; the device equilibration below)
       const size_t per = (size_t)an.Pp[n] + n;
       if ((rc = ensure_stage(h, raw_pq.size() + 1, 0))) return rc;
       HIPCHK(hipMemcpyAsync(h->stage.p, raw_pq.data(), raw_pq.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -960,7 +965,34 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     size_t cnt = (size_t)DS_COUNT * T;
     for (size_t k = 0; k < cnt; k++) h->h_dscal[k] = 0.0;
     HIPCHK(hipMemcpy(h->dscal.p, h->h_dscal, cnt * sizeof(double), hipMemcpyHostToDevice));
-    if ((rc = sync_scalars_to_device(h, all, true))) return rc;
+    if ((rc = sync_scalars_to_device(h, all, !dev_ruiz))) return rc;          // (c and 1/c belong to the equilibration)
+  }
+  if (dev_ruiz) {
+    double tb = now_s();
+    // raw A and bounds as the caller gave them (QP-major) -> ruiz_kernel in its "fresh" form -> scaled P, A, q, bounds, D, E, c
+    // in the handle's layout + the scaled values once more QP-major for the check streams
+    const size_t cA = (size_t)B * nnzA, cb = (size_t)B * m, cpa = (size_t)B * (an.Pp[n] + nnzA);
+    if ((rc = ensure_pin(h, cA + 2 * cb + 1)) || (rc = ensure_stage(h, cA + 2 * cb + cpa + 1, (size_t)B))) return rc;
+    par_copy(h->pin, Av, cA);
+    if (m) { par_copy(h->pin + cA, l, cb); par_copy(h->pin + cA + cb, u, cb); }
+    HIPCHK(hipMemcpyAsync(h->stage.p, h->pin, (cA + 2 * cb) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    RuizArgs r{};
+    r.n = (int)n; r.m = (int)m; r.nnzP = an.Pp[n]; r.nnzA = nnzA; r.B = (int)B; r.BT = BT; r.iters = (int)h->st.scaling;
+    r.ids = nullptr; r.fresh = 1; r.rawP = h->rawP.p; r.rawq = h->rawq.p;
+    r.Prow = h->rz_prow.p; r.Pcol = h->rz_pcol.p; r.Arow = h->rz_arow.p; r.Acol = h->rz_acol.p;
+    r.rawA = h->stage.p; r.rawl = h->stage.p + cA; r.rawu = h->stage.p + cA + cb;
+    r.pa_val = h->pa_val.p; r.q = h->q.p; r.Dsc = h->Dsc.p; r.Dsc_inv = h->Dsc_inv.p; r.Esc = h->Esc.p; r.Esc_inv = h->Esc_inv.p;
+    r.l = h->l.p; r.u = h->u.p; r.dscal = h->dscal.p;
+    r.dn = h->out1.p; r.en = h->out1.p + (size_t)B * n;
+    r.pa_out = h->stage.p + cA + 2 * cb;
+    HIPCHK(launch_ruiz(r, h->stream));
+    std::vector<int> ids(B);
+    for (int i = 0; i < (int)B; i++) ids[i] = i;
+    HIPCHK(hipMemcpyAsync(h->ids.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(launch_scatter(r.pa_out, h->chk_val.p, h->chk.src.p, h->ids.p, (int)B, an.Pp[n] + nnzA, h->chk.view(an.chk), BT, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->host_scaling_stale = true; h->host_bounds_stale = true; h->host_rho_stale = true;
+    t_factor += now_s() - tb;
   }
   // E5 numeric on the device: KKT assembly + block LDL' + inverted diagonal blocks + scatter into the solve
   // streams of every QP (the kernel every later rho / A update uses); a wrong inertia comes back as an error

@@ -246,8 +246,8 @@ def test_update_of_values_and_bounds_in_one_call_equals_the_two_calls():
 
 @pytest.mark.parametrize("tile", [1, 2])
 def test_ruiz_on_the_device_equals_the_host_equilibration_bitwise(tile, monkeypatch):
-    """Row E2 after new A values runs on the device (ruiz_kernel: maxima by atomics, separate multiplications, one sum in
-    index order); MI_OSQP_HOST_RUIZ=1 keeps the host path (scale_qp) - same iterates bit for bit, with and without new
+    """Row E2 - at setup and after new A values - runs on the device (ruiz_kernel: maxima by atomics, separate multiplications,
+    one sum in index order); MI_OSQP_HOST_RUIZ=1 keeps the host path (scale_qp) - same iterates bit for bit, with and without new
     bounds, scaling on and off, GOMP pattern (many all-zero rows with infinite bounds) and random pattern."""
     monkeypatch.setenv("MI_OSQP_TILE", str(tile))
     rng = np.random.default_rng(21)
@@ -261,17 +261,17 @@ def test_ruiz_on_the_device_equals_the_host_equilibration_bitwise(tile, monkeypa
             monkeypatch.delenv("MI_OSQP_DEVICE_RUIZ" if host else "MI_OSQP_HOST_RUIZ", raising=False)
             monkeypatch.setenv("MI_OSQP_HOST_RUIZ" if host else "MI_OSQP_DEVICE_RUIZ", "1")      # (small batches default to the host)
             s = M.BatchSolver(pr["P"], pr["Px"], pr.get("q"), pr["A"], pr["Ax"], pr["l"], pr["u"], **kw)
-            s.solve()
+            i0 = s.solve(); x0 = s.primal().copy()                # (the setup itself equilibrates on the device / on the host)
             s.update_A_bounds(Ax2, l2, u2)
             i1 = s.solve(); x1, y1 = s.primal().copy(), s.dual().copy()
             s.update_A(pr["Ax"])                                   # values back, bounds kept
             i2 = s.solve(); x2 = s.primal().copy()
             s.update_bounds(pr["l"], pr["u"])                      # (host mirrors are fetched from the device if a row changes type)
             i3 = s.solve(); x3 = s.primal().copy()
-            res.append(([i.iter for i in i1], x1, y1, [i.iter for i in i2], x2, [i.iter for i in i3], x3))
+            res.append(([i.iter for i in i1], x1, y1, [i.iter for i in i2], x2, [i.iter for i in i3], x3, [i.iter for i in i0], x0))
         dev, hst = res
-        assert dev[0] == hst[0] and dev[3] == hst[3] and dev[5] == hst[5]
-        for k in (1, 2, 4, 6): np.testing.assert_array_equal(dev[k], hst[k])
+        assert dev[0] == hst[0] and dev[3] == hst[3] and dev[5] == hst[5] and dev[7] == hst[7]
+        for k in (1, 2, 4, 6, 8): np.testing.assert_array_equal(dev[k], hst[k])
 
 
 def test_headline_config_properties_full_size():
