@@ -181,7 +181,7 @@ hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st);
 hipError_t launch_start_slots(const KernelArgs &a, const int *slots, const int *clear, int nslots, int BT, int cold, hipStream_t st);
 // the state a fresh setup leaves in the listed slots: zero iterates, rho = rho0, no rho updates, idle
 hipError_t launch_fresh_slots(const KernelArgs &a, const int *slots, int nslots, int BT, double rho0, hipStream_t st);
-// work[0 .. nslots) = the slots paused for their refactorisation (IS_NEED_REFACTOR = 1; any order), then -1
+// work[0 .. nslots) = the slots whose rho changed (IS_NEED_REFACTOR = 1: paused, or finished at max_iter; any order), then -1
 hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipStream_t st);
 // paused slots: resume (flag 0) or, when the refactorisation lost the inertia (flag -1), kNonConvex at their own iteration count
 hipError_t launch_resume_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st);

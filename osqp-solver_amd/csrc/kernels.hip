@@ -23,6 +23,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "device_types.h"
 #include "sched_format.h"
@@ -1232,6 +1234,9 @@ __global__ __launch_bounds__(NT) void advance_kernel(KernelArgs a, AdvanceArgs v
     if (__syncthreads_and(done)) break;
     iterated = true;
     iterate_body<BT, NT, false>(a, smem, v.seg_len);
+    // (inlined next to iterate_body the two bodies share one register allocation - 128 VGPRs + spills at 16 waves against
+    //  68 for iterate_kernel alone - and every iteration pays ~10 % for it; check_body out of line, as a real function, was
+    //  measured twice as slow: the call's register convention puts scratch traffic into the sweeps)
     const int ev = check_body<BT, NT, false>(a, smem, v.seg_len);
     if ((ev & 1) && v.stop && tid == 0) __hip_atomic_store(v.stop, v.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ev & 2) {
@@ -2541,8 +2546,9 @@ __global__ __launch_bounds__(1024) void worklist_kernel(const int *__restrict__ 
   for (int s = threadIdx.x; s < nslots; s += blockDim.x) work[s] = -1;
   __syncthreads();
   for (int s = threadIdx.x; s < nslots; s += blockDim.x)
-    if (iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] == 1 &&
-        iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_PENDING * BT + s % BT] == 2) work[atomicAdd(&s_cnt, 1)] = s;
+    if (iscal[(size_t)(s / BT) * IS_COUNT * BT + IS_NEED_REFACTOR * BT + s % BT] == 1) work[atomicAdd(&s_cnt, 1)] = s;
+  // (flag 1: a QP paused by advance_kernel - or one that ran into max_iter on a rho-update iteration: finished AND to be
+  //  refactored, because the next solve of a warm-started solver continues from that factor)
 }
 hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipStream_t st) {
   hipLaunchKernelGGL(worklist_kernel, dim3(1), dim3(1024), 0, st, iscal, work, nslots, BT);
@@ -2738,11 +2744,26 @@ hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
 
 // all iterate kernels are built for <= 512 threads per workgroup (256 VGPRs per lane
 // hold the 16-step prefetch buffer); the host clamps `threads` accordingly
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size class instead of on every launch (it takes a
+// runtime lock; a lone small QP launches two kernels per 25 iterations): the largest size set so far is remembered per
+// kernel and device, a launch that needs more raises it.
+static hipError_t ensure_dynamic_lds(const void *kern, size_t lds) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> have;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  size_t &cur = have[{kern, dev}];
+  if (lds <= cur && cur != 0) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) cur = std::max<size_t>(lds, 1);
+  return e;
+}
 #define MI_DISPATCH(KERNEL, ...)                                                                   \
   do {                                                                                             \
     hipError_t e_;                                                                                 \
     auto go = [&](auto kern) -> hipError_t {                                                       \
-      e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      e_ = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);                          \
       if (e_ != hipSuccess) return e_;                                                             \
       hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, __VA_ARGS__);                  \
       return hipGetLastError();                                                                    \
@@ -2799,7 +2820,7 @@ hipError_t launch_advance(const KernelArgs &a, int BT, int tiles, int threads, s
   if (a.xs_global || a.wide || a.df || threads > 1024 || (threads > 512 && BT > 2)) return hipErrorInvalidValue;
   AdvanceArgs v{max_segments, seg_len, host_is, host_ds, stop, seq, counter, host_done};
   auto go = [&](auto kern) -> hipError_t {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(threads), lds, st, a, v);
     return hipGetLastError();

@@ -1175,6 +1175,77 @@ static int apply_swaps(mi_osqp_batch *h, const std::vector<int2> &pairs) {
 // runs the device refactorisation for the QPs whose rho changed, and continues.
 // The swaps are undone at the end - also when the loop ends with an error - so outside a solve
 // every array is in the identity layout.
+static int gcd_i(int a, int b);
+static int segment_length(const Settings &S);
+static int ensure_advance_buffers(mi_osqp_batch *h);
+static int wait_launch_over(mi_osqp_batch *h, unsigned seq);
+
+// The latency regime - no more tiles than CUs, the solve vector in LDS (a lone trajectory QP, a strong-scaling shard, the
+// stragglers' world): the host round trip per segment (two launches, a copy of the flags, a stream synchronisation) is a
+// tenth to a third of such a solve.  Here ONE advance_kernel launch carries every QP to its end or to its next rho update
+// (the QP pauses), the host waits on a word in pinned memory, refactors the paused QPs with the grouped factor_kernel and
+// launches again: host round trips = rho-update rounds + 1.  Same arithmetic, same per-QP iteration counts.
+// Measured (round 3): NOT a win as it stands - advance_kernel's fused bodies iterate ~10 % slower than iterate_kernel
+// (register allocation shared with the check), which eats the saved round trips (config 2: 0.73 against 0.69 ms).  Hence
+// opt-in (MI_OSQP_ADVANCE_SOLVE=1; tests/test_gpu_continuous.py runs it for parity).
+static bool small_batch_path(const mi_osqp_batch *h) {
+  if (!getenv("MI_OSQP_ADVANCE_SOLVE")) return false;
+  if (h->global_xs || h->mw_groups > 0 || h->ntiles > h->n_cus || h->BT != 1) return false;      // (tiles of 2 QPs at 16 waves spill in the fused kernel)
+  if (getenv("MI_OSQP_COMPACT") && !(*h->anp).dt.k) return false;
+  return segment_length(h->st) >= 5;
+}
+static int solve_small(mi_osqp_batch *h, KernelArgs a) {
+  mi_osqp_batch::Cont &c = h->cont;
+  const int BT = h->BT, nslots = h->ntiles * BT, L = segment_length(h->st);
+  int rc;
+  if ((rc = ensure_advance_buffers(h))) return rc;
+  HIPCHK(hipMemsetAsync(c.counter.p, 0, 2 * sizeof(unsigned), h->stream));
+  a.info_at_end = 1;
+  const int max_segments = (int)((h->st.max_iter + L - 1) / L) + 1;
+  std::vector<int> paused;
+  for (int round = 0; round < 100000; round++) {
+    const unsigned seq = ++c.launch_seq ? c.launch_seq : ++c.launch_seq;       // (never 0: the word's idle value)
+    c.h_done[0] = 0;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(launch_advance(a, BT, h->ntiles, h->threads, h->lds, h->stream, max_segments, L, c.h_is[0], c.h_ds[0], nullptr, seq, c.counter.p, c.h_done));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if ((rc = wait_launch_over(h, seq))) return rc;
+    h->last_launches++; h->kernel_launches++;
+    paused.clear();
+    bool any_active = false;
+    for (int sl = 0; sl < nslots && sl < h->B; sl++) {
+      const int *t = c.h_is[0] + (size_t)(sl / BT) * IS_COUNT * BT;
+      const int b = sl % BT;
+      if (t[IS_NEED_REFACTOR * BT + b] == 1) paused.push_back(sl);      // paused - or finished at max_iter on a rho-update iteration
+      else if (!t[IS_DONE * BT + b]) any_active = true;       // (cannot happen: a tile leaves only done or paused)
+    }
+    bool any_paused = false;
+    for (int sl : paused) any_paused = any_paused || c.h_is[0][(size_t)(sl / BT) * IS_COUNT * BT + IS_PENDING * BT + sl % BT] == 2;
+    if (paused.empty()) { if (any_active) continue; break; }
+    // ---- row E13 for the paused QPs: the grouped refactorisation of short lists, then resume (or isolate: kNonConvex)
+    const double tr = now_s();
+    std::vector<int> bad;
+    if ((rc = device_refactor_slots(h, paused, &bad))) return rc;
+    HIPCHK(launch_resume_flagged(a, nslots, BT, h->stream));
+    for (int sl : bad) h->failed[(size_t)sl] = 1;
+    h->host_rho_stale = true;
+    h->last_refactors += (int64_t)paused.size();
+    h->last_refactor_s += now_s() - tr;
+    if (!any_paused && !any_active) break;        // (only finished QPs were refactored: nothing is left to iterate)
+  }
+  {     // device time of the launches of this solve (events around the last launch; earlier ones through the stream order)
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->last_device_s += ms * 1e-3; h->kernel_ms_sum += ms; }
+  }
+  // the final flags are in the pinned image already
+  memcpy(h->h_iscal, c.h_is[0], (size_t)h->ntiles * IS_COUNT * BT * sizeof(int));
+  for (int qi = 0; qi < h->B; qi++)
+    h->last_total_iters += h->h_iscal[(size_t)(qi / BT) * IS_COUNT * BT + IS_ITER * BT + qi % BT];
+  h->solved_once = true;
+  return MI_OSQP_OK;
+}
+
 static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream) {
   hipStream_t keep = h->stream;
   struct Restore { mi_osqp_batch *h; hipStream_t s; ~Restore() { h->stream = s; } } restore{h, keep};
@@ -1195,6 +1266,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
     for (int q = 0; q < h->B; q++) if (h->failed[q]) bad.push_back(q);
     if ((rc = fail_slots(h, a, bad, &qp_of_slot, 0))) return rc;
   }
+  if (small_batch_path(h)) return solve_small(h, a);
   std::vector<std::vector<int2>> rounds;
   // compaction (re-pairing the QPs still iterating into fewer tiles) is implemented and tested but OFF by default:
   // since the value streams are per QP, a finished QP costs no bytes anyway, and moving data only breaks even
@@ -1861,24 +1933,53 @@ int mi_osqp_debug_trace_kkt_solve(mi_osqp_batch *h, int32_t which, const double 
 
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
+// iterations per segment of advance_kernel: the gcd of the periods at which a solve looks at itself
+static int segment_length(const Settings &S) {
+  int L = (int)S.max_iter;
+  if (S.check_termination > 0) L = gcd_i(L, (int)S.check_termination);
+  if (S.adaptive_rho && S.adaptive_rho_interval > 0) L = gcd_i(L, (int)S.adaptive_rho_interval);
+  return std::max(1, L);
+}
+// the pinned images advance_kernel publishes flags / scalars in, its tile counter and completion word
+static int ensure_advance_buffers(mi_osqp_batch *h) {
+  mi_osqp_batch::Cont &c = h->cont;
+  const size_t icnt = (size_t)h->ntiles * IS_COUNT * h->BT, dcnt = (size_t)h->ntiles * DS_COUNT * h->BT;
+  for (int k = 0; k < 2; k++) {
+    if (!c.h_is[k]) HIPCHK(hostpool::alloc((void **)&c.h_is[k], icnt * sizeof(int), &c.h_is_cap[k]));
+    if (!c.h_ds[k]) HIPCHK(hostpool::alloc((void **)&c.h_ds[k], dcnt * sizeof(double), &c.h_ds_cap[k]));
+  }
+  int rc;
+  if (!c.counter.p) { if ((rc = c.counter.alloc(4)) || (rc = c.counter.zero(h->stream))) return rc; }
+  if (!c.h_done) { HIPCHK(hostpool::alloc((void **)&c.h_done, 64, &c.h_done_cap)); c.h_done[0] = c.h_done[1] = 0; }
+  return MI_OSQP_OK;
+}
+// wait for the completion word of launch `seq` (no runtime call in the way); fallback: the stream
+static int wait_launch_over(mi_osqp_batch *h, unsigned seq) {
+  mi_osqp_batch::Cont &c = h->cont;
+  auto over = [&]() { return __atomic_load_n(c.h_done, __ATOMIC_ACQUIRE) == seq; };
+  const double t0 = now_s();
+  for (int spin = 0; !over(); spin++) {
+    if (spin < 20000) { __builtin_ia32_pause(); continue; }
+    struct timespec ts{0, 20000};
+    nanosleep(&ts, nullptr);
+    if ((spin & 1023) == 0 && now_s() - t0 > 5.0) { HIPCHK(hipStreamSynchronize(h->stream)); if (!over()) { g_last_error = "advance launch ended without reporting"; return MI_OSQP_ERR_DEVICE; } }
+  }
+  return MI_OSQP_OK;
+}
+
 static int cont_enter(mi_osqp_batch *h) {
   mi_osqp_batch::Cont &c = h->cont;
   if (c.on) return MI_OSQP_OK;
   if (h->global_xs || h->mw_groups > 0) { g_last_error = "continuous batching serves LDS-resident QPs (a large single QP has no batch to be continuous in)"; return MI_OSQP_ERR_INVALID_DATA; }
   const Analysis &an = (*h->anp);
   const int B = h->B, n = an.n, m = an.m, BT = h->BT, nslots = h->ntiles * BT;
-  const Settings &S = h->st;
-  int L = (int)S.max_iter;
-  if (S.check_termination > 0) L = gcd_i(L, (int)S.check_termination);
-  if (S.adaptive_rho && S.adaptive_rho_interval > 0) L = gcd_i(L, (int)S.adaptive_rho_interval);
-  c.L = std::max(1, L);
+  c.L = segment_length(h->st);
   c.running.assign((size_t)B, 0); c.clear_rho.assign((size_t)B, 0); c.epoch.assign((size_t)B, 0);
   c.info.assign((size_t)B, mi_osqp_info{});
   c.n_running = 0; c.adv_seq = c.polled_seq = 0; c.launch_seq = 0;
-  const size_t icnt = (size_t)h->ntiles * IS_COUNT * BT, dcnt = (size_t)h->ntiles * DS_COUNT * BT;
+  const size_t icnt = (size_t)h->ntiles * IS_COUNT * BT;
+  { const int rc0 = ensure_advance_buffers(h); if (rc0) return rc0; }
   for (int k = 0; k < 2; k++) {
-    if (!c.h_is[k]) HIPCHK(hostpool::alloc((void **)&c.h_is[k], icnt * sizeof(int), &c.h_is_cap[k]));
-    if (!c.h_ds[k]) HIPCHK(hostpool::alloc((void **)&c.h_ds[k], dcnt * sizeof(double), &c.h_ds_cap[k]));
     if (!c.ev[k]) HIPCHK(hipEventCreateWithFlags(&c.ev[k], hipEventDisableTiming));
     c.seq_of[k] = 0;
   }
@@ -1906,8 +2007,7 @@ static int cont_enter(mi_osqp_batch *h) {
     else c.ustream = h->stream;
     HIPCHK(hipEventCreateWithFlags(&c.ev_adv, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c.ev_u, hipEventDisableTiming));
-    if ((rc = c.rz_scratch.alloc((size_t)B * (n + m) + 1)) || (rc = c.counter.alloc(4))) return rc;
-    HIPCHK(hostpool::alloc((void **)&c.h_done, 64, &c.h_done_cap));
+    if ((rc = c.rz_scratch.alloc((size_t)B * (n + m) + 1))) return rc;
   }
   if ((rc = c.counter.zero(h->stream))) return rc;
   c.h_done[0] = c.h_done[1] = 0; c.last_active = 0;

@@ -180,3 +180,25 @@ def test_failure_isolation_and_errors_in_continuous_mode():
         _same(info[b], s.primal_some([b])[0], iref[b], ref.primal()[b])
     with pytest.raises(M.MiOsqpError):
         s.solve_begin_some([B])
+
+
+def test_blocking_solve_through_the_advance_kernel_is_bitwise_the_segment_loop(monkeypatch):
+    """MI_OSQP_ADVANCE_SOLVE=1 (opt-in): a batch of no more tiles than CUs solved by advance_kernel launches - every QP runs
+    to its end or to its next rho update inside one launch, the host only refactors the paused QPs - instead of two launches
+    and a synchronisation per segment.  Same results bit for bit, also when a QP runs into max_iter on a rho-update iteration
+    (it finishes AND is refactored: the warm re-solve continues from that factor)."""
+    B = 9
+    pr = PR.random_box_qp(B, n=96, mg=64, nnz_per_row=6)
+    for kw in ({}, dict(max_iter=100, check_termination=0), dict(max_iter=50, check_termination=30, eps_abs=1e-9, eps_rel=1e-9)):
+        ref = _make(pr, **kw)
+        i1, x1 = ref.solve(), ref.primal().copy()
+        i2, x2 = ref.solve(), ref.primal().copy()
+        monkeypatch.setenv("MI_OSQP_ADVANCE_SOLVE", "1")
+        s = _make(pr, **kw)
+        j1, y1 = s.solve(), s.primal().copy()
+        j2, y2 = s.solve(), s.primal().copy()
+        monkeypatch.delenv("MI_OSQP_ADVANCE_SOLVE")
+        for b in range(B):
+            _same(j1[b], y1[b], i1[b], x1[b])
+            _same(j2[b], y2[b], i2[b], x2[b])
+        assert s.last_solve_stats()["launches"] <= ref.last_solve_stats()["launches"]
