@@ -118,6 +118,7 @@ struct TailArgs {
 hipError_t launch_tail(const TailArgs &a, int nwork, size_t lds_asm, size_t lds, hipStream_t st);
 hipError_t launch_factor(const FactorArgs &a, int BT, int tiles, int threads, hipStream_t st);
 size_t factor_lds_bytes(int BT, int threads);
+bool factor_fits_lds(const FactorArgs &a, int threads);      // the LDS-resident form of factor_kernel<1> applies (one QP per workgroup, no group sharing)
 
 int max_coresident_groups(int threads, size_t lds, int n_cus);
 int max_coresident_factor_groups(int threads, int n_cus);

@@ -1061,6 +1061,9 @@ static int device_refactor_slots(mi_osqp_batch *h, std::vector<int> work, std::v
   // Short work lists (the rho updates of the last few QPs of a batch, a strong-scaling shard, a handle with one QP): the
   // block tasks of a QP are shared by several workgroups with barriers of the group between the phases of a level
   // (3 x levels x ~6 us): one QP of config 5 (ms): 1: 275, 8: 45, 16: 28, 32: 19, 64: 15, 128: 14
+  // (measured in round 3: the LDS-resident single-workgroup form of factor_kernel does NOT beat the group of workgroups on a
+  //  lone QP - 0.88 against 0.43 ms at config 2: a lone QP's levels hold hundreds of block tasks, the kernel is short of
+  //  waves, not of memory latency - so short lists keep their groups and the LDS form serves one-workgroup-per-QP launches)
   if (kbt == 1 && h->mw_bar.p && (*h->anp).N >= 1000) {
     const char *eg = getenv("MI_OSQP_FACTOR_GROUPS");
     const int cap = h->B == 1 ? std::max(4, std::min(64, (*h->anp).N / 600)) : 8;
