@@ -237,6 +237,15 @@ __device__ __forceinline__ void reduce_write(double (&acc)[BT], uint32_t lt, uin
 // per iteration at config 5 either way; that mode is bound by the global gathers / read-modify-writes of the solve vector
 // and the full drains at its phase barriers, not by the value stream)
 #define MI_PFV_OF(BT, GX) MI_PFV
+// 16 waves per tile = a tile that has its CU to itself (no more tiles than CUs: lone QPs, GOMP batches of <= 256, the QPs
+// still iterating in a continuous batch): the factor streams come from L2 after the first iteration and every sweep is a
+// chain of phases with about one step per wave, so what counts is how fast a ring starts up after it was emptied - measured
+// in round 3 (scripts/tail_latency_probe.py, us per iteration, config 2 / 256 x 7 DOF x 100 waypoints): ring of 18: 30.1 /
+// 47.3, 15: 27.8 / 45.0, 9: 23.9 / 41.4, 6: 22.3 / 39.8, 3: 21.7 / 42.6.
+#ifndef MI_PFV_LAT
+#define MI_PFV_LAT 6
+#endif
+#define MI_PFV_NT(NT, GX) (((NT) > 512 && !(GX)) ? MI_PFV_LAT : MI_PFV)
 template <int BT, int PF>
 struct Ring { double v[PF][BT]; uint32_t gi[PF]; uint32_t gr[PF]; uint32_t desc; };     // gr: target rows of the wide index words (unused otherwise)
 // The value streams of a tile: ONE stream per QP ([slot][step][64] doubles, 8 B per lane and load) plus the shared
@@ -901,7 +910,7 @@ __device__ __forceinline__ void iterate_body(const KernelArgs &a, double *smem, 
   for (int iter = 1; iter <= n_iter; iter++) {
     const bool do_info = a.info_at_end && iter == n_iter;     // delta_x / delta_y are only needed by check_kernel
     // ---- E7
-    kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
+    kkt_solve_lds<BT, MI_PFV_NT(NT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
     // ---- E8-E10 fused with E6 of the next iteration (run_tri ends with a barrier): every thread replaces the
     // solution entry it has just consumed by the next right-hand side entry - same position, no other reader
     // (global-vector mode: one workgroup walks 4 x 10^5 entries, each a dependent pinv -> xs gather: U entries per thread
@@ -1484,7 +1493,7 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
       }
       if (tid == 0) st_sc1(xs + 2 * (size_t)sh, 0.0);
       wg_or_grid_barrier(mw);
-      kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
+      kkt_solve_lds<BT, MI_PFV_NT(NT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
       for (int i = tid; i < N; i += nthr) { const uint32_t pe = a.pinv[i]; sol[i] = ld_sc1(xs + df_bloc(pe, a.rflag[pe], sh)); }
     }
     return;
@@ -1494,7 +1503,7 @@ __global__ __launch_bounds__(NT) void kkt_solve_kernel(KernelArgs a, const doubl
     for (int i = tid; i < N; i += nthr) xs[(size_t)a.pinv[i] * BT + bb] = q < a.B ? rhs[(size_t)q * N + i] : 0.0;
   }
   __syncthreads();
-  kkt_solve_lds<BT, MI_PFV_OF(BT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
+  kkt_solve_lds<BT, MI_PFV_NT(NT, GX), GX, WIDE>(a, p, xs, tid, nthr, wave, nw, lane, mw);
   for (int bb = 0; bb < BT; bb++) {
     const int q = tile * BT + bb;
     if (q < a.B) for (int i = tid; i < N; i += nthr) sol[(size_t)q * N + i] = xs[(size_t)a.pinv[i] * BT + bb];
