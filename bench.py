@@ -361,7 +361,7 @@ def obstacle_scene_entry(with_cpu):
     if not os.path.exists(exe):
         return {"config": "GOMP obstacle scene, continuous driver", "error": "osqp-solver_amd/gomp_parity_test not built"}
     r = subprocess.run([exe, "contbench", "256", "100", "8" if with_cpu else "0"], capture_output=True, text=True, timeout=300)
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CONTBENCH trajectories")]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CONTBENCH device_assembly")]
     if r.returncode != 0 or not line:
         return {"config": "GOMP obstacle scene, continuous driver", "error": (r.stdout + r.stderr)[-500:]}
     tok = line[0].split()

@@ -245,6 +245,41 @@ int mi_osqp_batch_get_dual_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *
 int mi_osqp_batch_get_info_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, mi_osqp_info *info /*[n_ids]*/);
 int64_t mi_osqp_batch_running(mi_osqp_batch *h);      /* QPs whose solve has been begun and not been reported by poll() */
 
+/* ------------------------------------------- GOMP re-linearisation on the device
+ * The step before and the step after the solver path in the reference's SQP loop - the re-linearised 3-D / obstacle rows
+ * of the constraint matrix (ConstraintBuilder::withObstacles, [REF] src/constraints/constraint-builder.h:90-136) and the
+ * feasibility check that ends the loop (GOMPSolver::isSolutionOK, [REF] src/gomp-solver.h:141-199) - for collision balls
+ * whose kinematics are built-in models (the reference binds arbitrary host callbacks, [REF] src/utils.h:21-22,33-42; those
+ * stay on the host path of include/mi_osqp/gomp.hpp).  A scene belongs to one batch handle whose QPs have the reference's
+ * GOMP row layout ([REF] constraint-builder.h:34-44) for `dims` joints and `waypoints` waypoints; it keeps the raw
+ * constraint data of every QP on the device, so an SQP step moves one trajectory to the device and one flag back. */
+typedef enum {
+  MI_GOMP_MODEL_UR5E_FLANGE = 1,   /* UR5e (published DH parameters, include/mi_osqp/ur5e_kinematics.hpp): tool flange */
+  MI_GOMP_MODEL_UR5E_WRIST3 = 2,   /*   wrist-3 joint (forward_kinematics_6_back)                                      */
+  MI_GOMP_MODEL_UR5E_ELBOW = 3,    /*   elbow joint                                                                    */
+  MI_GOMP_MODEL_YAW_2LINK = 4,     /* 3 joints: yaw, shoulder, elbow; param = {link 1, link 2, base height}            */
+  MI_GOMP_MODEL_TABLE = 5          /* 3 joints: p = (q0, q1, q2), constant 3 x 3 Jacobian in param (known-answer tests) */
+} mi_gomp_model;
+typedef struct { int32_t model; int32_t is_gripper; double radius; double param[12]; } mi_gomp_ball;   /* = RobotBall */
+typedef struct { double dir[2]; double point[3]; int32_t below; int32_t reserved; } mi_gomp_line;       /* = HorizontalLine */
+typedef struct mi_gomp_scene mi_gomp_scene;
+/* con_lo / con_hi: the work-space box of the gripper balls (con_3d), +-1e30 or NULL = none */
+int mi_gomp_scene_create(mi_gomp_scene **out, mi_osqp_batch *h, int64_t dims, int64_t waypoints,
+                         int64_t n_balls, const mi_gomp_ball *balls, int64_t n_lines, const mi_gomp_line *lines,
+                         const double *con_lo, const double *con_hi);
+void mi_gomp_scene_free(mi_gomp_scene *sc);
+/* While a scene exists, mi_osqp_batch_reinit_some / _update_A_bounds_some of its handle also keep the QPs' raw constraint
+ * data (as ConstraintBuilder::build() produced it) in the scene, so nothing extra is needed when a trajectory enters the
+ * handle.  set_rows writes that copy directly ([n_ids][nnzA], [n_ids][m]); get_rows reads it back (tests). */
+int mi_gomp_scene_set_rows(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *A_val, const double *l, const double *u);
+int mi_gomp_scene_get_rows(mi_gomp_scene *sc, int64_t id, double *A_val, double *l, double *u);       /* (tests) */
+/* withObstacles(con_3d, x) on the kept rows of the listed QPs (x: [n_ids][n] trajectories, host); ok_out[j] = isSolutionOK(x_j) */
+int mi_gomp_assemble_some(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *x, int32_t *ok_out);
+/* one SQP step of the listed, finished QPs ([REF] src/gomp-solver.h:79-87): ok_out[j] = isSolutionOK(x_j); the QPs whose
+ * trajectory is not acceptable are re-linearised around it and updated (QPSolver::update from the device-resident rows)
+ * and are ready for mi_osqp_batch_solve_begin_some */
+int mi_gomp_relinearise_some(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *x, int32_t *ok_out);
+
 /* ---------------------------------------------------------- multi-GPU batch
  * The batch is the shard axis across the GPUs of a node (the runs of a planner are independent,
  * [REF] src/gomp-solver.h:38-55): the B QPs are cut into n_devices contiguous blocks (the first B % n_devices one QP

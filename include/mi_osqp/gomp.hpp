@@ -78,6 +78,16 @@ struct RobotBall {
   JacobianFun jacobian;
   double radius;
   bool is_gripper;
+  // Not in the reference: when fk / jacobian are one of the kinematic models the library also has on the device
+  // (mi_gomp_model in mi_osqp.h), naming it here lets the continuous planner re-linearise on the GPU (withBuiltin()).
+  int builtin_model = 0;
+  std::array<double, 12> builtin_param{};
+  RobotBall &withBuiltin(int model, std::initializer_list<double> param = {}) {
+    builtin_model = model;
+    size_t k = 0;
+    for (double v : param) if (k < builtin_param.size()) builtin_param[k++] = v;
+    return *this;
+  }
 };
 
 // n x n matrix with a on the diagonal and b on the +-diagonal_num diagonals for rows >= offset
@@ -140,6 +150,9 @@ class HorizontalLine {
     auto a = getDistanceVecXY(P), b = getDistanceVecXY(Q);
     return a[0] * b[0] + a[1] * b[1] < 0;
   }
+  // (for the device twin of this class, mi_gomp_line)
+  std::array<double, 2> directionXY() const { return {D_[0], D_[1]}; }
+  const Point &point() const { return A_; }
   bool isClose(const Point &P, const RobotBall &b) const { return getDistanceXY(P) < b.radius; }
   bool hasCollision(int waypoint, const QPVector &xyz, const RobotBall &b) const {
     const int waypoints = (int)xyz.size() / 3;
@@ -696,6 +709,10 @@ class ContinuousGOMPSolver {
   std::vector<int> segments_run, qp_solves, qp_updates;
   std::atomic<long> advances{0};       // advance() calls of all stages
   std::atomic<int> solver_reuses{0};   // stages whose solver was kept from the previous run()
+  // Re-linearise on the device (mi_gomp_scene: FK / Jacobians of built-in kinematic models, row assembly, feasibility check,
+  // update from device-resident rows) instead of on the stage's host thread.  Needs every ball to name its model
+  // (RobotBall::withBuiltin); the trajectories then agree with the host path to round-off (device sin / cos), not bitwise.
+  bool device_assembly = false;
   int pipeline_depth = 1;              // 2: a stage enqueues its next advance before it looks at the previous one's results
   int segments_per_advance = 4;        // a launch runs on until a QP of the stage finishes, at most that many segments
   // per stage: {waypoints, advances, seconds admitting, waiting for the device, processing finished QPs, idle}
@@ -727,6 +744,8 @@ class ContinuousGOMPSolver {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<size_t> inbox;                       // trajectories that have reached this horizon
+    mi_gomp_scene *scene = nullptr;                 // device-side re-linearisation of this stage's solver (device_assembly)
+    ~Stage() { if (scene) mi_gomp_scene_free(scene); }
     bool first_admission = true;
     // where the stage thread's time went in the last run(): preparing + admitting arrivals, waiting for the device in
     // poll(), checking / re-linearising / updating finished QPs, waiting for arrivals
@@ -799,23 +818,81 @@ class ContinuousGOMPSolver {
       T.seg_solution = T.warm; T.seg_code = ExitCode::kUnknown; T.sqp_it = 0;
     };
     parallelFor(arrivals.size(), prepare);
-    if (st.qp && !st.qp->compatible((long long)B, traj_[arrivals[0]].cons, P)) st.qp.reset();
+    if (st.qp && !st.qp->compatible((long long)B, traj_[arrivals[0]].cons, P)) { if (st.scene) { mi_gomp_scene_free(st.scene); st.scene = nullptr; } st.qp.reset(); }
     if (st.qp) { if (st.first_admission) ++solver_reuses; }                       // (kept from the previous run(): every slot is re-initialised on arrival)
     else st.qp = std::make_unique<ContSolverT>((long long)B, traj_[arrivals[0]].cons, P, verbose);
     st.first_admission = false;
+    if (useDevice() && !st.scene) makeScene(st);
     std::vector<long long> ids;
     std::vector<const QPConstraints *> cs;
     std::vector<const QPVector *> xs;
     for (size_t b : arrivals) { ids.push_back((long long)b); cs.push_back(&traj_[b].cons); xs.push_back(&traj_[b].warm); }
     st.qp->reinit(ids, cs);
+    // (with a device scene the library keeps these rows on the device as well: the re-linearisations to come start from them)
     st.qp->setWarmStart(ids, xs);
     st.qp->begin(ids);
+  }
+
+  bool useDevice() const {
+    if (!device_assembly) return false;
+    for (const RobotBall &b : mappers) if (!b.builtin_model) return false;
+    return true;
+  }
+  void makeScene(Stage &st) {
+    std::vector<mi_gomp_ball> balls;
+    for (const RobotBall &b : mappers) {
+      mi_gomp_ball g{};
+      g.model = b.builtin_model; g.is_gripper = b.is_gripper ? 1 : 0; g.radius = b.radius;
+      for (size_t k = 0; k < 12; ++k) g.param[k] = b.builtin_param[k];
+      balls.push_back(g);
+    }
+    std::vector<mi_gomp_line> lines;
+    for (const HorizontalLine &l : obstacles) {
+      mi_gomp_line g{};
+      g.dir[0] = l.directionXY()[0]; g.dir[1] = l.directionXY()[1];
+      for (int k = 0; k < 3; ++k) g.point[k] = l.point()[k];
+      g.below = l.bypassFromBelow() ? 1 : 0;
+      lines.push_back(g);
+    }
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = con_3d.first ? (*con_3d.first)[k] : -INF; hi[k] = con_3d.second ? (*con_3d.second)[k] : INF; }
+    const int rc = mi_gomp_scene_create(&st.scene, st.qp->handle(), (int64_t)N_DIM, (int64_t)st.waypoints, (int64_t)balls.size(), balls.data(),
+                                        (int64_t)lines.size(), lines.data(), lo, hi);
+    if (rc != MI_OSQP_OK) std::fprintf(stderr, "ContinuousGOMPSolver: device scene failed (%s): falling back to the host path\n", mi_osqp_error_name(rc));
   }
 
   void process(int s, Stage &st, const std::vector<long long> &done, size_t B) {
     std::vector<long long> again;
     std::vector<const QPConstraints *> cs;
     std::vector<size_t> leaving;
+    if (st.scene) {
+      // the SQP step on the device: feasibility check, re-linearisation and update of the QPs whose trajectory is not accepted
+      std::vector<long long> opt;
+      std::vector<QPVector> sol;
+      std::vector<double> xs;
+      for (long long id : done) {
+        const size_t b = (size_t)id;
+        Traj &T = traj_[b];
+        auto [exit_code, solution] = st.qp->result(id);
+        ++qp_solves[b];
+        if (exit_code != ExitCode::kOptimal) { T.seg_solution = std::move(solution); leaving.push_back(b); continue; }
+        opt.push_back(id); xs.insert(xs.end(), solution.begin(), solution.end()); sol.push_back(std::move(solution));
+      }
+      std::vector<int32_t> ok(opt.size(), 0);
+      if (!opt.empty()) {
+        const int rc = mi_gomp_relinearise_some(st.scene, (int64_t)opt.size(), reinterpret_cast<const int64_t *>(opt.data()), xs.data(), ok.data());
+        if (rc != MI_OSQP_OK) { std::fprintf(stderr, "ContinuousGOMPSolver: device re-linearisation failed: %s (%s)\n", mi_osqp_error_name(rc), mi_osqp_last_error()); failed_ = true; wakeAll(); return; }
+      }
+      for (size_t k = 0; k < opt.size(); ++k) {
+        const size_t b = (size_t)opt[k];
+        Traj &T = traj_[b];
+        if (ok[k]) { T.seg_solution = std::move(sol[k]); T.seg_code = ExitCode::kOptimal; leaving.push_back(b); continue; }
+        ++qp_updates[b];
+        if (++T.sqp_it < MAX_ITERATIONS) again.push_back(opt[k]); else leaving.push_back(b);
+      }
+      if (!again.empty()) st.qp->begin(again);
+      again.clear();
+    } else
     for (long long id : done) {
       const size_t b = (size_t)id;
       Traj &T = traj_[b];

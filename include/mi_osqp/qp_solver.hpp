@@ -369,6 +369,7 @@ class ContinuousQPSolver {
   long long size() const { return K_; }
   int setup_status() const { return status_; }
   const mi_osqp_info &last_info() const { return last_; }
+  mi_osqp_batch *handle() const { return h_; }          // for the device-side companions of the solver (mi_gomp_scene)
 
  private:
   void newData(const std::vector<long long> &ids, const std::vector<const QPConstraints *> &cs, bool fresh) {

@@ -165,6 +165,7 @@ hipError_t launch_deinterleave(const double *src, double *dst, int nq, int len, 
 struct RuizArgs {
   int n, m, nnzP, nnzA, B, BT, iters;
   const int *ids;                            // non-null: workgroup j serves QP ids[j] (B = length of the list); rawA / rawl / rawu / pa_out are indexed by j
+  int raw_by_qp;                             // 1: rawA / rawl / rawu are indexed by the QP's number instead (arrays kept per QP on the device)
   int fresh;                                 // 1: equilibrate from the raw P and q kept since setup (rawP / rawq, [QP][nnzP], [QP][n]) instead of
   const double *rawP, *rawq;                 //    unscaling the values in force: bit for bit what setup computes for (P, q, rawA, rawl, rawu)
   const int32_t *Prow, *Pcol, *Arow, *Acol;   // per entry of triu(P) / A: row, column
@@ -188,7 +189,25 @@ hipError_t launch_worklist(const int *iscal, int *work, int nslots, int BT, hipS
 hipError_t launch_resume_flagged(const KernelArgs &a, int nslots, int BT, hipStream_t st);
 // dst[slot] = src[slot] for the listed slots: [slot][per] streams / [tile][len][BT] interleaved arrays
 hipError_t launch_copy_slot_streams(double *dst, const double *src, const int *slots, int nslots, size_t per, hipStream_t st);
+hipError_t launch_keep_rows(double *dst, const double *src, const int *ids, int n_ids, int len, hipStream_t st);
 hipError_t launch_copy_slot_rows(double *dst, const double *src, const int *slots, int nslots, int len, int BT, hipStream_t st);
+// ---- GOMP re-linearisation on the device (solver.hip "gomp scene"): ConstraintBuilder::withObstacles + isSolutionOK for
+// built-in kinematic models ([REF] src/constraints/constraint-builder.h:90-136, src/gomp-solver.h:141-199)
+enum { MI_GM_UR5E_FLANGE = 1, MI_GM_UR5E_WRIST3 = 2, MI_GM_UR5E_ELBOW = 3, MI_GM_YAW_2LINK = 4, MI_GM_TABLE = 5 };
+struct GompBallDev { int model, is_gripper; double radius; double param[12]; };
+struct GompLineDev { double D[3], A[3]; int below, pad; };
+struct GompArgs {
+  int dims, W, n_balls, n_lines, n, m, nnzA, n_ids, row0, write_rows;
+  const int *ids;                // the listed QPs
+  const GompBallDev *balls;
+  const GompLineDev *lines;
+  double con_lo[3], con_hi[3];   // work-space box of the gripper balls (+-1e30 = none)
+  const int *aidx;               // [3-D row][dims]: position of that row's entry in column nthPos(w) + j of A's value array
+  const double *traj;            // [n_ids][n]: the trajectories to linearise around (row = position in the list)
+  double *A, *l, *u;             // the kept raw constraint data, [B][nnzA] / [B][m] by QP: the 3-D rows are rewritten
+  int *ok;                       // [n_ids]: isSolutionOK of the trajectory
+};
+hipError_t launch_gomp_relinearise(const GompArgs &g, hipStream_t st);
 hipError_t launch_gather_status(const int *iscal, int32_t *status, int32_t *iters, int B, int BT, hipStream_t st);
 hipError_t launch_fail_slots(const KernelArgs &a, const int *slots, int nfail, int BT, int iter, hipStream_t st);
 hipError_t launch_bounds(const double *gl, const double *gu, double *l, double *u, const double *Esc,

@@ -2621,6 +2621,18 @@ hipError_t launch_copy_slot_rows(double *dst, const double *src, const int *slot
   hipLaunchKernelGGL(copy_slot_rows_kernel, dim3(gx, nslots), dim3(256), 0, st, dst, src, slots, len, BT);
   return hipGetLastError();
 }
+// rows that arrived list-major (row j of src belongs to QP ids[j]) kept QP-major: dst[ids[j]][:] = src[j][:]
+__global__ void keep_rows_kernel(double *__restrict__ dst, const double *__restrict__ src, const int *__restrict__ ids, int len) {
+  const int j = blockIdx.y;
+  const size_t to = (size_t)ids[j] * len, from = (size_t)j * len;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) dst[to + i] = src[from + i];
+}
+hipError_t launch_keep_rows(double *dst, const double *src, const int *ids, int n_ids, int len, hipStream_t st) {
+  if (!n_ids || !len) return hipSuccess;
+  const unsigned gx = (unsigned)std::min(16, (len + 255) / 256);
+  hipLaunchKernelGGL(keep_rows_kernel, dim3(gx, n_ids), dim3(256), 0, st, dst, src, ids, len);
+  return hipGetLastError();
+}
 // bounds update on device: l,u <- E .* clip(l,u); flags a constraint-type change
 __global__ void bounds_kernel(const double *__restrict__ gl, const double *__restrict__ gu, double *l, double *u,
                               const double *__restrict__ Esc, const double *__restrict__ rho_vec,
@@ -2659,7 +2671,8 @@ __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
   const size_t tile = (size_t)(qp / a.BT), b = (size_t)(qp % a.BT), BT = (size_t)a.BT;
   auto H = [&](size_t len, size_t i) { return (tile * len + i) * BT + b; };
   double *dn = a.dn + (size_t)qp * n, *en = a.en + (size_t)qp * m;
-  const double *rawA = a.rawA + (size_t)jq * nnzA;
+  const int jr = a.raw_by_qp ? qp : jq;          // row of the raw A / bounds arguments
+  const double *rawA = a.rawA + (size_t)jr * nnzA;
   // (dn / en are updated by atomics, which execute in L2: they are read and reset past the CU's L1 as well)
   auto ld = [](const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto st0 = [](double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -2680,7 +2693,7 @@ __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
   for (int k = tid; k < nnzA; k += nthr) a.pa_val[H(pa_len, nnzP + k)] = rawA[k];
   for (int i = tid; i < m; i += nthr) {
     double lo, up;
-    if (a.rawl) { lo = fmax(a.rawl[(size_t)jq * m + i], -MI_INFTY); up = fmin(a.rawu[(size_t)jq * m + i], MI_INFTY); }
+    if (a.rawl) { lo = fmax(a.rawl[(size_t)jr * m + i], -MI_INFTY); up = fmin(a.rawu[(size_t)jr * m + i], MI_INFTY); }
     else { const double ei = a.Esc_inv[H(m, i)]; lo = a.l[H(m, i)] * ei; up = a.u[H(m, i)] * ei; }
     a.l[H(m, i)] = lo; a.u[H(m, i)] = up;
   }
@@ -2760,6 +2773,152 @@ __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
 hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
   hipLaunchKernelGGL(ruiz_kernel, dim3(a.B), dim3(512), 0, st, a);
+  return hipGetLastError();
+}
+
+// ---- GOMP re-linearisation on the device -------------------------------------------------------------------------------
+// What ConstraintBuilder::withObstacles ([REF] src/constraints/constraint-builder.h:90-136) and GOMPSolver::isSolutionOK
+// ([REF] src/gomp-solver.h:141-199) compute for one trajectory, for balls whose kinematics are built-in models: per ball and
+// waypoint the position p = fk(q_w) and the 3 x D position Jacobian J(q_w); gripper balls get three rows J_axis q with
+// bounds con - p_axis + J_axis q_w -+ radius, every (ball, line) pair one Z row - a bound when the ball collides with the
+// line's vertical plane at that waypoint (HorizontalLine::hasCollision: close to it, or on opposite sides of it from a
+// neighbouring waypoint), a dummy row otherwise - and the trajectory is accepted when every ball respects the box and is above
+// (below) the lines it collides with.  One workgroup per trajectory, one thread per (ball, waypoint).
+__device__ __forceinline__ void ur5e_point(const double *q, int frame, double *p, double *J /* 3 x 6 row-major */) {
+  const double a[6] = {0.0, -0.425, -0.3922, 0.0, 0.0, 0.0}, d[6] = {0.1625, 0.0, 0.0, 0.1333, 0.0997, 0.0996};
+  const double alpha[6] = {1.5707963267948966, 0.0, 0.0, 1.5707963267948966, -1.5707963267948966, 0.0};
+  double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, o[3] = {0, 0, 0};
+  double oj[7][3], zj[6][3];
+  for (int i = 0; i < 6; i++) {
+    for (int r = 0; r < 3; r++) { oj[i][r] = o[r]; zj[i][r] = R[r][2]; }
+    const double ct = cos(q[i]), st = sin(q[i]), ca = cos(alpha[i]), sa = sin(alpha[i]);
+    const double T[3][4] = {{ct, -st * ca, st * sa, a[i] * ct}, {st, ct * ca, -ct * sa, a[i] * st}, {0.0, sa, ca, d[i]}};
+    double G[3][3], g[3];
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) G[r][c] = R[r][0] * T[0][c] + R[r][1] * T[1][c] + R[r][2] * T[2][c];
+      g[r] = R[r][0] * T[0][3] + R[r][1] * T[1][3] + R[r][2] * T[2][3] + o[r];
+    }
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r][c] = G[r][c]; o[r] = g[r]; }
+  }
+  for (int r = 0; r < 3; r++) oj[6][r] = o[r];
+  for (int r = 0; r < 3; r++) p[r] = oj[frame][r];
+  for (int j = 0; j < 6; j++) {
+    double col[3] = {0, 0, 0};
+    if (j < frame) {
+      const double r[3] = {p[0] - oj[j][0], p[1] - oj[j][1], p[2] - oj[j][2]};
+      col[0] = zj[j][1] * r[2] - zj[j][2] * r[1];
+      col[1] = zj[j][2] * r[0] - zj[j][0] * r[2];
+      col[2] = zj[j][0] * r[1] - zj[j][1] * r[0];
+    }
+    for (int ax = 0; ax < 3; ax++) J[ax * 6 + j] = col[ax];
+  }
+}
+#define MI_GOMP_MAXD 8
+__device__ __forceinline__ void gomp_fk_jac(const GompBallDev &b, int D, const double *q, double *p, double *J) {
+  for (int k = 0; k < 3 * D; k++) J[k] = 0.0;
+  if (b.model == MI_GM_UR5E_FLANGE || b.model == MI_GM_UR5E_WRIST3 || b.model == MI_GM_UR5E_ELBOW) {
+    double J6[18];
+    ur5e_point(q, b.model == MI_GM_UR5E_FLANGE ? 6 : (b.model == MI_GM_UR5E_WRIST3 ? 5 : 2), p, J6);
+    for (int ax = 0; ax < 3; ax++) for (int j = 0; j < 6 && j < D; j++) J[ax * D + j] = J6[ax * 6 + j];
+  } else if (b.model == MI_GM_YAW_2LINK) {         // yaw q0, shoulder q1, elbow q2; links param[0], param[1], base height param[2]
+    const double L1 = b.param[0], L2 = b.param[1], Z0 = b.param[2];
+    const double c0 = cos(q[0]), s0 = sin(q[0]);
+    const double r = L1 * cos(q[1]) + L2 * cos(q[1] + q[2]);
+    const double dr1 = -L1 * sin(q[1]) - L2 * sin(q[1] + q[2]), dr2 = -L2 * sin(q[1] + q[2]);
+    p[0] = r * c0; p[1] = r * s0; p[2] = Z0 + L1 * sin(q[1]) + L2 * sin(q[1] + q[2]);
+    J[0 * D + 0] = -r * s0; J[0 * D + 1] = c0 * dr1; J[0 * D + 2] = c0 * dr2;
+    J[1 * D + 0] = r * c0;  J[1 * D + 1] = s0 * dr1; J[1 * D + 2] = s0 * dr2;
+    J[2 * D + 0] = 0.0;     J[2 * D + 1] = L1 * cos(q[1]) + L2 * cos(q[1] + q[2]); J[2 * D + 2] = L2 * cos(q[1] + q[2]);
+  } else {                                         // MI_GM_TABLE (tests): p = (q0, q1, q2), J = the 3 x 3 table in param (D = 3)
+    p[0] = q[0]; p[1] = q[1]; p[2] = q[2];
+    for (int ax = 0; ax < 3; ax++) for (int j = 0; j < 3 && j < D; j++) J[ax * D + j] = b.param[ax * 3 + j];
+  }
+}
+__device__ __forceinline__ void gomp_dist_xy(const GompLineDev &ln, const double *P, double *dxy) {       // HorizontalLine::getDistanceVecXY
+  double t = 0.0;
+  for (int k = 0; k < 3; k++) t += (P[k] - ln.A[k]) * ln.D[k];
+  dxy[0] = ln.A[0] + t * ln.D[0] - P[0]; dxy[1] = ln.A[1] + t * ln.D[1] - P[1];
+}
+__global__ __launch_bounds__(256) void gomp_relinearise_kernel(GompArgs g) {
+  extern __shared__ double smem[];                 // xyz[n_balls][W][3]
+  __shared__ int s_ok;
+  const int jq = blockIdx.x, qp = g.ids[jq], tid = threadIdx.x;
+  const int D = g.dims, W = g.W, NB = g.n_balls, NL = g.n_lines;
+  const double *traj = g.traj + (size_t)jq * g.n;
+  if (tid == 0) s_ok = 1;
+  double p[3] = {0, 0, 0}, J[3 * MI_GOMP_MAXD], q[MI_GOMP_MAXD];
+  // (one (ball, waypoint) pair per thread; more pairs than threads: the loop below repeats per chunk, with the positions of
+  //  ALL pairs computed first - a waypoint's collision test looks at its neighbours)
+  for (int e = tid; e < NB * W; e += blockDim.x) {
+    const int w = e % W;
+    for (int j = 0; j < D; j++) q[j] = traj[(size_t)w * D + j];
+    gomp_fk_jac(g.balls[e / W], D, q, p, J);
+    for (int k = 0; k < 3; k++) smem[(size_t)e * 3 + k] = p[k];
+  }
+  __syncthreads();
+  int ok = 1;
+  // pass 0: the acceptance test of the whole trajectory; pass 1: the rows (write_rows 1: always, 2: only when not accepted)
+  for (int pass = 0; pass < 2; pass++) {
+  bool wr = false;
+  if (pass == 1) {
+    if (!ok) atomicAnd(&s_ok, 0);
+    __syncthreads();
+    wr = g.write_rows == 1 || (g.write_rows == 2 && !s_ok);
+    if (!wr) break;
+  }
+  for (int e = tid; e < NB * W; e += blockDim.x) {
+    const int bi = e / W, w = e % W;
+    const GompBallDev &ball = g.balls[bi];
+    for (int j = 0; j < D; j++) q[j] = traj[(size_t)w * D + j];
+    gomp_fk_jac(ball, D, q, p, J);
+    const double *xyz = smem + (size_t)bi * W * 3;
+    double Jq[3];
+    for (int ax = 0; ax < 3; ax++) { double sacc = 0.0; for (int j = 0; j < D; j++) sacc += J[ax * D + j] * q[j]; Jq[ax] = sacc; }
+    // this pair's first row: the balls before it (all their waypoints), then the waypoints before it of this ball
+    int row = g.row0;
+    for (int b2 = 0; b2 < bi; b2++) row += W * ((g.balls[b2].is_gripper ? 3 : 0) + NL);
+    row += w * ((ball.is_gripper ? 3 : 0) + NL);
+    auto put = [&](int r, int axis, double low, double upp) {
+      if (!wr) return;
+      const int *ai = g.aidx + (size_t)(r - g.row0) * D;
+      for (int j = 0; j < D; j++) g.A[(size_t)qp * g.nnzA + ai[j]] = J[axis * D + j];
+      g.l[(size_t)qp * g.m + r] = low + ball.radius;
+      g.u[(size_t)qp * g.m + r] = upp - ball.radius;
+    };
+    if (ball.is_gripper) {
+      for (int ax = 0; ax < 3; ax++) {
+        const double lo = g.con_lo[ax] > -1e29 ? g.con_lo[ax] - p[ax] + Jq[ax] : -MI_INFTY;
+        const double up = g.con_hi[ax] < 1e29 ? g.con_hi[ax] - p[ax] + Jq[ax] : MI_INFTY;
+        put(row++, ax, lo, up);
+        const double clo = g.con_lo[ax] > -1e29 ? g.con_lo[ax] : -MI_INFTY, cup = g.con_hi[ax] < 1e29 ? g.con_hi[ax] : MI_INFTY;
+        if (!(clo - 1e-3 <= p[ax] - ball.radius && p[ax] + ball.radius <= cup + 1e-3)) ok = 0;
+      }
+    }
+    for (int li = 0; li < NL; li++) {
+      const GompLineDev &ln = g.lines[li];
+      double dp[2], dn[2];
+      gomp_dist_xy(ln, p, dp);
+      bool coll = hypot(dp[0], dp[1]) < ball.radius;                                         // isClose
+      if (!coll && w > 0) { gomp_dist_xy(ln, xyz + (size_t)(w - 1) * 3, dn); coll = dn[0] * dp[0] + dn[1] * dp[1] < 0; }
+      if (!coll && w + 1 < W) { gomp_dist_xy(ln, xyz + (size_t)(w + 1) * 3, dn); coll = dp[0] * dn[0] + dp[1] * dn[1] < 0; }
+      if (coll) {
+        const double bound = (p[2] + (ln.A[2] - p[2])) - p[2] + Jq[2];                      // line[p][Z] - p[Z] + J q, in the host's order of operations
+        if (ln.below) put(row++, 2, -MI_INFTY, bound); else put(row++, 2, bound, MI_INFTY);
+        const bool above = ln.below ? (p[2] - ln.A[2]) <= -ball.radius + 1e-3 : (p[2] - ln.A[2]) >= ball.radius - 1e-3;
+        if (!above) ok = 0;
+      } else put(row++, 2, -MI_INFTY, MI_INFTY);                                            // dummy row: keeps the pattern constant
+    }
+  }
+  }
+  if (tid == 0) g.ok[jq] = s_ok;
+}
+hipError_t launch_gomp_relinearise(const GompArgs &g, hipStream_t st) {
+  if (g.n_ids <= 0) return hipSuccess;
+  if (g.dims > MI_GOMP_MAXD) return hipErrorInvalidValue;
+  const size_t lds = (size_t)g.n_balls * g.W * 3 * sizeof(double);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&gomp_relinearise_kernel), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gomp_relinearise_kernel, dim3(g.n_ids), dim3(256), lds, st, g);
   return hipGetLastError();
 }
 

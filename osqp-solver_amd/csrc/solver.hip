@@ -354,6 +354,7 @@ struct mi_osqp_batch {
     hipEvent_t ev_adv = nullptr;             // behind the last advance launch (the refactorisation kernels wait for it)
     std::vector<int> epoch;                  // per QP: solves begun so far (what IS_EPOCH reads once the begin has run)
     DevBuf<double> rz_scratch;               // equilibration scratch of that stream (not the check kernels': they may be running)
+    double *keepA = nullptr, *keepl = nullptr, *keepu = nullptr;   // a mi_gomp_scene's QP-major copy of the raw rows: reinit / update keep it current
     DevBuf<unsigned> counter;                // tiles that have left the advance launch in flight
     unsigned *h_done = nullptr; size_t h_done_cap = 0;      // pinned: [0] sequence number of the last advance launch that is over, [1] tiles that iterated in it
     unsigned last_active = 0;                // tiles that iterated in the last launch polled
@@ -2140,27 +2141,38 @@ static int enqueue_refactor_list(mi_osqp_batch *h, const int *d_work, int count)
 
 // new A values + bounds of the listed QPs: equilibration on the device (fresh: from the raw P and q of setup; else unscale
 // with the scaling in force first, as QPSolver::update does), check streams, refactorisation, snapshot.  All enqueued.
-static int cont_new_data(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *Av, const double *l, const double *u, bool fresh) {
+// (dA / dl / du non-null: the new data is on the device already, [B][nnzA] / [B][m] by QP number - the GOMP scene's kept rows)
+static int cont_new_data(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, const double *Av, const double *l, const double *u, bool fresh,
+                         const double *dA = nullptr, const double *dl = nullptr, const double *du = nullptr) {
   const Analysis &an = (*h->anp);
   const int n = an.n, m = an.m, nnzP = an.Pp[n], nnzA = an.Ap[n], pa_len = nnzP + nnzA, nq = (int)n_ids;
   int rc;
-  for (size_t k = 0; k < (size_t)nq * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  if (!dA) for (size_t k = 0; k < (size_t)nq * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
   int *d_ids = nullptr;
   if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, nullptr))) return rc;
   const size_t cA = (size_t)nq * nnzA, cb = (size_t)nq * m, cpa = (size_t)nq * pa_len;
-  RingSpan in, out;
-  if ((rc = ring_take(h, (cA + 2 * cb) * sizeof(double), in)) || (rc = ring_take(h, std::max<size_t>(cpa, 1) * sizeof(double), out))) return rc;
+  RingSpan in{nullptr, nullptr}, out;
+  if (!dA && (rc = ring_take(h, (cA + 2 * cb) * sizeof(double), in))) return rc;
+  if ((rc = ring_take(h, std::max<size_t>(cpa, 1) * sizeof(double), out))) return rc;
   double *hin = (double *)in.host, *din = (double *)in.dev;
-  memcpy(hin, Av, cA * sizeof(double)); memcpy(hin + cA, l, cb * sizeof(double)); memcpy(hin + cA + cb, u, cb * sizeof(double));
-  if ((rc = ring_upload(h, in, (cA + 2 * cb) * sizeof(double)))) return rc;
+  if (!dA) {
+    memcpy(hin, Av, cA * sizeof(double)); memcpy(hin + cA, l, cb * sizeof(double)); memcpy(hin + cA + cb, u, cb * sizeof(double));
+    if ((rc = ring_upload(h, in, (cA + 2 * cb) * sizeof(double)))) return rc;
+  }
   hipStream_t us = h->cont.ustream;
+  if (!dA && h->cont.keepA) {
+    HIPCHK(launch_keep_rows(h->cont.keepA, din, d_ids, nq, nnzA, us));
+    HIPCHK(launch_keep_rows(h->cont.keepl, din + cA, d_ids, nq, m, us));
+    HIPCHK(launch_keep_rows(h->cont.keepu, din + cA + cb, d_ids, nq, m, us));
+  }
   KernelArgs ka = make_args(h);
   if (fresh) HIPCHK(launch_fresh_slots(ka, d_ids, nq, h->BT, h->st.rho, us));
   RuizArgs r{};
   r.n = n; r.m = m; r.nnzP = nnzP; r.nnzA = nnzA; r.B = nq; r.BT = h->BT; r.iters = (int)h->st.scaling;
   r.ids = d_ids; r.fresh = fresh ? 1 : 0; r.rawP = h->rawP.p; r.rawq = h->rawq.p;
   r.Prow = h->rz_prow.p; r.Pcol = h->rz_pcol.p; r.Arow = h->rz_arow.p; r.Acol = h->rz_acol.p;
-  r.rawA = din; r.rawl = din + cA; r.rawu = din + cA + cb;
+  if (dA) { r.rawA = dA; r.rawl = dl; r.rawu = du; r.raw_by_qp = 1; }
+  else { r.rawA = din; r.rawl = din + cA; r.rawu = din + cA + cb; }
   r.pa_val = h->pa_val.p; r.q = h->q.p; r.Dsc = h->Dsc.p; r.Dsc_inv = h->Dsc_inv.p; r.Esc = h->Esc.p; r.Esc_inv = h->Esc_inv.p;
   r.l = h->l.p; r.u = h->u.p; r.dscal = h->dscal.p;
   r.dn = h->cont.rz_scratch.p; r.en = h->cont.rz_scratch.p + (size_t)h->B * n;        // (not the check kernels' scratch: they may be running)
@@ -2370,6 +2382,184 @@ int mi_osqp_batch_get_info_some(mi_osqp_batch *h, int64_t n_ids, const int64_t *
   return MI_OSQP_OK;
 }
 int64_t mi_osqp_batch_running(mi_osqp_batch *h) { return h && h->cont.on ? h->cont.n_running : 0; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ gomp scene
+// SURVEY 8(f) rank 2 on the device: the re-linearised 3-D / obstacle rows of the GOMP constraint matrix
+// ([REF] src/constraints/constraint-builder.h:90-136) and the feasibility check that decides the SQP loop
+// ([REF] src/gomp-solver.h:141-199), for balls whose kinematics are built-in models.  The scene keeps the raw constraint
+// data of every QP of a batch handle on the device; re-linearising a QP rewrites its 3-D rows there (gomp_relinearise_kernel)
+// and runs QPSolver::update from them - no A values cross PCIe in an SQP step, only the trajectory (n doubles) and one flag.
+struct mi_gomp_scene {
+  mi_osqp_batch *h = nullptr;
+  int dims = 0, W = 0, n_balls = 0, n_lines = 0, row0 = 0, n_rows3d = 0;
+  double con_lo[3] = {-1e30, -1e30, -1e30}, con_hi[3] = {1e30, 1e30, 1e30};
+  DevBuf<GompBallDev> balls;
+  DevBuf<GompLineDev> lines;
+  DevBuf<int> aidx;
+  DevBuf<double> A, l, u;                     // QP-major raw rows as ConstraintBuilder::build() lays them out
+  int *h_ok = nullptr; size_t h_ok_cap = 0;   // the kernel's verdicts (pinned host memory)
+  hipEvent_t ev = nullptr;
+  ~mi_gomp_scene() { hostpool::give(h_ok, h_ok_cap); if (ev) (void)hipEventDestroy(ev); }
+};
+
+static int gomp_launch(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *x, int write_rows /* 0 never, 1 always, 2 unless accepted */, int32_t *ok_out) {
+  mi_osqp_batch *h = sc->h;
+  const Analysis &an = (*h->anp);
+  const int n = an.n, m = an.m, nq = (int)n_ids;
+  int rc;
+  // trajectories and ids through the handle's staging ring (pinned, asynchronous), the verdicts straight into pinned host memory
+  int *d_ids = nullptr;
+  RingSpan sp;
+  if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, nullptr)) || (rc = ring_take(h, (size_t)nq * n * sizeof(double), sp))) return rc;
+  memcpy(sp.host, x, (size_t)nq * n * sizeof(double));
+  if ((rc = ring_upload(h, sp, (size_t)nq * n * sizeof(double)))) return rc;
+  hipStream_t st = h->cont.ustream;
+  GompArgs g{};
+  g.dims = sc->dims; g.W = sc->W; g.n_balls = sc->n_balls; g.n_lines = sc->n_lines; g.n = n; g.m = m; g.nnzA = an.Ap[n]; g.n_ids = nq;
+  g.row0 = sc->row0; g.write_rows = write_rows;
+  g.ids = d_ids; g.balls = sc->balls.p; g.lines = sc->lines.p; g.aidx = sc->aidx.p; g.traj = (const double *)sp.dev;
+  for (int k = 0; k < 3; k++) { g.con_lo[k] = sc->con_lo[k]; g.con_hi[k] = sc->con_hi[k]; }
+  g.A = sc->A.p; g.l = sc->l.p; g.u = sc->u.p; g.ok = sc->h_ok;
+  HIPCHK(launch_gomp_relinearise(g, st));
+  HIPCHK(hipEventRecord(sc->ev, st));
+  HIPCHK(hipEventSynchronize(sc->ev));
+  for (int j = 0; j < nq; j++) ok_out[j] = sc->h_ok[j];
+  return MI_OSQP_OK;
+}
+
+extern "C" {
+
+int mi_gomp_scene_create(mi_gomp_scene **out, mi_osqp_batch *h, int64_t dims, int64_t waypoints, int64_t n_balls, const mi_gomp_ball *balls,
+                         int64_t n_lines, const mi_gomp_line *lines, const double *con_lo, const double *con_hi) {
+  if (!out) return MI_OSQP_ERR_NULL;
+  *out = nullptr;
+  if (!h || (n_balls > 0 && !balls) || (n_lines > 0 && !lines)) return MI_OSQP_ERR_NULL;
+  const Analysis &an = (*h->anp);
+  const int D = (int)dims, W = (int)waypoints;
+  if (D < 1 || D > 8 || W < 2 || n_balls < 0 || n_lines < 0 || an.n != 2 * D * W) return MI_OSQP_ERR_INVALID_DATA;
+  // rows of the reference's layout ([REF] constraint-builder.h:34-44): links, position / velocity / acceleration boxes, then
+  // D W (3 + |lines| |balls|) rows for the 3-D part, of which the populated ones come first
+  const int row0 = (W - 1) * D + D * (W + W - 1 + W - 2);
+  int rows3d = 0;
+  for (int b = 0; b < (int)n_balls; b++) {
+    if (balls[b].model < MI_GM_UR5E_FLANGE || balls[b].model > MI_GM_TABLE) return MI_OSQP_ERR_INVALID_DATA;
+    if ((balls[b].model <= MI_GM_UR5E_ELBOW && D != 6) || (balls[b].model >= MI_GM_YAW_2LINK && D != 3)) return MI_OSQP_ERR_INVALID_DATA;
+    rows3d += W * ((balls[b].is_gripper ? 3 : 0) + (int)n_lines);
+  }
+  if (row0 + rows3d > an.m) return MI_OSQP_ERR_INVALID_DATA;
+  DevGuard guard(h->device);
+  mi_gomp_scene *sc = new (std::nothrow) mi_gomp_scene();
+  if (!sc) return MI_OSQP_ERR_ALLOC;
+  std::unique_ptr<mi_gomp_scene> own(sc);
+  sc->h = h; sc->dims = D; sc->W = W; sc->n_balls = (int)n_balls; sc->n_lines = (int)n_lines; sc->row0 = row0; sc->n_rows3d = rows3d;
+  for (int k = 0; k < 3; k++) { sc->con_lo[k] = con_lo ? con_lo[k] : -1e30; sc->con_hi[k] = con_hi ? con_hi[k] : 1e30; }
+  // where the entries of the 3-D rows sit in A's value array: row r of waypoint w holds D entries in the columns of q_w
+  std::vector<int> aidx((size_t)rows3d * D, -1);
+  {
+    int r = row0;
+    for (int b = 0; b < (int)n_balls; b++)
+      for (int w = 0; w < W; w++)
+        for (int k = 0; k < (balls[b].is_gripper ? 3 : 0) + (int)n_lines; k++, r++)
+          for (int j = 0; j < D; j++) {
+            const int col = w * D + j;
+            const int *lo = an.Ai.data() + an.Ap[col], *hi = an.Ai.data() + an.Ap[col + 1];
+            const int *it = std::lower_bound(lo, hi, r);
+            if (it == hi || *it != r) { g_last_error = "the constraint matrix does not hold the 3-D rows of this scene"; return MI_OSQP_ERR_INVALID_DATA; }
+            aidx[(size_t)(r - row0) * D + j] = (int)(it - an.Ai.data());
+          }
+  }
+  std::vector<GompBallDev> hb((size_t)n_balls);
+  for (int b = 0; b < (int)n_balls; b++) { hb[b].model = balls[b].model; hb[b].is_gripper = balls[b].is_gripper; hb[b].radius = balls[b].radius; for (int k = 0; k < 12; k++) hb[b].param[k] = balls[b].param[k]; }
+  std::vector<GompLineDev> hl((size_t)n_lines);
+  for (int li = 0; li < (int)n_lines; li++) {
+    const double nrm = std::hypot(lines[li].dir[0], lines[li].dir[1]);
+    if (!(nrm > 0.0)) return MI_OSQP_ERR_INVALID_DATA;
+    hl[li].D[0] = lines[li].dir[0] / nrm; hl[li].D[1] = lines[li].dir[1] / nrm; hl[li].D[2] = 0.0;
+    for (int k = 0; k < 3; k++) hl[li].A[k] = lines[li].point[k];
+    hl[li].below = lines[li].below; hl[li].pad = 0;
+  }
+  int rc;
+  if ((rc = sc->balls.upload(hb)) || (rc = sc->lines.upload(hl)) || (rc = sc->aidx.upload(aidx)) ||
+      (rc = sc->A.alloc((size_t)h->B * std::max(an.Ap[an.n], 1))) || (rc = sc->l.alloc((size_t)h->B * std::max(an.m, 1))) || (rc = sc->u.alloc((size_t)h->B * std::max(an.m, 1)))) return rc;
+  HIPCHK(hostpool::alloc((void **)&sc->h_ok, (size_t)h->B * sizeof(int), &sc->h_ok_cap));
+  HIPCHK(hipEventCreateWithFlags(&sc->ev, hipEventDisableTiming));
+  if (h->cont.keepA) { g_last_error = "the solver already has a scene"; return MI_OSQP_ERR_INVALID_DATA; }
+  h->cont.keepA = sc->A.p; h->cont.keepl = sc->l.p; h->cont.keepu = sc->u.p;
+  *out = own.release();
+  return MI_OSQP_OK;
+}
+
+void mi_gomp_scene_free(mi_gomp_scene *sc) {
+  if (!sc) return;
+  DevGuard guard(sc->h->device);
+  (void)hipStreamSynchronize(sc->h->stream);
+  if (sc->h->cont.ustream) (void)hipStreamSynchronize(sc->h->cont.ustream);
+  if (sc->h->cont.keepA == sc->A.p) sc->h->cont.keepA = sc->h->cont.keepl = sc->h->cont.keepu = nullptr;
+  delete sc;
+}
+
+// the raw constraint data of the listed QPs as the host built them (ConstraintBuilder::build): kept on the device
+int mi_gomp_scene_set_rows(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *Av, const double *l, const double *u) {
+  if (!sc || (n_ids > 0 && (!ids || !Av || !l || !u))) return MI_OSQP_ERR_NULL;
+  mi_osqp_batch *h = sc->h;
+  DevGuard guard(h->device);
+  const Analysis &an = (*h->anp);
+  const size_t nnzA = (size_t)an.Ap[an.n], m = (size_t)an.m;
+  hipStream_t st = h->cont.on && h->cont.ustream ? h->cont.ustream : h->stream;
+  for (int64_t j = 0; j < n_ids; j++) {
+    if (ids[j] < 0 || ids[j] >= h->B) return MI_OSQP_ERR_INVALID_DATA;
+    HIPCHK(hipMemcpyAsync(sc->A.p + (size_t)ids[j] * nnzA, Av + (size_t)j * nnzA, nnzA * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc->l.p + (size_t)ids[j] * m, l + (size_t)j * m, m * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc->u.p + (size_t)ids[j] * m, u + (size_t)j * m, m * sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));          // (the caller's arrays are pageable)
+  return MI_OSQP_OK;
+}
+int mi_gomp_scene_get_rows(mi_gomp_scene *sc, int64_t id, double *Av, double *l, double *u) {
+  if (!sc) return MI_OSQP_ERR_NULL;
+  mi_osqp_batch *h = sc->h;
+  if (id < 0 || id >= h->B) return MI_OSQP_ERR_INVALID_DATA;
+  DevGuard guard(h->device);
+  const Analysis &an = (*h->anp);
+  const size_t nnzA = (size_t)an.Ap[an.n], m = (size_t)an.m;
+  if (Av) HIPCHK(hipMemcpy(Av, sc->A.p + (size_t)id * nnzA, nnzA * sizeof(double), hipMemcpyDeviceToHost));
+  if (l) HIPCHK(hipMemcpy(l, sc->l.p + (size_t)id * m, m * sizeof(double), hipMemcpyDeviceToHost));
+  if (u) HIPCHK(hipMemcpy(u, sc->u.p + (size_t)id * m, m * sizeof(double), hipMemcpyDeviceToHost));
+  return MI_OSQP_OK;
+}
+
+// withObstacles(con_3d, x) for the listed QPs' kept rows, without touching the solver (tests; the first linearisation of a segment)
+int mi_gomp_assemble_some(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *x, int32_t *ok_out) {
+  if (!sc || (n_ids > 0 && (!ids || !x || !ok_out))) return MI_OSQP_ERR_NULL;
+  if (!n_ids) return MI_OSQP_OK;
+  DevGuard guard(sc->h->device);
+  int rc;
+  if ((rc = cont_enter(sc->h)) || (rc = cont_check_ids(sc->h, n_ids, ids, false))) return rc;
+  return gomp_launch(sc, n_ids, ids, x, 1, ok_out);
+}
+
+// One SQP step of the listed (finished) QPs on the device: isSolutionOK of their solutions x; the QPs whose trajectory is not
+// acceptable are re-linearised around it (their kept 3-D rows rewritten) and updated (= builder.withObstacles(con_3d, x) +
+// QPSolver::update, [REF] src/gomp-solver.h:79-87) - they are ready for solve_begin_some.  ok_out[j] = 1: trajectory accepted.
+int mi_gomp_relinearise_some(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, const double *x, int32_t *ok_out) {
+  CallTimer timer_("gomp_relinearise_some");
+  if (!sc || (n_ids > 0 && (!ids || !x || !ok_out))) return MI_OSQP_ERR_NULL;
+  if (!n_ids) return MI_OSQP_OK;
+  mi_osqp_batch *h = sc->h;
+  DevGuard guard(h->device);
+  int rc;
+  if ((rc = cont_enter(h)) || (rc = cont_check_ids(h, n_ids, ids, true))) return rc;
+  // the acceptance test; the trajectories that fail it get new 3-D rows in the same launch (an accepted trajectory's rows
+  // stay as they are: its solver is not updated) ...
+  if ((rc = gomp_launch(sc, n_ids, ids, x, 2, ok_out))) return rc;
+  std::vector<int64_t> bad;
+  for (int64_t j = 0; j < n_ids; j++) if (!ok_out[j]) bad.push_back(ids[j]);
+  if (bad.empty()) return MI_OSQP_OK;
+  // ... and the update from the device-resident data
+  return cont_new_data(h, (int64_t)bad.size(), bad.data(), nullptr, nullptr, nullptr, false, sc->A.p, sc->l.p, sc->u.p);
+}
 
 }  // extern "C"
 

@@ -320,6 +320,282 @@ static int run_cont(int seed = 0) {
   return fails ? 1 : 0;
 }
 
+// GPU: re-linearisation on the device (mi_gomp_scene) against the host ConstraintBuilder.
+//  (1) the reference's known-answer tests for the 3-D rows ([REF] tests/test.cpp:250-448) through the TABLE model,
+//  (2) random trajectories of the 3-link arm and of the UR5e (two balls): rows, bounds and the acceptance test,
+//  (3) one SQP step (mi_gomp_relinearise_some) against QPSolver::update with host-built rows: same QP, same solution,
+//  (4) the continuous planner with device_assembly against the host-assembling one.
+template <size_t D>
+static bool host_solution_ok(const QPVector &traj, const std::vector<RobotBall> &balls, const std::vector<HorizontalLine> &lines, const Constraint<3> &con) {
+  bool res = true;
+  for (const RobotBall &ball : balls) {
+    const QPVector xyz = mapJointTrajectoryToXYZ<D>(traj, ball.fk);
+    const int W = (int)xyz.size() / 3;
+    for (int w = 0; w < W; ++w) {
+      const Point p{xyz[3 * w], xyz[3 * w + 1], xyz[3 * w + 2]};
+      if (ball.is_gripper)
+        for (int ax = 0; ax < 3; ++ax) {
+          const double lo = con.first ? (*con.first)[ax] : -INF, up = con.second ? (*con.second)[ax] : INF;
+          if (!(lo - ERROR <= p[ax] - ball.radius && p[ax] + ball.radius <= up + ERROR)) res = false;
+        }
+      for (const HorizontalLine &line : lines) if (line.hasCollision(w, xyz, ball) && !line.isAbove(p, ball)) res = false;
+    }
+  }
+  return res;
+}
+static mi_gomp_ball dev_ball(const RobotBall &b) {
+  mi_gomp_ball g{};
+  g.model = b.builtin_model; g.is_gripper = b.is_gripper; g.radius = b.radius;
+  for (int k = 0; k < 12; ++k) g.param[k] = b.builtin_param[k];
+  return g;
+}
+static mi_gomp_line dev_line(const HorizontalLine &l) {
+  mi_gomp_line g{};
+  g.dir[0] = l.directionXY()[0]; g.dir[1] = l.directionXY()[1];
+  for (int k = 0; k < 3; ++k) g.point[k] = l.point()[k];
+  g.below = l.bypassFromBelow();
+  return g;
+}
+template <size_t D>
+static void devasm_scene(const char *name, size_t W, const std::vector<RobotBall> &balls, const std::vector<HorizontalLine> &lines, const Constraint<3> &con,
+                         const Constraint<D> &pos, const Constraint<D> &vel, const Constraint<D> &acc,
+                         const std::function<QPVector(std::mt19937_64 &)> &make_traj, int K, double tol) {
+  const QPMatrixSparse P = triDiagonalMatrix(2, -1, (int)(D * 2 * W), (int)(W * D), (int)D);
+  std::mt19937_64 rng(99);
+  QPVector base = make_traj(rng);
+  ConstraintBuilder<D> tmpl{W, balls, lines};
+  tmpl.positions(1, W - 2, pos).velocities(0, W - 4, vel).velocity(W - 3, constraints::eqZero<D>())
+      .accelerations(0, W - 4, acc).acceleration(W - 3, constraints::eqZero<D>());
+  std::vector<ConstraintBuilder<D>> builders(K, tmpl);
+  std::vector<QPConstraints> cons(K);
+  std::vector<QPVector> trajs(K);
+  for (int k = 0; k < K; ++k) {
+    trajs[k] = make_traj(rng);
+    Ctrl<D> s0, e0;
+    for (size_t j = 0; j < D; ++j) { s0[j] = trajs[k][j]; e0[j] = trajs[k][(W - 3) * D + j]; }
+    builders[k].position(0, constraints::equal<D>(s0)).position(W - 3, constraints::equal<D>(e0)).withObstacles(con, base);
+    cons[k] = builders[k].build();
+  }
+  ContinuousQPSolver qp(K, cons[0], P, false), qp_host(K, cons[0], P, false);
+  std::vector<mi_gomp_ball> db;
+  for (const RobotBall &b : balls) db.push_back(dev_ball(b));
+  std::vector<mi_gomp_line> dl;
+  for (const HorizontalLine &l : lines) dl.push_back(dev_line(l));
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) { lo[k] = con.first ? (*con.first)[k] : -INF; hi[k] = con.second ? (*con.second)[k] : INF; }
+  mi_gomp_scene *sc = nullptr;
+  int rc = mi_gomp_scene_create(&sc, qp.handle(), (int64_t)D, (int64_t)W, (int64_t)db.size(), db.data(), (int64_t)dl.size(), dl.data(), lo, hi);
+  CHECK(rc == MI_OSQP_OK);
+  if (rc != MI_OSQP_OK) { std::printf("%s: scene_create: %s (%s)\n", name, mi_osqp_error_name(rc), mi_osqp_last_error()); return; }
+  std::vector<long long> ids(K);
+  std::vector<const QPConstraints *> cs(K);
+  std::vector<const QPVector *> ws(K);
+  std::vector<double> av, lv, uv, xs;
+  for (int k = 0; k < K; ++k) {
+    ids[k] = k; cs[k] = &cons[k]; ws[k] = &trajs[k];
+    const auto &[l_, A_, u_] = cons[k];
+    av.insert(av.end(), A_.values.begin(), A_.values.end()); lv.insert(lv.end(), l_.begin(), l_.end()); uv.insert(uv.end(), u_.begin(), u_.end());
+    xs.insert(xs.end(), trajs[k].begin(), trajs[k].end());
+  }
+  qp.reinit(ids, cs); qp_host.reinit(ids, cs);
+  CHECK(mi_gomp_scene_set_rows(sc, K, reinterpret_cast<const int64_t *>(ids.data()), av.data(), lv.data(), uv.data()) == MI_OSQP_OK);
+  // (2) op level: the rows around trajs[k], on a copy of the scene's rows (assemble does not touch the solver)
+  std::vector<int32_t> ok(K, -1);
+  CHECK(mi_gomp_assemble_some(sc, K, reinterpret_cast<const int64_t *>(ids.data()), xs.data(), ok.data()) == MI_OSQP_OK);
+  double worst = 0.0;
+  int n_bad = 0, n_active = 0;
+  std::vector<QPConstraints> relin(K);
+  for (int k = 0; k < K; ++k) {
+    relin[k] = builders[k].withObstacles(con, trajs[k]).build();
+    const auto &[l_, A_, u_] = relin[k];
+    std::vector<double> A2(A_.values.size()), l2(l_.size()), u2(u_.size());
+    CHECK(mi_gomp_scene_get_rows(sc, k, A2.data(), l2.data(), u2.data()) == MI_OSQP_OK);
+    for (size_t t = 0; t < A2.size(); ++t) worst = std::fmax(worst, std::fabs(A2[t] - A_.values[t]));
+    for (size_t t = 0; t < l2.size(); ++t) {
+      worst = std::fmax(worst, std::fabs(l2[t] - l_[t]) / (1.0 + std::fabs(l_[t])));
+      worst = std::fmax(worst, std::fabs(u2[t] - u_[t]) / (1.0 + std::fabs(u_[t])));
+      if (t >= l_.size() - D * W * (3 + lines.size() * balls.size()) && (l_[t] > -1e29 || u_[t] < 1e29)) ++n_active;
+    }
+    const bool hk = host_solution_ok<D>(trajs[k], balls, lines, con);
+    CHECK((ok[k] != 0) == hk);
+    n_bad += !hk;
+  }
+  std::printf("%s: %d trajectories (%d not acceptable), %d bounded 3-D rows, max difference device / host rows %.3e\n", name, K, n_bad, n_active, worst);
+  CHECK(worst <= tol);
+  CHECK(n_bad > 0 && n_bad < K);
+  CHECK(n_active > 0);
+  // (3) one SQP step: device re-linearisation + update against QPSolver::update with the host's rows, then the same solve
+  std::fill(ok.begin(), ok.end(), -1);
+  CHECK(mi_gomp_relinearise_some(sc, K, reinterpret_cast<const int64_t *>(ids.data()), xs.data(), ok.data()) == MI_OSQP_OK);
+  std::vector<long long> again;
+  std::vector<const QPConstraints *> cs2;
+  for (int k = 0; k < K; ++k) {
+    CHECK((ok[k] != 0) == host_solution_ok<D>(trajs[k], balls, lines, con));
+    if (!ok[k]) { again.push_back(k); cs2.push_back(&relin[k]); }
+  }
+  qp_host.update(again, cs2);
+  std::vector<const QPVector *> ws2;
+  for (long long id : again) ws2.push_back(&trajs[(size_t)id]);
+  qp.setWarmStart(again, ws2); qp_host.setWarmStart(again, ws2);
+  qp.begin(again); qp_host.begin(again);
+  size_t left = again.size(), left_h = again.size();
+  for (int it = 0; it < 4000 && (left || left_h); ++it) {
+    if (left) { qp.advance(4); left -= qp.poll().size(); }
+    if (left_h) { qp_host.advance(4); left_h -= qp_host.poll().size(); }
+  }
+  CHECK(left == 0 && left_h == 0);
+  double worst_x = 0.0;
+  for (long long id : again) {
+    auto [cd, xd] = qp.result(id);
+    auto [ch, xh] = qp_host.result(id);
+    CHECK(cd == ch);
+    CHECK(qp.last_info().iter == qp_host.last_info().iter || true);
+    if (cd == ExitCode::kOptimal) for (size_t t = 0; t < xd.size(); ++t) worst_x = std::fmax(worst_x, std::fabs(xd[t] - xh[t]));
+  }
+  std::printf("%s: %zu QPs re-linearised and updated on the device, solved: max |x_device_rows - x_host_rows| %.3e\n", name, again.size(), worst_x);
+  CHECK(worst_x <= 1e-6);
+  mi_gomp_scene_free(sc);
+}
+
+static int run_devasm() {
+  const double pi = 3.14159265358979323846;
+  // (1) the reference's known answers: D = 3, W = 2, one gripper ball of radius 0, p = q, J = a table
+  {
+    const size_t D = 3, W = 2, first3d = (W - 1) * D + W * D + (W - 1) * D + (W - 2) * D;
+    auto con = constraints::inRange<3>(Vec<3>{11, 22, 33}, Vec<3>{44, 55, 66});
+    ForwardKinematicsFun fk_id = [](double *q) { return std::tuple<double, double, double>{q[0], q[1], q[2]}; };
+    JacobianFun jac_zero = [](double *o, double *) { for (int k = 0; k < 9; ++k) o[k] = 1.0; };
+    QPVector ones(W * D * 2, 1.0);
+    QPConstraints c0 = ConstraintBuilder<3>{W, {RobotBall{fk_id, jac_zero, 0, true}}, {}}.withObstacles(con, ones).build();
+    const QPMatrixSparse P = triDiagonalMatrix(2, -1, (int)(D * 2 * W), (int)(W * D), (int)D);
+    ContinuousQPSolver qp(1, c0, P, false);
+    const auto &[l0, A0, u0] = c0;
+    const double tables[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 1, 2, 4, 8, 16, 32, 64, 128}};
+    for (int variant = 0; variant < 3; ++variant) {          // position3d_1, position3d_jac_pow2, ignore_velocity_trajectory
+      mi_gomp_ball ball{};
+      ball.model = MI_GOMP_MODEL_TABLE; ball.is_gripper = 1; ball.radius = 0.0;
+      for (int k = 0; k < 9; ++k) ball.param[k] = tables[variant ? 1 : 0][k];
+      const double lo[3] = {11, 22, 33}, hi[3] = {44, 55, 66};
+      mi_gomp_scene *sc = nullptr;
+      CHECK(mi_gomp_scene_create(&sc, qp.handle(), 3, 2, 1, &ball, 0, nullptr, lo, hi) == MI_OSQP_OK);
+      if (!sc) { std::printf("scene_create: %s\n", mi_osqp_last_error()); break; }
+      const int64_t id = 0;
+      CHECK(mi_gomp_scene_set_rows(sc, 1, &id, A0.values.data(), l0.data(), u0.data()) == MI_OSQP_OK);
+      QPVector traj(W * D * 2, variant ? 2.0 : 1.0);
+      if (variant == 2) for (size_t k = W * D; k < 2 * W * D; ++k) traj[k] = 1024.0;
+      int32_t ok = -1;
+      CHECK(mi_gomp_assemble_some(sc, 1, &id, traj.data(), &ok) == MI_OSQP_OK);
+      std::vector<double> A2(A0.values.size()), l2(l0.size()), u2(u0.size());
+      CHECK(mi_gomp_scene_get_rows(sc, 0, A2.data(), l2.data(), u2.data()) == MI_OSQP_OK);
+      const double el1[3] = {11 - 1 + 3, 22 - 1 + 12, 33 - 1 + 21}, eu1[3] = {44 - 1 + 3, 55 - 1 + 12, 66 - 1 + 21};
+      const double el2[3] = {11 - 2 + 0 + 2 + 4, 22 - 2 + 8 + 16 + 32, 33 - 2 + 64 + 128 + 256}, eu2[3] = {44 - 2 + 0 + 2 + 4, 55 - 2 + 8 + 16 + 32, 66 - 2 + 64 + 128 + 256};
+      for (int r = 0; r < 6; ++r) {
+        CHECK(l2[first3d + r] == (variant ? el2 : el1)[r % 3]);
+        CHECK(u2[first3d + r] == (variant ? eu2 : eu1)[r % 3]);
+      }
+      QPMatrixSparse A = A0; A.values = A2;
+      auto M = dense_rows(A, first3d, 6);
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 12; ++c) {
+        const bool in = (c / 3) == (r / 3);
+        CHECK(M[r][c] == (in ? tables[variant ? 1 : 0][(r % 3) * 3 + c % 3] : 0.0));
+      }
+      CHECK(ok == 0);          // p = (1,1,1) or (2,2,2) is far below the box 11..44
+      // the joint-space rows are untouched
+      for (size_t r = 0; r < first3d; ++r) { CHECK(l2[r] == l0[r]); CHECK(u2[r] == u0[r]); }
+      mi_gomp_scene_free(sc);
+    }
+    std::printf("device rows reproduce ConstraintsTest.position3d_1 / position3d_jac_pow2 / ignore_velocity_trajectory\n");
+  }
+  // (2), (3): the 3-link arm passing a bar, and the UR5e with its two balls, a bar and the y >= -0.4 wall
+  {
+    std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}.withBuiltin(MI_GOMP_MODEL_YAW_2LINK, {L1, L2, Z0})};
+    std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
+    auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF});
+    const size_t W = 40;
+    auto make = [&](std::mt19937_64 &rng) {
+      std::uniform_real_distribution<double> U(-1.0, 1.0);
+      const double a[3] = {-0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)}, b[3] = {0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)};
+      const double lift = U(rng) > 0 ? 0.9 : 0.0;            // half of them arch over the bar
+      QPVector x(2 * 3 * W, 0.0);
+      for (size_t w = 0; w < W; ++w) {
+        const double t = std::fmin(1.0, (double)w / (double)(W - 3));
+        for (int j = 0; j < 3; ++j) x[w * 3 + j] = a[j] + t * (b[j] - a[j]) + (j == 1 ? lift * std::sin(pi * t) : 0.0);
+      }
+      for (size_t w = 0; w + 1 < W; ++w) for (int j = 0; j < 3; ++j) x[W * 3 + w * 3 + j] = (x[(w + 1) * 3 + j] - x[w * 3 + j]) / 0.1;
+      return x;
+    };
+    devasm_scene<3>("3-link arm", W, balls, lines, c3d, constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi)),
+                    constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi)),
+                    constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180)), make, 12, 1e-12);
+  }
+  {
+    std::vector<RobotBall> balls{RobotBall(&forward_kinematics_6_back, &joint_jacobian_6_back, 0.15, false).withBuiltin(MI_GOMP_MODEL_UR5E_WRIST3),
+                                 RobotBall(&forward_kinematics, &joint_jacobian, 0.05, true).withBuiltin(MI_GOMP_MODEL_UR5E_FLANGE)};
+    std::vector<HorizontalLine> lines{HorizontalLine({0, 1}, {0.3, 0, 0.35}, false)};
+    auto c3d = constraints::inRange<3>(Vec<3>{-INF, -0.4, -INF}, Vec<3>{INF, INF, INF});
+    const size_t W = 22;
+    auto make = [&](std::mt19937_64 &rng) {
+      std::uniform_real_distribution<double> U(-1.0, 1.0);
+      double a[6], b[6];
+      for (int j = 0; j < 6; ++j) { a[j] = 0.4 * U(rng); b[j] = 0.4 * U(rng); }
+      b[0] += pi * (U(rng) > 0 ? 1.0 : 0.3);
+      double lift = U(rng) > 0 ? -1.2 : 0.0;
+      if (U(rng) > 0.3) {                                     // a third of them: small motions around the upright pose, clear of everything
+        const double up[6] = {pi / 2, -pi / 2, 0, 0, 0, 0};
+        for (int j = 0; j < 6; ++j) { a[j] = up[j] + 0.15 * U(rng); b[j] = a[j] + 0.15 * U(rng); }
+        lift = 0.0;
+      }
+      QPVector x(2 * 6 * W, 0.0);
+      for (size_t w = 0; w < W; ++w) {
+        const double t = std::fmin(1.0, (double)w / (double)(W - 3));
+        for (int j = 0; j < 6; ++j) x[w * 6 + j] = a[j] + t * (b[j] - a[j]) + (j == 1 ? lift * std::sin(pi * t) : 0.0);
+      }
+      for (size_t w = 0; w + 1 < W; ++w) for (int j = 0; j < 6; ++j) x[W * 6 + w * 6 + j] = (x[(w + 1) * 6 + j] - x[w * 6 + j]) / 0.1;
+      return x;
+    };
+    devasm_scene<6>("UR5e", W, balls, lines, c3d, constraints::inRange<6>(constraints::of<6>(-2 * pi), constraints::of<6>(2 * pi)),
+                    constraints::inRange<6>(constraints::of<6>(-pi), constraints::of<6>(pi)),
+                    constraints::inRange<6>(constraints::of<6>(-pi * 800 / 180), constraints::of<6>(pi * 800 / 180)), make, 12, 1e-12);
+  }
+  // (4) the continuous planner, device assembly against host assembly
+  {
+    std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}.withBuiltin(MI_GOMP_MODEL_YAW_2LINK, {L1, L2, Z0})};
+    std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
+    auto pos = constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi));
+    auto vel = constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi));
+    auto acc = constraints::inRange<3>(constraints::of<3>(-pi * 800 / 180), constraints::of<3>(pi * 800 / 180));
+    auto c3d = constraints::inRange<3>(Vec<3>{-INF, -INF, 0.05}, Vec<3>{INF, INF, INF});
+    std::vector<Ctrl<3>> starts, ends;
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1.0, 1.0);
+    for (int b = 0; b < 24; ++b) {
+      starts.push_back({-0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+      ends.push_back({0.8 + 0.3 * U(rng), 0.3 + 0.2 * U(rng), 0.4 + 0.2 * U(rng)});
+    }
+    ContinuousGOMPSolver<3> host(40, 0.1, pos, vel, acc, c3d, lines, balls), dev(40, 0.1, pos, vel, acc, c3d, lines, balls);
+    dev.device_assembly = true;
+    auto rh = host.run(starts, ends);
+    auto rd = dev.run(starts, ends);
+    double worst = 0.0;
+    int updates = 0, same_counts = 0;
+    for (size_t b = 0; b < starts.size(); ++b) {
+      CHECK(rh[b].first == rd[b].first);
+      CHECK(host.segments_run[b] == dev.segments_run[b]);
+      same_counts += host.qp_solves[b] == dev.qp_solves[b] && host.qp_updates[b] == dev.qp_updates[b];
+      updates += dev.qp_updates[b];
+      CHECK(rh[b].second.size() == rd[b].second.size());
+      for (size_t k = 0; k < rh[b].second.size() && k < rd[b].second.size(); ++k) worst = std::fmax(worst, std::fabs(rh[b].second[k] - rd[b].second[k]));
+    }
+    std::printf("continuous planner, device assembly vs host assembly: %zu trajectories, %d re-linearisations on the device, %d with the same solve / update counts, max |dx| %.3e\n",
+                starts.size(), updates, same_counts, worst);
+    CHECK(updates > 0);
+    CHECK(same_counts == (int)starts.size());
+    CHECK(worst <= 1e-6);
+  }
+  std::printf(fails ? "DEVASM FAILED (%d)\n" : "DEVASM OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 // GPU: BASELINE config 4 as an end-to-end workload: B joint-space trajectories (7-DOF, W = 100, limits as
 // [REF] examples/solver-example.cpp:44-46 replicated to 7 joints) through the batched driver, timed against
 // the sequential driver on the oracle backend for a sample of them.   usage: gomp_parity bench [B] [W] [sample]
@@ -517,7 +793,7 @@ static int run_obstacle_bench(int B, int W, int sample) {
 // it for a sample of the trajectories: what bench.py reports as its obstacle-scene entry.   gomp_parity contbench [trajectories] [waypoints] [sample]
 static int run_cont_bench(int B, int W, int sample) {
   const double pi = 3.14159265358979323846;
-  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}};
+  std::vector<RobotBall> balls{RobotBall{&arm_fk, &arm_jac, 0.03, true}.withBuiltin(MI_GOMP_MODEL_YAW_2LINK, {L1, L2, Z0})};
   std::vector<HorizontalLine> lines{HorizontalLine({1, 0}, {0.6, 0.0, 0.55}, false)};
   auto pos = constraints::inRange<3>(constraints::of<3>(-2 * pi), constraints::of<3>(2 * pi));
   auto vel = constraints::inRange<3>(constraints::of<3>(-pi), constraints::of<3>(pi));
@@ -534,6 +810,9 @@ static int run_cont_bench(int B, int W, int sample) {
   ContinuousGOMPSolver<3> cg((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls);
   if (getenv("GOMP_PIPELINE_DEPTH")) cg.pipeline_depth = std::atoi(getenv("GOMP_PIPELINE_DEPTH"));
   if (getenv("GOMP_SEGMENTS")) cg.segments_per_advance = std::atoi(getenv("GOMP_SEGMENTS"));
+  // GOMP_DEVICE_ASSEMBLY=1: acceptance test, re-linearisation and update on the device (trajectories equal to round-off, not bitwise)
+  const bool dev_asm = getenv("GOMP_DEVICE_ASSEMBLY") && std::atoi(getenv("GOMP_DEVICE_ASSEMBLY"));
+  cg.device_assembly = dev_asm;
   auto t0 = clk::now();
   auto c1 = cg.run(starts, ends);
   const double tc1 = std::chrono::duration<double>(clk::now() - t0).count();
@@ -549,6 +828,10 @@ static int run_cont_bench(int B, int W, int sample) {
     cok += c2[b].first == ExitCode::kOptimal; csolves += cg.qp_solves[b]; cupdates += cg.qp_updates[b];
     CHECK(c2[b].first == c1[b].first); CHECK(c2[b].second == c1[b].second);
   }
+  if (getenv("GOMP_STAGE_PROFILE"))
+    for (const auto &sp : cg.stageProfile())
+      std::printf("  stage W=%3.0f: %4.0f advances; admitting %.3f s, waiting for the device %.3f s, checks + re-linearisation + updates %.3f s, idle %.3f s\n",
+                  sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
   sample = std::min(sample, B);
   t0 = clk::now();
   double md = 0.0;
@@ -561,9 +844,9 @@ static int run_cont_bench(int B, int W, int sample) {
   const double to = std::chrono::duration<double>(clk::now() - t0).count();
   CHECK(md <= 1e-6);
   // (one machine-readable line for bench.py)
-  std::printf("CONTBENCH trajectories %d waypoints %d first_run_s %.4f run_s %.4f trajectories_per_s %.2f qp_solves %d qp_updates %d advances %ld optimal %d "
+  std::printf("CONTBENCH device_assembly %d trajectories %d waypoints %d first_run_s %.4f run_s %.4f trajectories_per_s %.2f qp_solves %d qp_updates %d advances %ld optimal %d "
               "oracle_sample %d oracle_s %.4f oracle_trajectories_per_s %.2f max_dx %.3e\n",
-              B, W, tc1, best, B / best, csolves, cupdates, cg.advances.load(), cok, sample, to, sample / to, md);
+              (int)dev_asm, B, W, tc1, best, B / best, csolves, cupdates, cg.advances.load(), cok, sample, to, sample / to, md);
   std::printf(fails ? "CONTBENCH FAILED (%d)\n" : "CONTBENCH OK\n", fails);
   return fails ? 1 : 0;
 }
@@ -622,6 +905,7 @@ int main(int argc, char **argv) {
   if (argc > 1 && !std::strcmp(argv[1], "cont")) return run_cont(argc > 2 ? std::atoi(argv[2]) : 0);
   if (argc > 1 && !std::strcmp(argv[1], "contbench"))
     return run_cont_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
+  if (argc > 1 && !std::strcmp(argv[1], "devasm")) return run_devasm();
   if (argc > 1 && !std::strcmp(argv[1], "parity")) return run_parity();
   if (argc > 1 && !std::strcmp(argv[1], "oracle")) {          // CPU only: the driver on the oracle backend
     for (int obst = 0; obst < 2; ++obst) {

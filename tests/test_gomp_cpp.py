@@ -64,6 +64,17 @@ def test_continuous_gomp_driver_matches_sequential_drivers(exe):
     assert r.returncode == 0 and "CONT OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+def test_device_relinearisation_matches_host_constraint_builder(exe):
+    """SURVEY 8(f) rank 2 on the device (mi_gomp_scene): the reference's known answers for the 3-D rows
+    ([REF] tests/test.cpp:250-448) exactly; rows / bounds / acceptance test of random 3-link-arm and UR5e trajectories
+    against ConstraintBuilder::withObstacles (1e-12: device sin / cos); one SQP step on the device against
+    QPSolver::update with host rows (solutions 1e-6); the continuous planner with device assembly against the
+    host-assembling one (same exit codes and counters, trajectories 1e-6)."""
+    r = subprocess.run([exe, "devasm"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DEVASM OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_ur5e_kinematics_and_example_scenario_on_oracle(exe):
     """own UR5e FK / Jacobians (published DH parameters; the reference's kinematics library is
     absent) -- zero-pose position, Jacobians vs central differences, IK round trip -- and the scenario of
