@@ -174,6 +174,12 @@ int mi_osqp_batch_get_stats(mi_osqp_batch *h, mi_osqp_stats *st);
  * large KKT matrix without a minimum-degree ordering of its own.) */
 int mi_osqp_batch_get_ordering(mi_osqp_batch *h, int64_t *kkt_perm);
 void mi_osqp_batch_free(mi_osqp_batch *h);
+/* Compute the pattern analysis (ordering, symbolic factor, schedules) that a later mi_osqp_batch_setup / mi_osqp_setup of B
+ * QPs with this sparsity pattern on this device will need, into the process-wide analysis cache.  Thread-safe; blocking (call
+ * it from a spare host thread); a setup that arrives meanwhile waits for it.  The reference builds a fresh QPSolver per horizon
+ * ([REF] src/gomp-solver.h:61-65): a planner that knows its horizons up front takes the analyses off its critical path. */
+int mi_osqp_prefetch_analysis(int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
+                              const int64_t *Ap, const int64_t *Ai, int64_t device);
 /* Freed handles leave their device buffers (at most 8 GiB), pinned host buffers (at most 1 GiB) and stream / event sets in
  * process-wide caches for the next setup - the GOMP drivers build one solver per horizon segment; this returns them to
  * the HIP runtime. */

@@ -32,6 +32,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "qp_solver.hpp"
@@ -249,6 +250,19 @@ class ConstraintBuilder {
     return *this;
   }
 
+  // the cells and rows withObstacles() writes, with zero values and open bounds, without calling the balls' callbacks: the
+  // sparsity pattern of every later build() (pattern analysis ahead of time, GOMPSolver::run)
+  ConstraintBuilder &withObstaclePattern() {
+    size_t row = user_off_ + N_DIM * (W_ + W_ - 1 + W_ - 2);
+    const std::array<double, 3 * N_DIM> J{};
+    for (const RobotBall &ball : balls_)
+      for (size_t w = 0; w < W_; ++w) {
+        if (ball.is_gripper) for (Axis axis : XYZ_AXES) axisRow(row++, ball, axis, J, w, -INF, INF);
+        for (size_t k = 0; k < lines_.size(); ++k) axisRow(row++, ball, Z, J, w, -INF, INF);
+      }
+    return *this;
+  }
+
   // sort and de-duplicate the write log now (build() does it on demand): a builder that serves as a template for copies
   ConstraintBuilder &normalised() { normalise(); return *this; }
 
@@ -346,6 +360,11 @@ class ConstraintBuilder {
 };
 
 // ------------------------------------------------------------------- gomp-solver.h
+namespace detail {
+template <class S, class = void> struct has_prefetch : std::false_type {};
+template <class S>
+struct has_prefetch<S, std::void_t<decltype(S::prefetch(std::declval<const QPConstraints &>(), std::declval<const QPMatrixSparse &>()))>> : std::true_type {};
+}  // namespace detail
 constexpr int MAX_ITERATIONS = 100;
 constexpr int SEGMENTS = 10;
 
@@ -366,6 +385,20 @@ class GOMPSolver {
   std::pair<ExitCode, QPVector> run(Ctrl<N_DIM> start_pos, Ctrl<N_DIM> end_pos) {
     QPVector last_solution = calcWarmStart(start_pos, end_pos);
     ExitCode last_code = ExitCode::kUnknown;
+    // Not in the reference: the horizons of this run are known now, and a solver backend that can analyse a sparsity pattern
+    // ahead of time (SolverT::prefetch) does so for the later horizons on spare host threads while the first ones are solved.
+    PrefetchJoiner prefetching;
+    if constexpr (detail::has_prefetch<SolverT>::value) {
+      if (prefetch_patterns && max_waypoints * N_DIM >= 600)
+        for (int i = SEGMENTS - 1; i >= 1; --i) {
+          const size_t waypoints = max_waypoints * i / SEGMENTS;
+          if (waypoints < 4) continue;
+          prefetching.threads.emplace_back([this, waypoints, start_pos, end_pos] {
+            ConstraintBuilder<N_DIM> b = jointSpaceRows(start_pos, end_pos, waypoints);
+            SolverT::prefetch(b.withObstaclePattern().build(), triDiagonalMatrix(2, -1, (int)(N_DIM * 2 * waypoints), (int)(waypoints * N_DIM), (int)N_DIM));
+          });
+        }
+    }
     for (int i = SEGMENTS; i >= 1; --i) {
       const size_t waypoints = max_waypoints * i / SEGMENTS;
       QPVector warm_start(waypoints * N_DIM * 2);
@@ -405,8 +438,10 @@ class GOMPSolver {
 
   // counters for tests / reporting
   int segments_run = 0, qp_solves = 0, qp_updates = 0;
+  bool prefetch_patterns = true;
 
  private:
+  struct PrefetchJoiner { std::vector<std::thread> threads; ~PrefetchJoiner() { for (auto &t : threads) t.join(); } };
   const size_t max_waypoints;
   const double time_step;
   const Constraint<N_DIM> pos_con, vel_con, acc_con;
@@ -424,6 +459,11 @@ class GOMPSolver {
 
   ConstraintBuilder<N_DIM> initConstraints(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, const QPVector &warm_start,
                                            size_t waypoints) const {
+    ConstraintBuilder<N_DIM> b = jointSpaceRows(start_pos, end_pos, waypoints);
+    b.withObstacles(con_3d, warm_start);
+    return b;
+  }
+  ConstraintBuilder<N_DIM> jointSpaceRows(const Ctrl<N_DIM> &start_pos, const Ctrl<N_DIM> &end_pos, size_t waypoints) const {
     assert(waypoints >= 4);
     ConstraintBuilder<N_DIM> b{waypoints, mappers, obstacles};
     b.position(0, constraints::equal<N_DIM>(start_pos))
@@ -432,8 +472,7 @@ class GOMPSolver {
         .velocities(0, waypoints - 4, vel_con)
         .velocity(waypoints - 3, constraints::eqZero<N_DIM>())
         .accelerations(0, waypoints - 4, acc_con)
-        .acceleration(waypoints - 3, constraints::eqZero<N_DIM>())
-        .withObstacles(con_3d, warm_start);
+        .acceleration(waypoints - 3, constraints::eqZero<N_DIM>());
     return b;
   }
 

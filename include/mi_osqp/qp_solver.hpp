@@ -91,6 +91,13 @@ class QPSolver {
     n_ = A.cols;
   }
   ~QPSolver() { mi_osqp_free(h_); }
+  // Not in the reference: the pattern analysis of a solver that will be constructed later for (c, P), computed now (blocking;
+  // meant for a spare host thread).  Values are not looked at, only the patterns.
+  static void prefetch(const QPConstraints &c, const QPMatrixSparse &P) {
+    const QPMatrixSparse &A = std::get<1>(c);
+    (void)mi_osqp_prefetch_analysis(1, A.cols, A.rows, reinterpret_cast<const int64_t *>(P.outer.data()), reinterpret_cast<const int64_t *>(P.inner.data()),
+                                    reinterpret_cast<const int64_t *>(A.outer.data()), reinterpret_cast<const int64_t *>(A.inner.data()), -1);
+  }
   QPSolver(const QPSolver &) = delete;
   QPSolver &operator=(const QPSolver &) = delete;
 

@@ -145,6 +145,7 @@ def lib():
         L.mi_osqp_multi_batch_free.argtypes = [vp]; L.mi_osqp_multi_batch_free.restype = None
         L.mi_osqp_debug_host_kkt_solve.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
                                                    C.POINTER(Settings), C.c_int64, dp, dp, dp, C.POINTER(Stats)]
+        L.mi_osqp_prefetch_analysis.argtypes = [C.c_int64, C.c_int64, C.c_int64, ip, ip, ip, ip, C.c_int64]
         L.mi_osqp_debug_host_block_factor.argtypes = [C.c_int64, C.c_int64, ip, ip, dp, ip, ip, dp, dp, dp,
                                                       C.POINTER(Settings), dp, dp, ip]
         _LIB = L
@@ -553,6 +554,19 @@ def debug_host_kkt_solve(P, A, l, u, rhs, tri_waves=0, **settings):
                                         C.byref(s), 1 + int(tri_waves), _dp(rhs), _dp(sol_s), _dp(sol_d), C.byref(st))
     _chk(rc, "debug_host_kkt_solve")
     return sol_s, sol_d, st.as_dict()
+
+
+def prefetch_analysis(P, A, B=1, device=-1, check=True):
+    """Pattern analysis of a later setup of B QPs with the patterns of (P, A), computed now into the process-wide cache
+    (host work only; blocking - call it from a spare thread).  Returns the C-ABI status."""
+    L = lib()
+    P, A = _csc(P), _csc(A)
+    n, m = A.shape[1], A.shape[0]
+    Pp, Pi, Ap, Ai = _i64(P.indptr), _i64(P.indices), _i64(A.indptr), _i64(A.indices)
+    rc = L.mi_osqp_prefetch_analysis(B, n, m, _ip(Pp), _ip(Pi), _ip(Ap), _ip(Ai), device)
+    if check:
+        _chk(rc, "prefetch_analysis")
+    return rc
 
 
 def debug_host_block_factor(P, A, l, u, **settings):

@@ -11,6 +11,7 @@
 #include <numeric>
 #include <set>
 #include <chrono>
+#include <thread>
 
 #include "../../include/mi_osqp.h"
 
@@ -1027,7 +1028,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   an.wide = N >= 65535 || 2 * n + m >= 65535 || tri_waves > 0;        // (the dataflow form doubles the index range)
   if (max_extra_rows < 0) max_extra_rows = 1 << 30;       // (also the budget of the dense tail's two accumulation vectors)
   if (!an.wide && max_extra_rows > 65534 - N) max_extra_rows = 65534 - N;
-  auto finalize = [&](const std::vector<int> &perm0, double &cost) {
+  auto finalize = [&](Analysis &an, const std::vector<int> &perm0, double &cost) {
     an.perm = perm0;
     an.pinv.assign(N, 0);
     for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
@@ -1139,11 +1140,12 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     // nested dissection takes 0.2 s and wins anyway - so beyond 60 k rows only on request) and nested dissections with
     // several leaf sizes (all of them while the pattern is small enough for that to cost milliseconds; MI_OSQP_ND_LEAF
     // forces one size).  The cheapest by the modelled time of one KKT solve wins; ties go to the earlier candidate.
-    struct Cand { std::vector<int> perm; double cost = 0.0; int leaf = 0; };      // leaf 0 = minimum degree
+    // Every candidate (ordering + symbolic analysis of its permutation) runs on a host thread of its own, on its own copy of
+    // the analysis so far (the 802-waypoint example: 155 -> 60 ms of the 220 ms a setup spends here).
+    struct Cand { std::vector<int> perm; double cost = 0.0; int leaf = 0; Analysis an; double t_order = 0.0, t_final = 0.0; };      // leaf 0 = minimum degree
     std::vector<Cand> cands;
     const bool try_md = (N <= 60000 && !(force && force[0] == 'n')) || (force && force[0] == 'm');
-    if (try_md) { cands.emplace_back(); min_degree(N, an.Kp, an.Ki, cands.back().perm); }
-    if (dbg_t) { fprintf(stderr, "[mi_osqp] min_degree %.1f ms\n", 1e3 * (now_() - tt)); tt = now_(); }
+    if (try_md) cands.emplace_back();
     if (!(force && force[0] == 'm')) {
       std::vector<int> leaves;
       const char *el = getenv("MI_OSQP_ND_LEAF");
@@ -1151,24 +1153,52 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
       else if (N <= 8000) leaves = {48, 24, 12, 8, 4};
       else if (N <= 60000) leaves = {48, 12};
       else leaves = {48};
-      for (int lf : leaves) { cands.emplace_back(); cands.back().leaf = lf; nested_dissection(N, an.Kp, an.Ki, cands.back().perm, lf); }
-      if (dbg_t) { fprintf(stderr, "[mi_osqp] nested_dissection x %zu %.1f ms\n", leaves.size(), 1e3 * (now_() - tt)); tt = now_(); }
+      for (int lf : leaves) { cands.emplace_back(); cands.back().leaf = lf; }
     }
+    auto run_cand = [&](Cand &c) {
+      double t0 = now_();
+      c.an = an;
+      if (c.leaf) nested_dissection(N, an.Kp, an.Ki, c.perm, c.leaf); else min_degree(N, an.Kp, an.Ki, c.perm);
+      c.t_order = now_() - t0; t0 = now_();
+      finalize(c.an, c.perm, c.cost);
+      c.t_final = now_() - t0;
+    };
+    if (cands.size() > 1 && N >= 1000 && !getenv("MI_OSQP_SERIAL_ANALYSIS")) {
+      std::vector<std::thread> th;
+      for (size_t c = 1; c < cands.size(); c++) th.emplace_back([&, c] { run_cand(cands[c]); });
+      run_cand(cands[0]);
+      for (auto &t : th) t.join();
+    } else for (Cand &c : cands) run_cand(c);
     size_t best = 0;
     for (size_t c = 0; c < cands.size(); c++) {
-      finalize(cands[c].perm, cands[c].cost);
-      if (dbg_t) fprintf(stderr, "[mi_osqp] ordering candidate %s leaf %d: modelled solve %.3e s, nnz(L) %d\n", cands[c].leaf ? "nd" : "md", cands[c].leaf, cands[c].cost, an.Lp[N]);
+      if (dbg_t) fprintf(stderr, "[mi_osqp] ordering candidate %s leaf %d: modelled solve %.3e s, nnz(L) %d (ordering %.1f ms, symbolic %.1f ms)\n", cands[c].leaf ? "nd" : "md",
+                         cands[c].leaf, cands[c].cost, cands[c].an.Lp[N], 1e3 * cands[c].t_order, 1e3 * cands[c].t_final);
       if (cands[c].cost < cands[best].cost) best = c;
     }
-    if (dbg_t) { fprintf(stderr, "[mi_osqp] finalize x %zu %.1f ms\n", cands.size(), 1e3 * (now_() - tt)); tt = now_(); }
-    if (best + 1 != cands.size()) finalize(cands[best].perm, cands[best].cost);
-    an.ordering = cands[best].leaf ? 1 : 0;
+    if (dbg_t) { fprintf(stderr, "[mi_osqp] ordering candidates x %zu %.1f ms\n", cands.size(), 1e3 * (now_() - tt)); tt = now_(); }
+    { const int leaf = cands[best].leaf; Analysis chosen = std::move(cands[best].an); an = std::move(chosen); an.ordering = leaf ? 1 : 0; }
   }
   if (tri_waves > 0 && (bt != 1 || an.dt.k)) return MI_OSQP_ERR_INVALID_SETTINGS;
-  build_tri_schedules(an, tri_waves > 0 ? tri_waves : nwaves, bt, tri_waves > 0);
-  build_chk_schedule(an, tri_waves > 0 ? tri_waves : nwaves, bt);      // (dataflow form: check_kernel runs on the whole grid too)
-  build_dense_tail(an, nwaves);
-  build_block_factor(an);
+  {
+    // the check (SpMV) schedule only reads the symbolic analysis and writes tables of its own: a host thread beside the
+    // solve schedules + refactorisation plan (which reads them) for patterns where that pays
+    const bool dbg_t = getenv("MI_OSQP_DEBUG_ORDER") != nullptr;
+    auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now_();
+    double t_chk = 0.0, t_bf = 0.0;
+    auto chk_part = [&] { const double t = now_(); build_chk_schedule(an, tri_waves > 0 ? tri_waves : nwaves, bt); t_chk = now_() - t; };      // (dataflow form: check_kernel runs on the whole grid too)
+    auto bf_part = [&] { const double t = now_(); build_block_factor(an); t_bf = now_() - t; };
+    const bool par = N >= 1000 && !getenv("MI_OSQP_SERIAL_ANALYSIS");
+    std::thread th_chk;
+    if (par) th_chk = std::thread(chk_part);
+    build_tri_schedules(an, tri_waves > 0 ? tri_waves : nwaves, bt, tri_waves > 0);
+    build_dense_tail(an, nwaves);
+    const double t_tri = now_() - t0;
+    bf_part();
+    if (par) th_chk.join(); else chk_part();
+    if (dbg_t) fprintf(stderr, "[mi_osqp] tables: solve schedules + dense tail %.1f ms, check schedule %.1f ms, block factor %.1f ms; wall %.1f ms\n",
+                       1e3 * t_tri, 1e3 * t_chk, 1e3 * t_bf, 1e3 * (now_() - t0));
+  }
   // A wave that passes fewer barriers than the others would hang its workgroup (and the GPU): re-count.
   for (const Schedule *sc : {&an.fwd, &an.bwd, &an.chk})
     for (int w = 0; w < sc->nw; w++) {

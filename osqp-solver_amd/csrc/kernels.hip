@@ -2770,8 +2770,144 @@ __global__ __launch_bounds__(512) void ruiz_kernel(RuizArgs a) {
   if (tid == 0) { a.dscal[H(DS_COUNT, DS_C)] = c; a.dscal[H(DS_COUNT, DS_CINV)] = 1.0 / c; }
   for (int k = tid; k < pa_len; k += nthr) a.pa_out[(size_t)jq * pa_len + k] = a.pa_val[H(pa_len, k)];
 }
+// The same computation for QPs of up to 16 k entries and n + m <= 16 k (the GOMP QPs of BASELINE.md's batch configs, the
+// random QPs of the headline): each thread keeps its share of the values of P and A - and their two norm slots, packed - in
+// registers through all iterations, the norm vectors live in LDS (ds_max_u64 instead of L2 atomics); global memory is touched
+// for the small vectors (q, D, E, bounds) only.  Operation for operation the kernel above (same bits).
+// An entry of triu(P) at (r, c) has the slots (r, c) of dn, an entry of A at (r, c) the slots (n + r, c) of [dn ; en].
+template <int VPT>
+__global__ __launch_bounds__(512) void ruiz_reg_kernel(RuizArgs a) {
+  extern __shared__ double rz_lds[];               // nv = [dn[n] ; en[m]]
+  __shared__ double s_red[16];
+  const int jq = blockIdx.x, qp = a.ids ? a.ids[jq] : jq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NT = 512, NW = NT / 64;
+  const int n = a.n, m = a.m, nnzP = a.nnzP, nnzA = a.nnzA, pa_len = nnzP + nnzA;
+  const size_t tile = (size_t)(qp / a.BT), b = (size_t)(qp % a.BT), BT = (size_t)a.BT;
+  auto H = [&](size_t len, size_t i) { return (tile * len + i) * BT + b; };
+  double *nv = rz_lds;
+  const int jr = a.raw_by_qp ? qp : jq;
+  const double *rawA = a.rawA + (size_t)jr * nnzA;
+  auto amax = [](double *p, double v) { atomicMax(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v)); };
+  double c = a.dscal[H(DS_COUNT, DS_C)];
+  const double cinv0 = a.dscal[H(DS_COUNT, DS_CINV)];
+  double v[VPT];
+  unsigned slot[VPT];                              // row slot << 16 | column slot
+#pragma unroll
+  for (int i = 0; i < VPT; i++) {
+    const int k = tid + i * NT;
+    double x = 0.0;
+    unsigned sl = 0;
+    if (k < nnzP) {
+      const int r = a.Prow[k], cc = a.Pcol[k];
+      sl = ((unsigned)r << 16) | (unsigned)cc;
+      if (a.fresh) x = a.rawP[(size_t)qp * nnzP + k];
+      else { x = a.pa_val[H(pa_len, k)]; x *= cinv0; x *= a.Dsc_inv[H(n, r)]; x *= a.Dsc_inv[H(n, cc)]; }
+    } else if (k < pa_len) {
+      sl = ((unsigned)(n + a.Arow[k - nnzP]) << 16) | (unsigned)a.Acol[k - nnzP];
+      x = rawA[k - nnzP];
+    }
+    v[i] = x; slot[i] = sl;
+  }
+  if (a.fresh) { for (int j = tid; j < n; j += NT) a.q[H(n, j)] = a.rawq[(size_t)qp * n + j]; }
+  else { for (int j = tid; j < n; j += NT) a.q[H(n, j)] *= cinv0 * a.Dsc_inv[H(n, j)]; }
+  for (int i = tid; i < m; i += NT) {
+    double lo, up;
+    if (a.rawl) { lo = fmax(a.rawl[(size_t)jr * m + i], -MI_INFTY); up = fmin(a.rawu[(size_t)jr * m + i], MI_INFTY); }
+    else { const double ei = a.Esc_inv[H(m, i)]; lo = a.l[H(m, i)] * ei; up = a.u[H(m, i)] * ei; }
+    a.l[H(m, i)] = lo; a.u[H(m, i)] = up;
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += NT) a.Dsc[H(n, j)] = 1.0;
+  for (int i = tid; i < m; i += NT) a.Esc[H(m, i)] = 1.0;
+  c = 1.0;
+  __syncthreads();
+  // norms of the entries below `upto` (nnzP: P alone; pa_len: the whole KKT matrix) into the zeroed nv
+  auto norms = [&](int upto) {
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int k = tid + i * NT;
+      if (k < upto) {
+        const double x = fabs(v[i]);
+        const unsigned s1 = slot[i] >> 16, s0 = slot[i] & 0xffffu;
+        amax(&nv[s0], x);
+        if (s1 != s0) amax(&nv[s1], x);
+      }
+    }
+  };
+  for (int it = 0; it < a.iters; it++) {
+    for (int j = tid; j < n + m; j += NT) nv[j] = 0.0;
+    __syncthreads();
+    norms(pa_len);
+    __syncthreads();
+    for (int j = tid; j < n + m; j += NT) nv[j] = 1.0 / sqrt(ruiz_limit(nv[j]));
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+      const int k = tid + i * NT;
+      if (k < pa_len) { double x = v[i]; x *= nv[slot[i] >> 16]; x *= nv[slot[i] & 0xffffu]; v[i] = x; }
+    }
+    for (int j = tid; j < n; j += NT) { const double d = nv[j]; a.q[H(n, j)] *= d; a.Dsc[H(n, j)] *= d; }
+    for (int i = tid; i < m; i += NT) a.Esc[H(m, i)] *= nv[n + i];
+    __syncthreads();
+    for (int j = tid; j < n; j += NT) nv[j] = 0.0;
+    __syncthreads();
+    norms(nnzP);
+    double nq = 0.0;
+    for (int j = tid; j < n; j += NT) nq = fmax(nq, fabs(a.q[H(n, j)]));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nq = fmax(nq, shfl_xor_d(nq, off));
+    if (lane == 0) s_red[wave] = nq;
+    __syncthreads();
+    if (tid == 0) {
+      double mean = 0.0;                     // added up in index order, like the host does
+      for (int j = 0; j < n; j++) mean += nv[j];
+      mean /= (double)n;
+      double q1 = s_red[0];
+      for (int w = 1; w < NW; w++) q1 = fmax(q1, s_red[w]);
+      q1 = ruiz_limit(q1);
+      const double ct = ruiz_limit(fmax(mean, q1));
+      s_red[15] = 1.0 / ct;
+    }
+    __syncthreads();
+    const double ct = s_red[15];
+#pragma unroll
+    for (int i = 0; i < VPT; i++) { const int k = tid + i * NT; if (k < nnzP) v[i] *= ct; }
+    for (int j = tid; j < n; j += NT) a.q[H(n, j)] *= ct;
+    c *= ct;
+    __syncthreads();
+  }
+  for (int j = tid; j < n; j += NT) a.Dsc_inv[H(n, j)] = 1.0 / a.Dsc[H(n, j)];
+  for (int i = tid; i < m; i += NT) {
+    const double e = a.Esc[H(m, i)];
+    a.Esc_inv[H(m, i)] = 1.0 / e;
+    a.l[H(m, i)] *= e; a.u[H(m, i)] *= e;
+  }
+  if (tid == 0) { a.dscal[H(DS_COUNT, DS_C)] = c; a.dscal[H(DS_COUNT, DS_CINV)] = 1.0 / c; }
+#pragma unroll
+  for (int i = 0; i < VPT; i++) {
+    const int k = tid + i * NT;
+    if (k < pa_len) { a.pa_val[H(pa_len, k)] = v[i]; a.pa_out[(size_t)jq * pa_len + k] = v[i]; }
+  }
+}
+template <int VPT>
+static hipError_t launch_ruiz_reg(const RuizArgs &a, size_t lds, hipStream_t st) {
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(&ruiz_reg_kernel<VPT>), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ruiz_reg_kernel<VPT>, dim3(a.B), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
 hipError_t launch_ruiz(const RuizArgs &a, hipStream_t st) {
   if (a.B <= 0) return hipSuccess;
+  const long pa_len = (long)a.nnzP + a.nnzA;
+  static const bool global_form = getenv("MI_OSQP_RUIZ_GLOBAL") != nullptr;      // (tests: the two forms give the same bits)
+  if (!global_form && (long)a.n + a.m <= 16384 && pa_len <= 32 * 512) {
+    const size_t lds = ((size_t)a.n + a.m) * sizeof(double);
+    if (pa_len <= 4 * 512) return launch_ruiz_reg<4>(a, lds, st);
+    if (pa_len <= 8 * 512) return launch_ruiz_reg<8>(a, lds, st);
+    if (pa_len <= 16 * 512) return launch_ruiz_reg<16>(a, lds, st);
+    return launch_ruiz_reg<32>(a, lds, st);
+  }
   hipLaunchKernelGGL(ruiz_kernel, dim3(a.B), dim3(512), 0, st, a);
   return hipGetLastError();
 }

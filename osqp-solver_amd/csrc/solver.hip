@@ -634,9 +634,10 @@ namespace ancache {
 struct Entry {
   uint64_t hash; int64_t n, m; int nw, bt, max_extra, dt_max, tri_waves; std::string env;
   std::vector<int64_t> Pp, Pi, Ap, Ai;
-  std::shared_ptr<const Analysis> an;
+  std::shared_ptr<const Analysis> an;           // null while a thread is still computing it (mi_osqp_prefetch_analysis): others wait
 };
 static std::mutex mu;
+static std::condition_variable cv;
 static std::vector<Entry> entries;            // most recently used last
 constexpr size_t kMaxEntries = 24;
 static uint64_t fnv(uint64_t h, const void *p, size_t bytes) {
@@ -654,31 +655,43 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
   std::string env;                              // the knobs analyze() reads
   for (const char *k : {"MI_OSQP_DENSE_TAIL", "MI_OSQP_ORDERING", "MI_OSQP_ND_LEAF"}) { const char *v = getenv(k); env += v ? v : "-"; env += ';'; }
   uint64_t hsh = 1469598103934665603ull;
+  auto same = [&](const ancache::Entry &e) {
+    if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.tri_waves != tri_waves || e.env != env) return false;
+    return (int64_t)e.Pi.size() == Pp[n] && (int64_t)e.Ai.size() == Ap[n] && !memcmp(e.Pp.data(), Pp, (size_t)(n + 1) * 8) &&
+           !memcmp(e.Pi.data(), Pi, (size_t)Pp[n] * 8) && !memcmp(e.Ap.data(), Ap, (size_t)(n + 1) * 8) && !memcmp(e.Ai.data(), Ai, (size_t)Ap[n] * 8);
+  };
   if (use) {
     hsh = ancache::fnv(hsh, Pp, (size_t)(n + 1) * 8); hsh = ancache::fnv(hsh, Pi, (size_t)Pp[n] * 8);
     hsh = ancache::fnv(hsh, Ap, (size_t)(n + 1) * 8); hsh = ancache::fnv(hsh, Ai, (size_t)Ap[n] * 8);
-    std::lock_guard<std::mutex> lk(ancache::mu);
-    for (size_t i = 0; i < ancache::entries.size(); i++) {
-      ancache::Entry &e = ancache::entries[i];
-      if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.tri_waves != tri_waves || e.env != env) continue;
-      if ((int64_t)e.Pi.size() != Pp[n] || (int64_t)e.Ai.size() != Ap[n] || memcmp(e.Pp.data(), Pp, (size_t)(n + 1) * 8) ||
-          memcmp(e.Pi.data(), Pi, (size_t)Pp[n] * 8) || memcmp(e.Ap.data(), Ap, (size_t)(n + 1) * 8) || memcmp(e.Ai.data(), Ai, (size_t)Ap[n] * 8)) continue;
-      out = e.an;
+    std::unique_lock<std::mutex> lk(ancache::mu);
+    for (;;) {
+      size_t i = 0;
+      while (i < ancache::entries.size() && !same(ancache::entries[i])) i++;
+      if (i == ancache::entries.size()) break;
+      if (!ancache::entries[i].an) { ancache::cv.wait(lk); continue; }      // being computed by another thread: wait, look again
+      out = ancache::entries[i].an;
       std::rotate(ancache::entries.begin() + i, ancache::entries.begin() + i + 1, ancache::entries.end());
       return MI_OSQP_OK;
     }
+    // ours to compute: a placeholder tells the others
+    if (ancache::entries.size() >= ancache::kMaxEntries) {
+      for (size_t i = 0; i < ancache::entries.size(); i++) if (ancache::entries[i].an) { ancache::entries.erase(ancache::entries.begin() + i); break; }
+    }
+    ancache::entries.push_back(ancache::Entry{hsh, n, m, nw, bt, max_extra, dt_max, tri_waves, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, nullptr});
   }
   auto an = std::make_shared<Analysis>();
   const int rc = analyze(n, m, Pp, Pi, Ap, Ai, *an, nw, bt, max_extra, dt_max, tri_waves);
-  if (rc) return rc;
-  out = an;
+  if (!rc) out = an;
   if (use) {
-    ancache::Entry e{hsh, n, m, nw, bt, max_extra, dt_max, tri_waves, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, out};
     std::lock_guard<std::mutex> lk(ancache::mu);
-    if (ancache::entries.size() >= ancache::kMaxEntries) ancache::entries.erase(ancache::entries.begin());
-    ancache::entries.push_back(std::move(e));
+    for (size_t i = 0; i < ancache::entries.size(); i++)
+      if (!ancache::entries[i].an && same(ancache::entries[i])) {
+        if (rc) ancache::entries.erase(ancache::entries.begin() + i); else ancache::entries[i].an = out;
+        break;
+      }
+    ancache::cv.notify_all();
   }
-  return MI_OSQP_OK;
+  return rc;
 }
 
 static int refactor_qps(mi_osqp_batch *h, std::vector<int> qps);
@@ -704,15 +717,9 @@ static int mw_barrier_ok(mi_osqp_batch *h) {
   return MI_OSQP_OK;
 }
 
-static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
-                            const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai,
-                            const double *Av, const double *l, const double *u, int64_t device) {
-  double t0 = now_s();
-  if (B <= 0 || !Pp || !Ap || (m > 0 && (!l || !u)) || (Pp[n] > 0 && !Pv) || (Ap[n] > 0 && !Av)) return MI_OSQP_ERR_INVALID_DATA;
-  if (validate_settings(h->st)) return MI_OSQP_ERR_INVALID_SETTINGS;
-  if (h->st.adaptive_rho && !h->st.adaptive_rho_interval)   // deterministic "auto" (upstream non-PROFILING rule)
-    h->st.adaptive_rho_interval = h->st.check_termination ? 4 * h->st.check_termination : 100;
-  for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+// The launch shape of a handle (threads per workgroup, QPs per tile, where the solve vector lives, the grid of a large single
+// QP): what the pattern analysis is built for.  Shared by setup and by mi_osqp_prefetch_analysis.
+static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int64_t device, int &BT_out, int &max_extra_out) {
   const char *eth = getenv("MI_OSQP_THREADS");
   h->threads = eth ? std::max(64, std::min(1024, atoi(eth) / 64 * 64)) : 512;
   // ---- tile shape (needed by the schedule layout)
@@ -751,7 +758,6 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     const size_t cap_rows = (lds_cap - lds_bytes(0, BT, h->threads)) / (sizeof(double) * BT);
     max_extra = (int)(cap_rows - (size_t)(n + m));
   }
-  const double ta0 = now_s();
   // dense tail (inverted Schur complement of the trailing rows): needs the LDS vector and <= 512 rows (one row per
   // thread of dense_inverse_kernel; k^3 flops per refactorisation)
   // one QP whose vector lives in global memory: the dataflow form of the solves, shared by several workgroups (one CU
@@ -777,6 +783,22 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     }
     (void)hipGetLastError();
   }
+  BT_out = BT; max_extra_out = max_extra;
+}
+
+static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
+                            const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai,
+                            const double *Av, const double *l, const double *u, int64_t device) {
+  double t0 = now_s();
+  if (B <= 0 || !Pp || !Ap || (m > 0 && (!l || !u)) || (Pp[n] > 0 && !Pv) || (Ap[n] > 0 && !Av)) return MI_OSQP_ERR_INVALID_DATA;
+  if (validate_settings(h->st)) return MI_OSQP_ERR_INVALID_SETTINGS;
+  if (h->st.adaptive_rho && !h->st.adaptive_rho_interval)   // deterministic "auto" (upstream non-PROFILING rule)
+    h->st.adaptive_rho_interval = h->st.check_termination ? 4 * h->st.check_termination : 100;
+  for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  int BT = 1, max_extra = -1;
+  derive_shape(h, B, n, m, device, BT, max_extra);
+  const size_t lds_cap = 160 * 1024 - 1024;
+  const double ta0 = now_s();
   int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), h->anp);
   const double t_analysis = now_s() - ta0;
   if (rc) return rc;
@@ -1450,6 +1472,19 @@ int mi_osqp_batch_setup(mi_osqp_batch **out, int64_t B, int64_t n, int64_t m, co
   if (rc) { delete h; return rc; }
   *out = h;
   return MI_OSQP_OK;
+}
+
+// The pattern analysis a later setup of B QPs with this pattern on this device will ask for, computed now into the
+// process-wide cache (a planner that knows its coming patterns - the ten horizons of a GOMP run - calls this from spare
+// host threads; a setup that arrives while it is still running waits for it instead of computing it twice).
+int mi_osqp_prefetch_analysis(int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap, const int64_t *Ai, int64_t device) {
+  CallTimer timer_("prefetch_analysis");
+  if (B <= 0 || n <= 0 || m < 0 || !Pp || !Ap || (Pp[n] > 0 && !Pi) || (Ap[n] > 0 && !Ai)) return MI_OSQP_ERR_INVALID_DATA;
+  mi_osqp_batch tmp;
+  int BT = 1, max_extra = -1;
+  derive_shape(&tmp, B, n, m, device, BT, max_extra);
+  std::shared_ptr<const Analysis> an;
+  return cached_analysis(n, m, Pp, Pi, Ap, Ai, tmp.threads / 64, BT, max_extra, tmp.global_xs ? 0 : 512, tmp.mw_groups * (tmp.mw_threads / 64), an);
 }
 
 void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }

@@ -16,13 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "mi_osqp.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mi_osqp_[a-z_A-Z0-9]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(mi_(?:osqp|gomp)_[a-z_A-Z0-9]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported():
     L = M.lib()
     names = _declared()
-    assert len(names) >= 30
+    assert len(names) >= 30 and "mi_gomp_relinearise_some" in names and "mi_osqp_prefetch_analysis" in names
     for nme in names:
         assert hasattr(L, nme), f"{nme} declared in include/mi_osqp.h but not exported"
 
@@ -69,3 +69,23 @@ def test_product_does_not_reference_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt and "osqp_oracle" not in txt, f
     for f in ("include/mi_osqp.h",):
         assert "osqp_oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_prefetch_analysis_fills_the_cache_without_a_gpu():
+    """mi_osqp_prefetch_analysis is host work only: it runs here, a second call with the same pattern is a cache hit (much
+    faster), concurrent calls for one pattern all succeed (one computes, the others wait), bad data is refused."""
+    import threading, time
+    from osqp_solver_amd import problems as PR
+    pr = PR.gomp_batch(1, 6, 120)
+    P, A = PR.qp_matrices(pr, 0)
+    t = time.perf_counter(); assert M.prefetch_analysis(P, A) == 0; t_first = time.perf_counter() - t
+    t = time.perf_counter(); assert M.prefetch_analysis(P, A) == 0; t_again = time.perf_counter() - t
+    assert t_again < 0.5 * t_first + 1e-3, (t_first, t_again)
+    pr2 = PR.gomp_batch(1, 6, 130)
+    P2, A2 = PR.qp_matrices(pr2, 0)
+    rcs = []
+    th = [threading.Thread(target=lambda: rcs.append(M.prefetch_analysis(P2, A2))) for _ in range(4)]
+    [x.start() for x in th]; [x.join() for x in th]
+    assert rcs == [0, 0, 0, 0]
+    bad = A.copy(); bad.indices = bad.indices.copy(); bad.indices[0] = A.shape[0] + 5
+    assert M.prefetch_analysis(P, bad, check=False) != 0
