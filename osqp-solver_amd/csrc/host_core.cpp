@@ -976,7 +976,7 @@ static void build_block_factor(Analysis &an) {
 // --------------------------------------------------------------------- analyze
 
 int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
-            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows, int dense_tail_max, int tri_waves) {
+            const int64_t *Ai, Analysis &an, int nwaves, int bt, int max_extra_rows, int dense_tail_max, int tri_waves, int n_tiles) {
   if (nwaves < 1 || nwaves > 16 || (bt != 1 && bt != 2 && bt != 4) || tri_waves < 0 || tri_waves > 2048) return MI_OSQP_ERR_INVALID_SETTINGS;
   if (n64 <= 0 || m64 < 0 || !Pp || !Ap || n64 + m64 > (int64_t)1 << 30) return MI_OSQP_ERR_INVALID_DATA;
   int n = (int)n64, m = (int)m64, N = n + m;
@@ -1028,7 +1028,8 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
   an.wide = N >= 65535 || 2 * n + m >= 65535 || tri_waves > 0;        // (the dataflow form doubles the index range)
   if (max_extra_rows < 0) max_extra_rows = 1 << 30;       // (also the budget of the dense tail's two accumulation vectors)
   if (!an.wide && max_extra_rows > 65534 - N) max_extra_rows = 65534 - N;
-  auto finalize = [&](Analysis &an, const std::vector<int> &perm0, double &cost) {
+  // (relax_zeros = explicit zeros a relaxed supernode may hold; 0 = fundamental supernodes only)
+  auto finalize = [&](Analysis &an, const std::vector<int> &perm0, double &cost, int relax_zeros = 0, int *phases_out = nullptr, double *stream_out = nullptr) {
     an.perm = perm0;
     an.pinv.assign(N, 0);
     for (int k = 0; k < N; k++) an.pinv[an.perm[k]] = k;
@@ -1046,6 +1047,31 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     build_permuted_lower(an);
     symbolic(an, cols, parent);
     an.etree = parent;
+    // Relaxed supernodes: a chain j -> j+1 -> ... of the elimination tree whose columns have ALMOST the same structure becomes
+    // one supernode by storing explicit zeros (column c takes the structure {c+1 .. e} u struct(e) of the chain's last column;
+    // still a closed symbolic factor).  The factors of the trajectory QPs are made of hundreds of one- and two-column
+    // supernodes - every one a level of the sweeps and a handful of 2-entry block tasks of the refactorisation.
+    if (relax_zeros > 0) {
+      auto close = [&](int s0, int e) {
+        for (int c = s0; c < e; c++) {
+          std::vector<int> ns;
+          ns.reserve((size_t)(e - c) + cols[e].size());
+          for (int r = c + 1; r <= e; r++) ns.push_back(r);
+          ns.insert(ns.end(), cols[e].begin(), cols[e].end());
+          cols[c].swap(ns);
+        }
+      };
+      int s0 = 0;
+      for (int j = 0; j < N; j++) {
+        bool extend = false;
+        if (j + 1 < N && parent[j] == j + 1 && j + 2 - s0 <= kChunk) {
+          long z = 0;
+          for (int c = s0; c <= j; c++) z += (long)(j + 1 - c) + (long)cols[j + 1].size() - (long)cols[c].size();
+          extend = z <= relax_zeros;
+        }
+        if (!extend) { if (j > s0) close(s0, j); s0 = j + 1; }
+      }
+    }
     an.Lp.assign(N + 1, 0);
     for (int j = 0; j < N; j++) an.Lp[j + 1] = an.Lp[j] + (int)cols[j].size();
     an.Li.resize(an.Lp[N]);
@@ -1130,6 +1156,8 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     for (int L = 0; L < depth; L++) phases += blocks_at[L] ? 1 : 0;
     const double stream = 2.0 * (double)(an.Lp[N] - tail_nnz_used) + 0.5 * (double)an.dt.k * an.dt.k;   // values read per solve
     cost = (2.0 * phases + (an.dt.k ? an.dt.k / 128 + 3 : 0)) * 0.4e-6 + 8.0 * bt * 1.15 * stream / 40e9;
+    if (phases_out) *phases_out = 2 * phases + (an.dt.k ? an.dt.k / 128 + 3 : 0);
+    if (stream_out) *stream_out = 8.0 * bt * 1.15 * stream;
   };
   {
     const bool dbg_t = getenv("MI_OSQP_DEBUG_ORDER") != nullptr;
@@ -1142,7 +1170,12 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     // forces one size).  The cheapest by the modelled time of one KKT solve wins; ties go to the earlier candidate.
     // Every candidate (ordering + symbolic analysis of its permutation) runs on a host thread of its own, on its own copy of
     // the analysis so far (the 802-waypoint example: 155 -> 60 ms of the 220 ms a setup spends here).
-    struct Cand { std::vector<int> perm; double cost = 0.0; int leaf = 0; Analysis an; double t_order = 0.0, t_final = 0.0; };      // leaf 0 = minimum degree
+    struct Cand {
+      std::vector<int> perm; int leaf = 0;       // leaf 0 = minimum degree
+      Analysis an, rel;                         // with fundamental / relaxed supernodes
+      double cost = 0.0, cost_rel = 0.0; int phases = 0, phases_rel = 0; double stream = 0.0, stream_rel = 0.0;
+      double t_order = 0.0, t_final = 0.0;
+    };
     std::vector<Cand> cands;
     const bool try_md = (N <= 60000 && !(force && force[0] == 'n')) || (force && force[0] == 'm');
     if (try_md) cands.emplace_back();
@@ -1155,12 +1188,19 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
       else leaves = {48};
       for (int lf : leaves) { cands.emplace_back(); cands.back().leaf = lf; }
     }
+    // Relaxed supernodes are a second form of every candidate: fewer phases per sweep (and a third fewer block tasks per
+    // refactorisation) against a longer factor stream.  MI_OSQP_RELAX = 0: never, = z: always, up to z zeros per supernode;
+    // default: decided below.  Barrier form only.
+    const char *er = getenv("MI_OSQP_RELAX");
+    const int relax_forced = er ? atoi(er) : -1;
+    const int relax_z = (relax_forced != 0 && tri_waves == 0 && N <= 60000) ? (relax_forced > 0 ? relax_forced : 16) : 0;
     auto run_cand = [&](Cand &c) {
       double t0 = now_();
       c.an = an;
       if (c.leaf) nested_dissection(N, an.Kp, an.Ki, c.perm, c.leaf); else min_degree(N, an.Kp, an.Ki, c.perm);
       c.t_order = now_() - t0; t0 = now_();
-      finalize(c.an, c.perm, c.cost);
+      if (relax_forced <= 0) finalize(c.an, c.perm, c.cost, 0, &c.phases, &c.stream);
+      if (relax_z) { c.rel = an; finalize(c.rel, c.perm, c.cost_rel, relax_z, &c.phases_rel, &c.stream_rel); }
       c.t_final = now_() - t0;
     };
     if (cands.size() > 1 && N >= 1000 && !getenv("MI_OSQP_SERIAL_ANALYSIS")) {
@@ -1169,14 +1209,35 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
       run_cand(cands[0]);
       for (auto &t : th) t.join();
     } else for (Cand &c : cands) run_cand(c);
-    size_t best = 0;
+    // 1. the cheapest candidate with fundamental supernodes (modelled time of one KKT solve of a lone tile);
+    // 2. against it the cheapest relaxed candidate, both priced with the stream rate a tile of THIS batch gets: the tiles
+    //    share the memory system - a lone tile streams ~40 GB/s, 256 of them ~16 GB/s each (measured per iteration with
+    //    MI_OSQP_RELAX forced, scripts/tail_latency_probe.py: 256 x 3-DOF x 60 waypoints 23.8 -> 20.9 us relaxed, 256 x 7-DOF
+    //    x 100 waypoints 39.7 -> 47.8 us).
+    const double rate = std::min(40e9, 4e12 / std::max(1, n_tiles));
+    auto priced = [&](int phases, double stream) { return phases * 0.4e-6 + stream / rate; };
+    size_t best = 0, best_rel = 0;
     for (size_t c = 0; c < cands.size(); c++) {
-      if (dbg_t) fprintf(stderr, "[mi_osqp] ordering candidate %s leaf %d: modelled solve %.3e s, nnz(L) %d (ordering %.1f ms, symbolic %.1f ms)\n", cands[c].leaf ? "nd" : "md",
-                         cands[c].leaf, cands[c].cost, cands[c].an.Lp[N], 1e3 * cands[c].t_order, 1e3 * cands[c].t_final);
+      if (dbg_t) fprintf(stderr, "[mi_osqp] ordering candidate %s leaf %d: modelled solve %.3e s, nnz(L) %d, %d phases; relaxed (%d zeros): %d phases, stream x %.2f (ordering %.1f ms, symbolic %.1f ms)\n",
+                         cands[c].leaf ? "nd" : "md", cands[c].leaf, cands[c].cost, relax_forced <= 0 ? cands[c].an.Lp[N] : 0, cands[c].phases, relax_z, cands[c].phases_rel,
+                         cands[c].stream > 0 ? cands[c].stream_rel / cands[c].stream : 0.0, 1e3 * cands[c].t_order, 1e3 * cands[c].t_final);
       if (cands[c].cost < cands[best].cost) best = c;
+      if (relax_z && priced(cands[c].phases_rel, cands[c].stream_rel) < priced(cands[best_rel].phases_rel, cands[best_rel].stream_rel)) best_rel = c;
+    }
+    bool take_rel = relax_forced > 0;
+    if (relax_z && relax_forced < 0) {
+      const double t0 = priced(cands[best].phases, cands[best].stream), t1 = priced(cands[best_rel].phases_rel, cands[best_rel].stream_rel);
+      take_rel = t1 < 0.97 * t0;
+      if (dbg_t) fprintf(stderr, "[mi_osqp] at %.0f GB/s per tile (%d tiles): fundamental %s leaf %d %.2f us, relaxed %s leaf %d %.2f us -> %s\n", rate / 1e9, n_tiles,
+                         cands[best].leaf ? "nd" : "md", cands[best].leaf, 1e6 * t0, cands[best_rel].leaf ? "nd" : "md", cands[best_rel].leaf, 1e6 * t1, take_rel ? "relaxed" : "fundamental");
     }
     if (dbg_t) { fprintf(stderr, "[mi_osqp] ordering candidates x %zu %.1f ms\n", cands.size(), 1e3 * (now_() - tt)); tt = now_(); }
-    { const int leaf = cands[best].leaf; Analysis chosen = std::move(cands[best].an); an = std::move(chosen); an.ordering = leaf ? 1 : 0; }
+    {
+      Cand &w = cands[take_rel ? best_rel : best];
+      const int leaf = w.leaf;
+      Analysis chosen = std::move(take_rel ? w.rel : w.an);
+      an = std::move(chosen); an.ordering = leaf ? 1 : 0; an.relaxed_zeros = take_rel ? relax_z : 0;
+    }
   }
   if (tri_waves > 0 && (bt != 1 || an.dt.k)) return MI_OSQP_ERR_INVALID_SETTINGS;
   {

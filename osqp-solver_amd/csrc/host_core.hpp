@@ -169,6 +169,7 @@ struct Analysis {
   // fill-reducing permutation (perm[new] = old)
   std::vector<int> perm, pinv;
   int ordering = 0;                // 0 minimum degree, 1 nested dissection (picked by analyze())
+  int relaxed_zeros = 0;           // > 0: relaxed supernodes with up to that many explicit zeros each (picked by analyze())
   // permuted KKT, lower triangle by columns, and map natural entry -> position
   std::vector<int> Klp, Kli, KtoKl;
   // symbolic factor: strictly-lower L by columns (sorted rows) + row view
@@ -226,7 +227,9 @@ struct Analysis {
 // (one workgroup of nwaves waves per tile).
 int analyze(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
             const int64_t *Ai, Analysis &an, int nwaves = 8, int bt = 1, int max_extra_rows = -1,
-            int dense_tail_max = 512, int tri_waves = 0);
+            int dense_tail_max = 512, int tri_waves = 0, int n_tiles = 1);
+// `n_tiles` = tiles of the batch the analysis is for (they share the device's memory bandwidth: the decision for relaxed
+// supernodes weighs fewer phases against a longer factor stream).
 // physical position (in doubles, inside one tile) of QP b's value of a logical slot
 size_t phys_index(const Schedule &s, uint32_t slot, int b);
 

@@ -632,7 +632,7 @@ static int reset_solve_state(mi_osqp_batch *h, bool cold) {
 // by a full comparison) and shared read-only between handles.  MI_OSQP_ANALYSIS_CACHE=0 switches the cache off.
 namespace ancache {
 struct Entry {
-  uint64_t hash; int64_t n, m; int nw, bt, max_extra, dt_max, tri_waves; std::string env;
+  uint64_t hash; int64_t n, m; int nw, bt, max_extra, dt_max, tri_waves, n_tiles; std::string env;
   std::vector<int64_t> Pp, Pi, Ap, Ai;
   std::shared_ptr<const Analysis> an;           // null while a thread is still computing it (mi_osqp_prefetch_analysis): others wait
 };
@@ -648,15 +648,16 @@ static uint64_t fnv(uint64_t h, const void *p, size_t bytes) {
 }  // namespace ancache
 
 static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap, const int64_t *Ai, int nw,
-                           int bt, int max_extra, int dt_max, int tri_waves, std::shared_ptr<const Analysis> &out) {
+                           int bt, int max_extra, int dt_max, int tri_waves, int n_tiles, std::shared_ptr<const Analysis> &out) {
+  n_tiles = n_tiles <= 1 ? 1 : (n_tiles <= 32 ? 32 : (n_tiles <= 128 ? 128 : (n_tiles <= 256 ? 256 : 512)));      // (buckets: the analysis is shared between handles)
   const char *off = getenv("MI_OSQP_ANALYSIS_CACHE");
   const bool use = !(off && atoi(off) == 0) && n > 0 && m >= 0 && Pp && Ap && Pp[0] == 0 && Ap[0] == 0 && Pp[n] >= 0 && Ap[n] >= 0 &&
                    Pp[n] < ((int64_t)1 << 30) && Ap[n] < ((int64_t)1 << 30);
   std::string env;                              // the knobs analyze() reads
-  for (const char *k : {"MI_OSQP_DENSE_TAIL", "MI_OSQP_ORDERING", "MI_OSQP_ND_LEAF"}) { const char *v = getenv(k); env += v ? v : "-"; env += ';'; }
+  for (const char *k : {"MI_OSQP_DENSE_TAIL", "MI_OSQP_ORDERING", "MI_OSQP_ND_LEAF", "MI_OSQP_RELAX"}) { const char *v = getenv(k); env += v ? v : "-"; env += ';'; }
   uint64_t hsh = 1469598103934665603ull;
   auto same = [&](const ancache::Entry &e) {
-    if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.tri_waves != tri_waves || e.env != env) return false;
+    if (e.hash != hsh || e.n != n || e.m != m || e.nw != nw || e.bt != bt || e.max_extra != max_extra || e.dt_max != dt_max || e.tri_waves != tri_waves || e.n_tiles != n_tiles || e.env != env) return false;
     return (int64_t)e.Pi.size() == Pp[n] && (int64_t)e.Ai.size() == Ap[n] && !memcmp(e.Pp.data(), Pp, (size_t)(n + 1) * 8) &&
            !memcmp(e.Pi.data(), Pi, (size_t)Pp[n] * 8) && !memcmp(e.Ap.data(), Ap, (size_t)(n + 1) * 8) && !memcmp(e.Ai.data(), Ai, (size_t)Ap[n] * 8);
   };
@@ -677,10 +678,10 @@ static int cached_analysis(int64_t n, int64_t m, const int64_t *Pp, const int64_
     if (ancache::entries.size() >= ancache::kMaxEntries) {
       for (size_t i = 0; i < ancache::entries.size(); i++) if (ancache::entries[i].an) { ancache::entries.erase(ancache::entries.begin() + i); break; }
     }
-    ancache::entries.push_back(ancache::Entry{hsh, n, m, nw, bt, max_extra, dt_max, tri_waves, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, nullptr});
+    ancache::entries.push_back(ancache::Entry{hsh, n, m, nw, bt, max_extra, dt_max, tri_waves, n_tiles, env, {Pp, Pp + n + 1}, {Pi, Pi + Pp[n]}, {Ap, Ap + n + 1}, {Ai, Ai + Ap[n]}, nullptr});
   }
   auto an = std::make_shared<Analysis>();
-  const int rc = analyze(n, m, Pp, Pi, Ap, Ai, *an, nw, bt, max_extra, dt_max, tri_waves);
+  const int rc = analyze(n, m, Pp, Pi, Ap, Ai, *an, nw, bt, max_extra, dt_max, tri_waves, n_tiles);
   if (!rc) out = an;
   if (use) {
     std::lock_guard<std::mutex> lk(ancache::mu);
@@ -799,7 +800,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   derive_shape(h, B, n, m, device, BT, max_extra);
   const size_t lds_cap = 160 * 1024 - 1024;
   const double ta0 = now_s();
-  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), h->anp);
+  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), (int)((B + BT - 1) / BT), h->anp);
   const double t_analysis = now_s() - ta0;
   if (rc) return rc;
   const Analysis &an = (*h->anp);
@@ -1484,7 +1485,7 @@ int mi_osqp_prefetch_analysis(int64_t B, int64_t n, int64_t m, const int64_t *Pp
   int BT = 1, max_extra = -1;
   derive_shape(&tmp, B, n, m, device, BT, max_extra);
   std::shared_ptr<const Analysis> an;
-  return cached_analysis(n, m, Pp, Pi, Ap, Ai, tmp.threads / 64, BT, max_extra, tmp.global_xs ? 0 : 512, tmp.mw_groups * (tmp.mw_threads / 64), an);
+  return cached_analysis(n, m, Pp, Pi, Ap, Ai, tmp.threads / 64, BT, max_extra, tmp.global_xs ? 0 : 512, tmp.mw_groups * (tmp.mw_threads / 64), (int)((B + BT - 1) / BT), an);
 }
 
 void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }
