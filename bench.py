@@ -371,6 +371,18 @@ def obstacle_scene_entry(with_cpu):
          "value": kv["trajectories_per_s"], "unit": "trajectories/s", "ms": 1e3 * kv["run_s"], "first_run_ms": 1e3 * kv["first_run_s"],
          "qp_solves": int(kv["qp_solves"]), "qp_updates": int(kv["qp_updates"]), "advances": int(kv["advances"]),
          "all_optimal": int(kv["optimal"]) == int(kv["trajectories"])}
+    # the same run with the SQP step on the device (mi_gomp_scene: FK / Jacobians, row assembly, acceptance test, update from
+    # device-resident rows): trajectories equal to round-off (device sin / cos), same solve / update counts
+    try:
+        r2 = subprocess.run([exe, "contbench", "256", "100", "0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, GOMP_DEVICE_ASSEMBLY="1"))
+        l2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("CONTBENCH device_assembly")]
+        if r2.returncode == 0 and l2:
+            t2 = l2[0].split()
+            k2 = {t2[i]: float(t2[i + 1]) for i in range(1, len(t2) - 1, 2)}
+            e["device_assembly"] = {"value": k2["trajectories_per_s"], "unit": "trajectories/s", "ms": 1e3 * k2["run_s"], "qp_solves": int(k2["qp_solves"]),
+                                    "qp_updates": int(k2["qp_updates"]), "all_optimal": int(k2["optimal"]) == int(k2["trajectories"])}
+    except Exception as ex:          # (secondary figure: never fails the bench line)
+        e["device_assembly"] = {"error": repr(ex)[:200]}
     if with_cpu and kv.get("oracle_sample", 0) > 0:
         e["cpu_baseline"] = {"value": kv["oracle_trajectories_per_s"], "unit": "trajectories/s", "cores": 1, "kind": "port",
                              "sample": "the first %d trajectories, sequential GOMPSolver on the oracle, one thread; same exit codes and "

@@ -852,6 +852,20 @@ static void build_block_factor(Analysis &an) {
       }
     bf.lvl.insert(bf.lvl.end(), {u0, (uint32_t)(bf.utask.size() / 4), d0, (uint32_t)bf.dtask.size(), t0, (uint32_t)(bf.ttask.size() / 2)});
   }
+  bf.utask4.resize(bf.utask.size());
+  for (size_t t = 0; t < bf.utask.size() / 4; t++) {
+    const uint32_t id = bf.utask[4 * t], tb = bf.utask[4 * t + 1], tm = bf.utask[4 * t + 2], te = bf.utask[4 * t + 3];
+    const uint32_t hw = bf.blk[4 * id + 3];
+    if (tm - tb >= (1u << 22)) bf.overflow = true;                // (4 M one-column sources of one block: analyze() refuses the pattern)
+    bf.utask4[4 * t] = bf.blk[4 * id]; bf.utask4[4 * t + 1] = tb; bf.utask4[4 * t + 2] = ((hw >> 8) << 27) | ((hw & 255u) << 22) | ((tm - tb) & 0x3FFFFFu); bf.utask4[4 * t + 3] = te - tm;
+  }
+  bf.dtask4.resize(4 * bf.dtask.size());
+  for (size_t t = 0; t < bf.dtask.size(); t++) for (int k = 0; k < 4; k++) bf.dtask4[4 * t + k] = bf.blk[4 * bf.dtask[t] + k];
+  bf.ttask4.resize(2 * bf.ttask.size());
+  for (size_t t = 0; t < bf.ttask.size() / 2; t++) {
+    const uint32_t id = bf.ttask[2 * t], dg = bf.ttask[2 * t + 1];
+    bf.ttask4[4 * t] = bf.blk[4 * id]; bf.ttask4[4 * t + 1] = bf.blk[4 * id + 2]; bf.ttask4[4 * t + 2] = bf.blk[4 * id + 3]; bf.ttask4[4 * t + 3] = bf.blk[4 * dg];
+  }
   bf.tri4.resize(2 * bf.tri.size());
   for (size_t q = 0; q < bf.tri.size() / 2; q++) {
     const uint32_t ia = bf.tri[2 * q], ib = bf.tri[2 * q + 1];
@@ -1193,7 +1207,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     // default: decided below.  Barrier form only.
     const char *er = getenv("MI_OSQP_RELAX");
     const int relax_forced = er ? atoi(er) : -1;
-    const int relax_z = (relax_forced != 0 && tri_waves == 0 && N <= 60000) ? (relax_forced > 0 ? relax_forced : 16) : 0;
+    const int relax_z = relax_forced > 0 ? relax_forced : ((relax_forced < 0 && tri_waves == 0 && N <= 60000) ? 16 : 0);      // (forcing works for every form: experiments)
     auto run_cand = [&](Cand &c) {
       double t0 = now_();
       c.an = an;
@@ -1257,6 +1271,7 @@ int analyze(int64_t n64, int64_t m64, const int64_t *Pp, const int64_t *Pi, cons
     const double t_tri = now_() - t0;
     bf_part();
     if (par) th_chk.join(); else chk_part();
+    if (an.bf.overflow) return MI_OSQP_ERR_INVALID_DATA;
     if (dbg_t) fprintf(stderr, "[mi_osqp] tables: solve schedules + dense tail %.1f ms, check schedule %.1f ms, block factor %.1f ms; wall %.1f ms\n",
                        1e3 * t_tri, 1e3 * t_chk, 1e3 * t_bf, 1e3 * (now_() - t0));
   }

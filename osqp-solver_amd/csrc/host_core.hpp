@@ -93,6 +93,11 @@ struct BlockFactor {
   std::vector<uint32_t> tri;          // 2/triple: block (I,K), block (J,K)
   std::vector<uint32_t> tri4;         // 4/triple, resolved for the device (one 16-byte load instead of a chain of three):
                                       // offset of (I,K), offset of (J,K), first column of K, (h_I << 16) | (w_K << 8) | h_J
+  std::vector<uint32_t> utask4;       // DEVICE form, 4/task (one 16-byte load, no second look-up): offset of the target block, tri_begin,
+                                      // (h << 27) | (w << 22) | rank-1 triples, general triples
+  bool overflow = false;              // a count that does not fit its field of the device form
+  std::vector<uint32_t> dtask4;       // DEVICE form, 4/task: the blk tuple of the diagonal block
+  std::vector<uint32_t> ttask4;       // DEVICE form, 4/task: offset of the block, first column of its chunk, (h << 8) | w, offset of the diagonal block
   std::vector<uint32_t> dtask;        // diagonal block ids
   std::vector<uint32_t> ttask;        // 2/task : block id, diagonal block id
   std::vector<uint32_t> asm_dst;      // per natural KKT entry: position in block storage

@@ -1595,17 +1595,15 @@ __device__ __forceinline__ void wave_sync() {
 
 template <int BT>
 __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, const double *Dl, double *Ss,
-                                           uint32_t t, int lane) {
+                                           const uint4 ud, int lane) {
   // lane = (h, i, b): i = row of the <=16-row target block, b = QP of the tile, and h splits the
   // source work (the k range of a source block / the members of a rank-1 batch) over the 64/(16*BT)
   // lane groups that would otherwise idle; the partial results are summed at the end.
   // (Software-pipelining the operand loads across batches was tried: it spills at 128 VGPRs and is slower.)
   constexpr int H = 64 / (MI_CHUNK * BT);
-  mi_cptr ut = as_const(a.utask) + 4 * (size_t)t;
-  mi_cptr blk = as_const(a.blk);
   mi_cptr tri4 = as_const(a.tri4);        // resolved triples: {offset A, offset B, first column of K, (h_A << 16) | (w_K << 8) | h_B}
-  const uint32_t tid_blk = ut[0], q0 = ut[1], qm = ut[2], q1 = ut[3];
-  const uint32_t off = blk[4 * tid_blk], hw = blk[4 * tid_blk + 3], h = hw >> 8, w = hw & 255u;
+  // the task's descriptor (BlockFactor::utask4) arrives in registers: the caller loads the next one while this task runs
+  const uint32_t off = ud.x, q0 = ud.y, qm = q0 + (ud.z & 0x3FFFFFu), q1 = qm + ud.w, h = ud.z >> 27, w = (ud.z >> 22) & 31u;
   const int hh = lane / (MI_CHUNK * BT), i = (lane / BT) % MI_CHUNK, b = lane % BT;
   const bool row_ok = (uint32_t)i < h;
   double acc[MI_CHUNK];
@@ -1689,8 +1687,7 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
 
 template <int BT>
 __device__ __forceinline__ void fct_diag(const FactorArgs &a, double *Lb, double *Dl, double *dinv, double *Ss,
-                                         uint32_t t, int lane, int &npos) {
-  const uint4 tb = reinterpret_cast<const uint4 *>(a.blk)[a.dtask[t]];
+                                         const uint4 tb, int lane, int &npos) {
   const uint32_t off = tb.x, c0 = tb.z, w = tb.w & 255u;
   const int i = lane / BT, b = lane % BT;
   const bool ok = (uint32_t)i < w && lane < MI_CHUNK * BT;
@@ -1742,16 +1739,14 @@ __device__ __forceinline__ void fct_diag(const FactorArgs &a, double *Lb, double
 
 template <int BT>
 __device__ __forceinline__ void fct_trsm(const FactorArgs &a, double *Lb, const double *Dl, const double *dinv,
-                                         double *Ss, uint32_t t, int lane) {
-  const uint2 tt = reinterpret_cast<const uint2 *>(a.ttask)[t];
-  const uint4 tb = reinterpret_cast<const uint4 *>(a.blk)[tt.x];
-  const uint4 db = reinterpret_cast<const uint4 *>(a.blk)[tt.y];
-  const uint32_t off = tb.x, h = tb.w >> 8, w = tb.w & 255u, c0 = tb.z;
+                                         double *Ss, const uint4 td, int lane) {
+  const uint32_t off = td.x, h = td.z >> 8, w = td.z & 255u, c0 = td.y;
+  const uint32_t db_off = td.w;
   const int i = lane / BT, b = lane % BT;
   // stage the diagonal block: Ss(k, b, j) = L_JJ[j,k] (strictly lower)
   if (lane < MI_CHUNK * BT) {
     for (uint32_t k = 0; k < w; k++)
-      Ss[MI_BS(k, b, i)] = ((uint32_t)i < w && (uint32_t)i > k) ? Lb[((size_t)db.x + k * w + i) * BT + b] : 0.0;
+      Ss[MI_BS(k, b, i)] = ((uint32_t)i < w && (uint32_t)i > k) ? Lb[((size_t)db_off + k * w + i) * BT + b] : 0.0;
   }
   wave_sync();
   if ((uint32_t)i < h && lane < MI_CHUNK * BT) {
@@ -1858,14 +1853,37 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
   else dnew = a.dinv_scratch + (size_t)tile * N * BT;
   for (int L = 0; L < a.n_levels; L++) {
     const uint32_t *lv = a.lvl + 6 * L;
+    // (task descriptors: one 16-byte load each, requested one task ahead - a lone QP is a chain of dependent memory round
+    //  trips, and descriptor -> block table -> operands used to be three of them per task)
+    const uint4 *ut4 = reinterpret_cast<const uint4 *>(a.utask), *dt4 = reinterpret_cast<const uint4 *>(a.dtask), *tt4 = reinterpret_cast<const uint4 *>(a.ttask);
     if (lv[1] > lv[0]) {
-      for (uint32_t t = lv[0] + wave; t < lv[1]; t += nw) fct_update<BT>(a, Lb, Dl, Ss, t, lane);
+      uint32_t t = lv[0] + wave;
+      uint4 nxt = t < lv[1] ? ut4[t] : make_uint4(0, 0, 0, 0);
+      for (; t < lv[1]; t += nw) {
+        const uint4 cur = nxt;
+        if (t + nw < lv[1]) nxt = ut4[t + nw];
+        fct_update<BT>(a, Lb, Dl, Ss, cur, lane);
+      }
       sync();
     }
-    if (!(MI_DBG_SKIP(a) & 4)) for (uint32_t t = lv[2] + wave; t < lv[3]; t += nw) fct_diag<BT>(a, Lb, Dl, dnew, Ss, t, lane, npos);
+    if (!(MI_DBG_SKIP(a) & 4)) {
+      uint32_t t = lv[2] + wave;
+      uint4 nxt = t < lv[3] ? dt4[t] : make_uint4(0, 0, 0, 0);
+      for (; t < lv[3]; t += nw) {
+        const uint4 cur = nxt;
+        if (t + nw < lv[3]) nxt = dt4[t + nw];
+        fct_diag<BT>(a, Lb, Dl, dnew, Ss, cur, lane, npos);
+      }
+    }
     sync();
     if (lv[5] > lv[4] && !(MI_DBG_SKIP(a) & 8)) {
-      for (uint32_t t = lv[4] + wave; t < lv[5]; t += nw) fct_trsm<BT>(a, Lb, Dl, dnew, Ss, t, lane);
+      uint32_t t = lv[4] + wave;
+      uint4 nxt = t < lv[5] ? tt4[t] : make_uint4(0, 0, 0, 0);
+      for (; t < lv[5]; t += nw) {
+        const uint4 cur = nxt;
+        if (t + nw < lv[5]) nxt = tt4[t + nw];
+        fct_trsm<BT>(a, Lb, Dl, dnew, Ss, cur, lane);
+      }
       sync();
     }
   }

@@ -868,8 +868,8 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
   {
     const BlockFactor &bf = an.bf;
-    if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_utask.upload(bf.utask)) ||
-        (rc = h->bf_tri.upload(bf.tri4)) || (rc = h->bf_dtask.upload(bf.dtask)) || (rc = h->bf_ttask.upload(bf.ttask)) ||
+    if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_utask.upload(bf.utask4)) ||
+        (rc = h->bf_tri.upload(bf.tri4)) || (rc = h->bf_dtask.upload(bf.dtask4)) || (rc = h->bf_ttask.upload(bf.ttask4)) ||
         (rc = h->bf_asm_dst.upload(bf.asm_dst)) || (rc = h->bf_asm_src.upload(bf.asm_src)) ||
         (rc = h->fwd_srcblk.upload(an.fwd_srcblk)) || (rc = h->bwd_srcblk.upload(an.bwd_srcblk))) return rc;
     if ((rc = h->pa_val.alloc((size_t)(an.Pp[n] + an.Ap[n]) * T)) || (rc = h->pa_val.zero(h->stream)) ||
