@@ -10,8 +10,13 @@ if len(sys.argv) > 4:
     M = importlib.import_module("osqp-solver_amd")
     PR = importlib.import_module("osqp-solver_amd.problems")
     B, D, W = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-    pr = PR.gomp_batch(B, D, W)
-    s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
+    if D == 0:                   # D = 0: the random QPs of the headline batch (config 3), W ignored
+        pr = PR.random_box_qp(1024)
+        for k in ("Px", "Ax", "q", "l", "u"): pr[k] = pr[k][:B]
+        s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    else:
+        pr = PR.gomp_batch(B, D, W)
+        s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
     ts = []
     for k in range(5):
         torch.cuda.synchronize(); t = time.perf_counter()
