@@ -718,3 +718,41 @@ def test_forced_dense_tail_on_gomp_matches_oracle(k, monkeypatch):
     st, xo = o.solve()
     assert code == 0 and st == 1 and s.info().iter == o.info().iter
     assert np.max(np.abs(x - xo)) <= TOL_X
+
+
+# ---- relaxed supernodes (explicit zeros merge chains of near-identical columns; analyze() decides, MI_OSQP_RELAX forces)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 6, 50), (5, 3, 40)])
+def test_relaxed_and_fundamental_supernodes_agree_and_match_oracle(shape, monkeypatch):
+    """The factor with relaxed supernodes holds the same numbers plus exact zeros: solves, the refactorisation after an
+    update of A and the bounds, and the rho updates of a long solve take the same iterations either way (x within 1e-9) and
+    match the oracle; the relaxed form has fewer phases per sweep."""
+    B, D, W = shape
+    pr = PR.gomp_batch(B, D, W)
+    res, phases = {}, {}
+    rng = np.random.default_rng(4)
+    Ax2 = pr["Ax"] * (1.0 + 0.05 * rng.standard_normal(pr["Ax"].shape))
+    for relax in ("0", "16"):
+        monkeypatch.setenv("MI_OSQP_RELAX", relax)
+        s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"], eps_abs=1e-7, eps_rel=1e-7)
+        st = s.stats()
+        phases[relax] = st["fwd_levels"] + st["bwd_levels"]
+        s.warm_start_x(pr["warm"])
+        info = s.solve(); x1 = s.primal().copy()
+        s.update_A_bounds(Ax2, pr["l"] * 0.9, pr["u"] * 0.9)
+        info2 = s.solve()
+        res[relax] = ([i.iter for i in info], x1, [i.iter for i in info2], s.primal().copy(), [i.rho_updates for i in info2], [i.exit_code for i in info2])
+        if relax == "16":
+            for b in range(B):
+                P, A = PR.qp_matrices(pr, b)
+                o = O.OracleQPSolver(P, None, A, pr["l"][b], pr["u"][b], eps_abs=1e-7, eps_rel=1e-7)
+                o.set_warm_start(pr["warm"][b])
+                sto, xo = o.solve()
+                assert info[b].exit_code == 0 and sto == 1 and info[b].iter == o.info().iter
+                assert np.max(np.abs(x1[b] - xo)) <= TOL_X
+        s.close()
+    assert phases["16"] < phases["0"]
+    a, r = res["0"], res["16"]
+    assert a[0] == r[0] and a[2] == r[2] and a[4] == r[4] and a[5] == r[5]
+    assert np.max(np.abs(a[1] - r[1])) <= 1e-9 and np.max(np.abs(a[3] - r[3])) <= 1e-9
