@@ -191,6 +191,9 @@ void mi_osqp_release_device_cache(void);
  * check run on the device (no refactor happens unless a type changes, in which
  * case the call returns through the host path transparently). */
 int mi_osqp_batch_update_bounds_device(mi_osqp_batch *h, const double *d_l, const double *d_u, void *stream);
+/* QPSolver::update ([REF] src/osqp-wrapper.h:33-43) with the new A values ([B][nnzA], CSC order of setup's pattern) and bounds
+ * ([B][m]) in HBM; `stream`: the stream that wrote them (NULL: none pending) */
+int mi_osqp_batch_update_A_bounds_device(mi_osqp_batch *h, const double *d_Av, const double *d_l, const double *d_u, void *stream);
 /* Solve and leave x[B][n] (and optionally status[B]/iters[B], int32) in HBM. */
 int mi_osqp_batch_solve_device(mi_osqp_batch *h, double *d_x_out, int32_t *d_status, int32_t *d_iters, void *stream);
 /* Back to the state right after setup (or after the last update that refactored): cold-start every QP, restore rho,

@@ -100,6 +100,7 @@ def lib():
         L.mi_osqp_batch_get_ordering.argtypes = [vp, ip]
         L.mi_osqp_batch_free.argtypes = [vp]; L.mi_osqp_batch_free.restype = None
         L.mi_osqp_batch_update_bounds_device.argtypes = [vp, vp, vp, vp]
+        L.mi_osqp_batch_update_A_bounds_device.argtypes = [vp, vp, vp, vp, vp]
         L.mi_osqp_batch_solve_device.argtypes = [vp, vp, vp, vp, vp]
         L.mi_osqp_batch_reset.argtypes = [vp]
         L.mi_osqp_batch_refactor_device.argtypes = [vp]
@@ -384,6 +385,11 @@ class BatchSolver:
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         _chk(lib().mi_osqp_batch_solve_device(self._h, p(x_out), p(status), p(iters),
                                               None if stream is None else C.c_void_p(stream)), "solve_device")
+
+    def update_A_bounds_device(self, Ax, l, u, stream=None):
+        """QPSolver::update from torch CUDA tensors ([B, nnzA], [B, m], [B, m], float64, contiguous)."""
+        _chk(lib().mi_osqp_batch_update_A_bounds_device(self._h, C.c_void_p(Ax.data_ptr()), C.c_void_p(l.data_ptr()), C.c_void_p(u.data_ptr()),
+                                                        None if stream is None else C.c_void_p(stream)), "update_A_bounds_device")
 
     def update_bounds_device(self, l, u, stream=None):
         _chk(lib().mi_osqp_batch_update_bounds_device(self._h, C.c_void_p(l.data_ptr()), C.c_void_p(u.data_ptr()),

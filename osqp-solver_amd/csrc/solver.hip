@@ -1776,20 +1776,33 @@ static int ensure_mirrors(mi_osqp_batch *h) {
 
 // Row E13's A / bounds update with row E2 on the device: raw values through pinned memory, ruiz_kernel (unscale, new A,
 // equilibrate, scale the bounds), the check streams re-scattered, ONE refactorisation of every QP.  l / u null: bounds kept.
-static int device_update(mi_osqp_batch *h, const double *Av, const double *l, const double *u) {
+static int device_update(mi_osqp_batch *h, const double *Av, const double *l, const double *u,
+                         const double *dA = nullptr, const double *dl = nullptr, const double *du = nullptr) {      // (dA / dl / du: the same data already in HBM)
   const Analysis &an = (*h->anp);
   const int n = an.n, m = an.m, B = h->B, nnzP = an.Pp[n], nnzA = an.Ap[n], pa_len = nnzP + nnzA;
   h->clear_rho_updates = true;
-  const size_t cA = (size_t)B * nnzA, cb = l ? (size_t)B * m : 0, cpa = (size_t)B * pa_len;
+  const size_t cA = (size_t)B * nnzA, cb = (l || dl) ? (size_t)B * m : 0, cpa = (size_t)B * pa_len;
   int rc;
   if ((rc = ensure_pin(h, cA + 2 * cb + 1)) || (rc = ensure_stage(h, cA + 2 * cb + cpa + 1, (size_t)B))) return rc;
-  par_copy(h->pin, Av, cA);
-  if (l) { par_copy(h->pin + cA, l, cb); par_copy(h->pin + cA + cb, u, cb); }
-  HIPCHK(hipMemcpyAsync(h->stage.p, h->pin, (cA + 2 * cb) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (!dA) {
+    // through pinned memory in slices of 4 MB: the transfer of a slice runs while the host threads copy the next one
+    // (256 GOMP QPs of config 4: 30 MB, ~2 ms when copied whole and then sent)
+    const size_t slice = (size_t)1 << 19;
+    struct Part { const double *src; size_t off, len; };
+    std::vector<Part> parts{{Av, 0, cA}};
+    if (l) { parts.push_back({l, cA, cb}); parts.push_back({u, cA + cb, cb}); }
+    for (const Part &pt : parts)
+      for (size_t o = 0; o < pt.len; o += slice) {
+        const size_t len = std::min(slice, pt.len - o);
+        par_copy(h->pin + pt.off + o, pt.src + o, len);
+        HIPCHK(hipMemcpyAsync(h->stage.p + pt.off + o, h->pin + pt.off + o, len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      }
+  }
   RuizArgs r{};
   r.n = n; r.m = m; r.nnzP = nnzP; r.nnzA = nnzA; r.B = B; r.BT = h->BT; r.iters = (int)h->st.scaling;
   r.Prow = h->rz_prow.p; r.Pcol = h->rz_pcol.p; r.Arow = h->rz_arow.p; r.Acol = h->rz_acol.p;
-  r.rawA = h->stage.p; r.rawl = l ? h->stage.p + cA : nullptr; r.rawu = l ? h->stage.p + cA + cb : nullptr;
+  if (dA) { r.rawA = dA; r.rawl = dl; r.rawu = du; }
+  else { r.rawA = h->stage.p; r.rawl = l ? h->stage.p + cA : nullptr; r.rawu = l ? h->stage.p + cA + cb : nullptr; }
   r.pa_val = h->pa_val.p; r.q = h->q.p; r.Dsc = h->Dsc.p; r.Dsc_inv = h->Dsc_inv.p; r.Esc = h->Esc.p; r.Esc_inv = h->Esc_inv.p;
   r.l = h->l.p; r.u = h->u.p; r.dscal = h->dscal.p;
   r.dn = h->out1.p; r.en = h->out1.p + (size_t)B * n;              // (scratch of check_kernel: (2n + m) doubles per QP)
@@ -1829,6 +1842,36 @@ int mi_osqp_batch_update_A(mi_osqp_batch *h, const int64_t *Ap, const int64_t *A
   return snapshot(h);
 }
 
+// QPSolver::update with the new values already in HBM (QP-major [B][nnzA], [B][m], natural CSC order of the pattern given at
+// setup - a planner that assembles its rows on the device, or mi_gomp_scene): nothing crosses PCIe but a validation flag.
+int mi_osqp_batch_update_A_bounds_device(mi_osqp_batch *h, const double *d_Av, const double *d_l, const double *d_u, void *stream) {
+  CallTimer timer_("batch_update_A_bounds_device");
+  if (!h || !d_Av || !d_l || !d_u) return MI_OSQP_ERR_NULL;
+  DevGuard guard(h->device);
+  { const int rc_ = cont_leave(h); if (rc_) return rc_; }
+  const Analysis &an = (*h->anp);
+  const int m = an.m, B = h->B, nnzA = an.Ap[an.n];
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  if (host_ruiz(h)) {            // a handful of large QPs: equilibrated on host threads, so the values come down first
+    std::vector<double> hA((size_t)B * nnzA), hl((size_t)B * m), hu((size_t)B * m);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(hA.data(), d_Av, hA.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hl.data(), d_l, hl.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hu.data(), d_u, hu.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<int64_t> Ap(an.Ap.begin(), an.Ap.end()), Ai(an.Ai.begin(), an.Ai.end());
+    return mi_osqp_batch_update_A_bounds(h, Ap.data(), Ai.data(), hA.data(), hl.data(), hu.data());
+  }
+  if (m) {                       // l <= u, checked without writing (pass 1 of the bounds update)
+    HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), s));
+    HIPCHK(launch_bounds(d_l, d_u, h->out1.p, h->out2.p, h->Esc.p, h->rho_vec.p, h->dscal.p, h->flag.p, B, m, h->BT, h->st.scaling ? 1 : 0, s));
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag & 2) return MI_OSQP_ERR_INVALID_DATA;
+  } else HIPCHK(hipStreamSynchronize(s));
+  return device_update(h, nullptr, nullptr, nullptr, d_Av, d_l, d_u);
+}
+
 // new A values and new bounds, ONE refactorisation (QPSolver::update: [REF] src/osqp-wrapper.h:33-43)
 int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *Ap, const int64_t *Ai, const double *Av, const double *l, const double *u) {
   CallTimer timer_("batch_update_A_bounds");
@@ -1837,7 +1880,14 @@ int mi_osqp_batch_update_A_bounds(mi_osqp_batch *h, const int64_t *Ap, const int
   { const int rc_ = cont_leave(h); if (rc_) return rc_; }
   const Analysis &an = (*h->anp);
   const int m = an.m, B = h->B;
-  for (size_t k = 0; k < (size_t)B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
+  {
+    const size_t tot = (size_t)B * m, chunk = (size_t)1 << 17;
+    std::atomic<int> bad{0};
+    const int parts = (int)((tot + chunk - 1) / chunk);
+    auto scan = [&](int i, int) { const size_t e = std::min(tot, ((size_t)i + 1) * chunk); for (size_t k = (size_t)i * chunk; k < e; k++) if (l[k] > u[k]) { bad.store(1); return; } };
+    if (parts <= 2) { for (int i = 0; i < parts; i++) scan(i, 0); } else parallel_for(parts, scan);
+    if (bad.load()) return MI_OSQP_ERR_INVALID_DATA;
+  }
   for (int j = 0; j <= an.n; j++) if (Ap[j] != an.Ap[j]) return MI_OSQP_ERR_PATTERN_CHANGED;
   for (int k = 0; k < an.Ap[an.n]; k++) if (Ai[k] != an.Ai[k]) return MI_OSQP_ERR_PATTERN_CHANGED;
   if (!host_ruiz(h)) return device_update(h, Av, l, u);

@@ -18,4 +18,12 @@ for Bq in (256, 1024):
         s.update_A_bounds(Ax2, pr["l"], pr["u"])
         torch.cuda.synchronize(); tu.append(time.perf_counter() - t)
         t = time.perf_counter(); info = s.solve(); tsv.append(time.perf_counter() - t)
-    print(f"B={Bq}: update {1e3 * min(tu):.2f} ms, solve {1e3 * min(tsv):.2f} ms ({max(i.iter for i in info)} iterations)", flush=True)
+    td = []
+    for k in range(4):
+        tA = torch.from_numpy(pr["Ax"] * (1.0 + 0.01 * rng.standard_normal(pr["Ax"].shape))).cuda()
+        tl, tu_ = torch.from_numpy(pr["l"]).cuda(), torch.from_numpy(pr["u"]).cuda()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        s.update_A_bounds_device(tA, tl, tu_)
+        torch.cuda.synchronize(); td.append(time.perf_counter() - t)
+        s.solve()
+    print(f"B={Bq}: update {1e3 * min(tu):.2f} ms from host pointers, {1e3 * min(td):.2f} ms from device-resident values; solve {1e3 * min(tsv):.2f} ms ({max(i.iter for i in info)} iterations)", flush=True)

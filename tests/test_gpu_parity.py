@@ -756,3 +756,32 @@ def test_relaxed_and_fundamental_supernodes_agree_and_match_oracle(shape, monkey
     a, r = res["0"], res["16"]
     assert a[0] == r[0] and a[2] == r[2] and a[4] == r[4] and a[5] == r[5]
     assert np.max(np.abs(a[1] - r[1])) <= 1e-9 and np.max(np.abs(a[3] - r[3])) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_update_from_device_resident_values_equals_the_host_pointer_update_bitwise():
+    """mi_osqp_batch_update_A_bounds_device (new A values and bounds already in HBM) is QPSolver::update without the PCIe
+    leg: same kernels on the same numbers -> the same bits as the host-pointer call; l > u is refused and leaves the handle as
+    it was."""
+    import torch
+    pr = PR.gomp_batch(24, 6, 30)
+    rng = np.random.default_rng(8)
+    Ax2 = pr["Ax"] * (1.0 + 0.05 * rng.standard_normal(pr["Ax"].shape))
+    l2, u2 = pr["l"] * 0.9, pr["u"] * 0.9
+    out = []
+    for dev in (False, True):
+        s = M.BatchSolver(pr["P"], pr["Px"], None, pr["A"], pr["Ax"], pr["l"], pr["u"])
+        s.warm_start_x(pr["warm"]); s.solve()
+        if dev:
+            tA, tl, tu = (torch.from_numpy(np.ascontiguousarray(v)).cuda() for v in (Ax2, l2, u2))
+            bad_l = tl.clone(); bad_l[3, 5] = 1e3; bad_u = tu.clone(); bad_u[3, 5] = -1e3
+            with pytest.raises(M.MiOsqpError):
+                s.update_A_bounds_device(tA, bad_l, bad_u)
+            s.update_A_bounds_device(tA, tl, tu, stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            s.update_A_bounds(Ax2, l2, u2)
+        info = s.solve()
+        out.append(([i.iter for i in info], [i.exit_code for i in info], s.primal().copy(), s.dual().copy()))
+        s.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
