@@ -2077,7 +2077,7 @@ static int cont_enter(mi_osqp_batch *h) {
   if (!c.yh) HIPCHK(hostpool::alloc((void **)&c.yh, (size_t)B * std::max(m, 1) * sizeof(double), &c.yh_cap));
   if (!c.ring_h) {
     // a few rounds of per-QP calls: (A values + bounds + a warm start) of every QP, twice
-    const size_t per_qp = ((size_t)an.Ap[n] + 2 * (size_t)m + (size_t)n + 16) * sizeof(double);
+    const size_t per_qp = ((size_t)an.Ap[n] + (size_t)an.Pp[n] + 2 * (size_t)m + (size_t)n + 16) * sizeof(double);      // (a whole call - ids, rows in, scaled values out - fits one lap)
     const size_t want = std::max<size_t>((size_t)4 << 20, std::min<size_t>((size_t)256 << 20, 2 * per_qp * (size_t)B));
     HIPCHK(hostpool::alloc((void **)&c.ring_h, want, &c.ring_h_cap));
     c.ring_cap = c.ring_h_cap;
@@ -2152,6 +2152,18 @@ static int ring_take(mi_osqp_batch *h, size_t bytes, RingSpan &out) {
   if (c.ring_head + bytes > c.ring_cap) { HIPCHK(hipStreamSynchronize(c.ustream)); HIPCHK(hipStreamSynchronize(h->stream)); c.ring_head = 0; }      // everything handed out so far has been consumed
   out.host = c.ring_h + c.ring_head; out.dev = c.ring_d.p + c.ring_head;
   c.ring_head += bytes;
+  return MI_OSQP_OK;
+}
+// Everything ONE call hands out must come from one lap of the ring.  A wrap between two spans of a call frees - at the wrap's
+// synchronisation - nothing of the call's own earlier spans (they are filled and enqueued after it), and the head runs into
+// them, unsynchronised, once it has advanced that far again: the staging of a QP's new rows could be overwritten while its
+// transfer or its equilibration was still reading it (seen as a sporadic memory fault on the fourth run of 128 UR5e
+// trajectories, whose updates take 140 KB of ring per QP).  So a call reserves its total first; the takes that follow cannot wrap.
+static int ring_reserve(mi_osqp_batch *h, size_t bytes, int spans) {
+  mi_osqp_batch::Cont &c = h->cont;
+  bytes += (size_t)256 * (size_t)spans;
+  if (bytes > c.ring_cap) { g_last_error = "per-QP call larger than the staging ring"; return MI_OSQP_ERR_ALLOC; }
+  if (c.ring_head + bytes > c.ring_cap) { HIPCHK(hipStreamSynchronize(c.ustream)); HIPCHK(hipStreamSynchronize(h->stream)); c.ring_head = 0; }
   return MI_OSQP_OK;
 }
 static int ring_upload(mi_osqp_batch *h, const RingSpan &sp, size_t bytes) {
@@ -2235,8 +2247,9 @@ static int cont_new_data(mi_osqp_batch *h, int64_t n_ids, const int64_t *ids, co
   int rc;
   if (!dA) for (size_t k = 0; k < (size_t)nq * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
   int *d_ids = nullptr;
-  if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, nullptr))) return rc;
   const size_t cA = (size_t)nq * nnzA, cb = (size_t)nq * m, cpa = (size_t)nq * pa_len;
+  if ((rc = ring_reserve(h, (size_t)nq * sizeof(int) + (dA ? 0 : (cA + 2 * cb) * sizeof(double)) + std::max<size_t>(cpa, 1) * sizeof(double), 3))) return rc;
+  if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, nullptr))) return rc;
   RingSpan in{nullptr, nullptr}, out;
   if (!dA && (rc = ring_take(h, (cA + 2 * cb) * sizeof(double), in))) return rc;
   if ((rc = ring_take(h, std::max<size_t>(cpa, 1) * sizeof(double), out))) return rc;
@@ -2305,6 +2318,7 @@ int mi_osqp_batch_warm_start_x_some(mi_osqp_batch *h, int64_t n_ids, const int64
   const size_t cnt = (size_t)n_ids * (*h->anp).n;
   int *d_ids = nullptr, *d_sel = nullptr;
   RingSpan sp;
+  if ((rc = ring_reserve(h, ((size_t)n_ids + (size_t)h->ntiles * h->BT) * sizeof(int) + cnt * sizeof(double), 2))) return rc;
   if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, &d_sel)) || (rc = ring_take(h, cnt * sizeof(double), sp))) return rc;
   memcpy(sp.host, x, cnt * sizeof(double));
   if ((rc = ring_upload(h, sp, cnt * sizeof(double)))) return rc;
@@ -2498,6 +2512,7 @@ static int gomp_launch(mi_gomp_scene *sc, int64_t n_ids, const int64_t *ids, con
   // trajectories and ids through the handle's staging ring (pinned, asynchronous), the verdicts straight into pinned host memory
   int *d_ids = nullptr;
   RingSpan sp;
+  if ((rc = ring_reserve(h, (size_t)nq * sizeof(int) + (size_t)nq * n * sizeof(double), 2))) return rc;
   if ((rc = cont_stage_ids(h, n_ids, ids, &d_ids, nullptr)) || (rc = ring_take(h, (size_t)nq * n * sizeof(double), sp))) return rc;
   memcpy(sp.host, x, (size_t)nq * n * sizeof(double));
   if ((rc = ring_upload(h, sp, (size_t)nq * n * sizeof(double)))) return rc;

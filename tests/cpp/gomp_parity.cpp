@@ -851,6 +851,75 @@ static int run_cont_bench(int B, int W, int sample) {
   return fails ? 1 : 0;
 }
 
+// The continuous driver on the reference's own robot and scene ([REF] examples/solver-example.cpp:31-70: UR5e, a collision ball
+// of 0.15 m at wrist 3 and the gripper ball of 0.05 m at the flange, the wall y >= -0.4) plus a bar to pass above, for a batch of
+// start / goal pairs around the example's (joint 1 turns by about pi).   gomp_parity contbench_ur5e [trajectories] [waypoints] [sample]
+static int run_cont_bench_ur5e(int B, int W, int sample) {
+  const double pi = 3.14159265358979323846;
+  std::vector<RobotBall> balls{RobotBall(&forward_kinematics_6_back, &joint_jacobian_6_back, 0.15, false).withBuiltin(MI_GOMP_MODEL_UR5E_WRIST3),
+                               RobotBall(&forward_kinematics, &joint_jacobian, 0.05, true).withBuiltin(MI_GOMP_MODEL_UR5E_FLANGE)};
+  std::vector<HorizontalLine> lines{HorizontalLine({0, 1}, {0.3, 0, 0.35}, false)};
+  auto pos = constraints::inRange<6>(constraints::of<6>(-2 * pi), constraints::of<6>(2 * pi));
+  auto vel = constraints::inRange<6>(constraints::of<6>(-pi), constraints::of<6>(pi));
+  auto acc = constraints::inRange<6>(constraints::of<6>(-pi * 800 / 180), constraints::of<6>(pi * 800 / 180));
+  auto c3d = constraints::inRange<3>(Vec<3>{-INF, -0.4, -INF}, Vec<3>{INF, INF, INF});
+  std::vector<Ctrl<6>> starts, ends;
+  std::mt19937_64 rng(777);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  for (int b = 0; b < B; ++b) {
+    Ctrl<6> s0{}, e0{};
+    for (int j = 0; j < 6; ++j) { s0[j] = 0.15 * U(rng); e0[j] = 0.15 * U(rng); }
+    e0[0] += pi * (0.8 + 0.2 * U(rng));
+    starts.push_back(s0); ends.push_back(e0);
+  }
+  using clk = std::chrono::steady_clock;
+  ContinuousGOMPSolver<6> cg((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls);
+  if (getenv("GOMP_PIPELINE_DEPTH")) cg.pipeline_depth = std::atoi(getenv("GOMP_PIPELINE_DEPTH"));
+  if (getenv("GOMP_SEGMENTS")) cg.segments_per_advance = std::atoi(getenv("GOMP_SEGMENTS"));
+  const bool dev_asm = getenv("GOMP_DEVICE_ASSEMBLY") && std::atoi(getenv("GOMP_DEVICE_ASSEMBLY"));
+  cg.device_assembly = dev_asm;
+  auto t0 = clk::now();
+  auto c1 = cg.run(starts, ends);
+  const double tc1 = std::chrono::duration<double>(clk::now() - t0).count();
+  if (getenv("GOMP_PROGRESS")) std::printf("first run done: %.3f s\n", tc1);
+  double best = 1e30;
+  std::vector<std::pair<ExitCode, QPVector>> c2;
+  for (int rep = 0; rep < 3; ++rep) {
+    t0 = clk::now();
+    c2 = cg.run(starts, ends);
+    best = std::fmin(best, std::chrono::duration<double>(clk::now() - t0).count());
+    if (getenv("GOMP_PROGRESS")) std::printf("run %d done\n", rep);
+  }
+  int cok = 0, csolves = 0, cupdates = 0;
+  for (int b = 0; b < B; ++b) {
+    cok += c2[b].first == ExitCode::kOptimal; csolves += cg.qp_solves[b]; cupdates += cg.qp_updates[b];
+    CHECK(c2[b].first == c1[b].first); CHECK(c2[b].second == c1[b].second);
+  }
+  if (getenv("GOMP_STAGE_PROFILE"))
+    for (const auto &sp : cg.stageProfile())
+      std::printf("  stage W=%3.0f: %4.0f advances; admitting %.3f s, waiting for the device %.3f s, checks + re-linearisation + updates %.3f s, idle %.3f s\n",
+                  sp[0], sp[1], sp[2], sp[3], sp[4], sp[5]);
+  sample = std::min(sample, B);
+  t0 = clk::now();
+  double md = 0.0;
+  int same = 0;
+  for (int b = 0; b < sample; ++b) {
+    GOMPSolver<6, OracleQPSolver> o((size_t)W, 0.1, pos, vel, acc, c3d, lines, balls, nullptr, false);
+    auto [code, x] = o.run(starts[b], ends[b]);
+    CHECK(code == c2[b].first);
+    same += o.qp_solves == cg.qp_solves[b] && o.qp_updates == cg.qp_updates[b];
+    if (code == ExitCode::kOptimal && x.size() == c2[b].second.size()) for (size_t k = 0; k < x.size(); ++k) md = std::fmax(md, std::fabs(x[k] - c2[b].second[k]));
+  }
+  const double to = std::chrono::duration<double>(clk::now() - t0).count();
+  CHECK(same == sample);
+  CHECK(md <= 1e-5);
+  std::printf("CONTBENCH_UR5E device_assembly %d trajectories %d waypoints %d first_run_s %.4f run_s %.4f trajectories_per_s %.2f qp_solves %d qp_updates %d advances %ld optimal %d "
+              "oracle_sample %d oracle_s %.4f oracle_trajectories_per_s %.2f max_dx %.3e\n",
+              (int)dev_asm, B, W, tc1, best, B / best, csolves, cupdates, cg.advances.load(), cok, sample, to, sample > 0 ? sample / to : 0.0, md);
+  std::printf(fails ? "CONTBENCH_UR5E FAILED (%d)\n" : "CONTBENCH_UR5E OK\n", fails);
+  return fails ? 1 : 0;
+}
+
 // The reference's example program ([REF] examples/solver-example.cpp:12-16,44-70: UR5e, joint 1 by pi, two balls, y >= -0.4)
 // as its sequential driver runs it - one trajectory, one QP at a time - on the GPU QPSolver and on the oracle backend
 // (one CPU thread): wall time of run() and the difference of the trajectories.   gomp_parity example [waypoints]
@@ -894,6 +963,7 @@ int main(int argc, char **argv) {
   // streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue wait for each other's
   // kernels.  One queue per stage (measured: 730 -> 900 trajectories/s on the obstacle scene); read at HIP start-up.
   setenv("GPU_MAX_HW_QUEUES", "10", 0);
+  setvbuf(stdout, nullptr, _IOLBF, 0);            // (a run that dies keeps what it has printed)
   if (argc > 1 && !std::strcmp(argv[1], "example")) return run_example(argc > 2 ? std::atoi(argv[2]) : 802);
   if (argc > 1 && !std::strcmp(argv[1], "obstbench"))
     return run_obstacle_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
@@ -903,6 +973,8 @@ int main(int argc, char **argv) {
     return run_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "batch")) return run_batch(argc > 2 ? std::atoi(argv[2]) : 0);
   if (argc > 1 && !std::strcmp(argv[1], "cont")) return run_cont(argc > 2 ? std::atoi(argv[2]) : 0);
+  if (argc > 1 && !std::strcmp(argv[1], "contbench_ur5e"))
+    return run_cont_bench_ur5e(argc > 2 ? std::atoi(argv[2]) : 128, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 4);
   if (argc > 1 && !std::strcmp(argv[1], "contbench"))
     return run_cont_bench(argc > 2 ? std::atoi(argv[2]) : 256, argc > 3 ? std::atoi(argv[3]) : 100, argc > 4 ? std::atoi(argv[4]) : 8);
   if (argc > 1 && !std::strcmp(argv[1], "devasm")) return run_devasm();
