@@ -390,6 +390,38 @@ def obstacle_scene_entry(with_cpu):
     return e
 
 
+def ur5e_scene_entry(with_cpu):
+    """The reference's own robot and scene ([REF] examples/solver-example.cpp:31-70: UR5e, collision balls at wrist 3 and at the
+    flange, the wall y >= -0.4) plus a bar to pass above, 128 start / goal pairs around the example's, 100 waypoints, through the
+    continuous driver - with the SQP step on the host threads and on the device (mi_gomp_scene)."""
+    exe = os.path.join(ROOT, "osqp-solver_amd", "gomp_parity_test")
+    cfg = "GOMP UR5e scene (6 DOF, two collision balls, wall, bar): 128 trajectories x 100 waypoints, 10 horizons, continuous driver"
+    if not os.path.exists(exe):
+        return {"config": cfg, "error": "osqp-solver_amd/gomp_parity_test not built"}
+    out = {}
+    for dev in ("0", "1"):
+        try:
+            r = subprocess.run([exe, "contbench_ur5e", "128", "100", "4" if (with_cpu and dev == "0") else "0"], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, GOMP_DEVICE_ASSEMBLY=dev))
+        except Exception as ex:
+            return {"config": cfg, "error": repr(ex)[:200]}
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("CONTBENCH_UR5E device_assembly")]
+        if r.returncode != 0 or not line:
+            return {"config": cfg, "error": (r.stdout + r.stderr)[-500:]}
+        tok = line[0].split()
+        out[dev] = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)}
+    kv = out["0"]
+    e = {"config": cfg, "value": kv["trajectories_per_s"], "unit": "trajectories/s", "ms": 1e3 * kv["run_s"], "first_run_ms": 1e3 * kv["first_run_s"],
+         "qp_solves": int(kv["qp_solves"]), "qp_updates": int(kv["qp_updates"]), "all_optimal": int(kv["optimal"]) == int(kv["trajectories"]),
+         "device_assembly": {"value": out["1"]["trajectories_per_s"], "unit": "trajectories/s", "ms": 1e3 * out["1"]["run_s"],
+                             "qp_solves": int(out["1"]["qp_solves"]), "qp_updates": int(out["1"]["qp_updates"])}}
+    if with_cpu and kv.get("oracle_sample", 0) > 0:
+        e["cpu_baseline"] = {"value": kv["oracle_trajectories_per_s"], "unit": "trajectories/s", "cores": 1, "kind": "port",
+                             "sample": "the first %d trajectories, sequential GOMPSolver on the oracle, one thread; same exit codes and "
+                                       "solve / update counts, max |dx| %.1e" % (int(kv["oracle_sample"]), kv["max_dx"])}
+    return e
+
+
 def secondary(M, PR, torch, with_cpu):
     """BASELINE configs 2, 4, 5 (outside the headline timing; each a few seconds)."""
     import numpy as np
@@ -450,6 +482,7 @@ def secondary(M, PR, torch, with_cpu):
     for g in sorted({150, int(os.environ.get("MI_OSQP_BENCH_GRID", "316"))}):
         res.append(_grid_entry(M, PR, torch, O, g))
     res.append(obstacle_scene_entry(with_cpu))
+    res.append(ur5e_scene_entry(with_cpu))
     return res
 
 

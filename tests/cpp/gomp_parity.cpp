@@ -868,8 +868,9 @@ static int run_cont_bench_ur5e(int B, int W, int sample) {
   std::uniform_real_distribution<double> U(-1.0, 1.0);
   for (int b = 0; b < B; ++b) {
     Ctrl<6> s0{}, e0{};
-    for (int j = 0; j < 6; ++j) { s0[j] = 0.15 * U(rng); e0[j] = 0.15 * U(rng); }
-    e0[0] += pi * (0.8 + 0.2 * U(rng));
+    const double spread = getenv("GOMP_SPREAD") ? std::atof(getenv("GOMP_SPREAD")) : 0.05;
+    for (int j = 0; j < 6; ++j) { s0[j] = spread * U(rng); e0[j] = spread * U(rng); }
+    e0[0] += pi * (0.9 + 0.1 * U(rng));
     starts.push_back(s0); ends.push_back(e0);
   }
   using clk = std::chrono::steady_clock;

@@ -75,6 +75,17 @@ def test_device_relinearisation_matches_host_constraint_builder(exe):
     assert r.returncode == 0 and "DEVASM OK" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_assembly", ["0", "1"])
+def test_continuous_driver_on_the_ur5e_scene(exe, device_assembly):
+    """The reference's robot and scene (UR5e, balls at wrist 3 and flange, the wall y >= -0.4, a bar) through the continuous
+    driver, SQP step on the host threads and on the device: repeated runs bitwise equal, the first trajectories against the
+    sequential driver on the oracle - same exit codes, same solve / update counts, trajectories within 1e-5."""
+    r = subprocess.run([exe, "contbench_ur5e", "24", "60", "3"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GOMP_DEVICE_ASSEMBLY=device_assembly))
+    assert r.returncode == 0 and "CONTBENCH_UR5E OK" in r.stdout and "Memory access fault" not in r.stdout + r.stderr, r.stdout + r.stderr
+
+
 def test_ur5e_kinematics_and_example_scenario_on_oracle(exe):
     """own UR5e FK / Jacobians (published DH parameters; the reference's kinematics library is
     absent) -- zero-pose position, Jacobians vs central differences, IK round trip -- and the scenario of
