@@ -2078,7 +2078,9 @@ static int cont_enter(mi_osqp_batch *h) {
   if (!c.ring_h) {
     // a few rounds of per-QP calls: (A values + bounds + a warm start) of every QP, twice
     const size_t per_qp = ((size_t)an.Ap[n] + (size_t)an.Pp[n] + 2 * (size_t)m + (size_t)n + 16) * sizeof(double);      // (a whole call - ids, rows in, scaled values out - fits one lap)
-    const size_t want = std::max<size_t>((size_t)4 << 20, std::min<size_t>((size_t)256 << 20, 2 * per_qp * (size_t)B));
+    size_t want = std::max<size_t>((size_t)4 << 20, std::min<size_t>((size_t)256 << 20, 2 * per_qp * (size_t)B));
+    // (tests: MI_OSQP_CONT_RING_KB = a ring barely larger than one whole-batch call, so that every few calls wrap)
+    if (const char *er = getenv("MI_OSQP_CONT_RING_KB")) want = std::max<size_t>((size_t)atol(er) << 10, per_qp * (size_t)B + ((size_t)64 << 10));
     HIPCHK(hostpool::alloc((void **)&c.ring_h, want, &c.ring_h_cap));
     c.ring_cap = c.ring_h_cap;
     int rc = c.ring_d.alloc(c.ring_cap);

@@ -202,3 +202,40 @@ def test_blocking_solve_through_the_advance_kernel_is_bitwise_the_segment_loop(m
             _same(j1[b], y1[b], i1[b], x1[b])
             _same(j2[b], y2[b], i2[b], x2[b])
         assert s.last_solve_stats()["launches"] <= ref.last_solve_stats()["launches"]
+
+
+def test_a_staging_ring_that_wraps_every_few_calls_changes_nothing(monkeypatch):
+    """The per-QP calls stage ids, rows, scaled values and warm starts in a pinned ring; a call's spans come from one lap
+    (solver.hip ring_reserve).  With a ring barely larger than one whole-batch call (MI_OSQP_CONT_RING_KB) every second call
+    wraps while the previous calls' transfers and kernels are still in flight: many rounds of partial updates / warm starts /
+    solves must stay bitwise equal to the blocking calls."""
+    B, n = 12, 80
+    pr = PR.random_box_qp(B, n=n, mg=56, nnz_per_row=5)
+    rng = np.random.default_rng(11)
+    ref = _make(pr)
+    ref.solve()
+    monkeypatch.setenv("MI_OSQP_CONT_RING_KB", "1")
+    s = _make(pr)
+    s.solve_begin_some(range(B)); _drain(s)
+    for rnd in range(12):
+        Ax2 = pr["Ax"] * (1.0 + 0.1 * rng.standard_normal(pr["Ax"].shape))
+        l2, u2 = pr["l"] * (1.0 + 0.05 * rnd), pr["u"] * (1.0 - 0.02 * rnd)
+        xw = 0.1 * rng.standard_normal((B, n))
+        ref.update_A_bounds(Ax2, l2, u2); ref.warm_start_x(xw)
+        info_ref, x_ref = ref.solve(), ref.primal()
+        order = rng.permutation(B)
+        groups = [sorted(order[:5].tolist()), sorted(order[5:9].tolist()), sorted(order[9:].tolist())]
+        fin = []
+        for k, g in enumerate(groups):                      # at most one poll behind: the groups' stagings queue up in the ring
+            s.update_A_bounds_some(g, Ax2[g], l2[g], u2[g])
+            s.warm_start_x_some(g, xw[g])
+            s.solve_begin_some(g)
+            if k >= 2:
+                fin += list(s.poll(True))
+            s.advance(1)
+        fin += list(s.poll(True)); fin += list(s.poll(True))
+        fin += _drain(s)
+        assert sorted(fin) == list(range(B))
+        info, x = s.info_some(range(B)), s.primal_some(range(B))
+        for b in range(B):
+            _same(info[b], x[b], info_ref[b], x_ref[b])
