@@ -81,6 +81,7 @@ struct FactorArgs {
   uint32_t storage;
   SchedDev fwd, bwd;
   const uint32_t *blk, *lvl, *utask, *tri4, *dtask, *ttask, *asm_dst, *asm_src;
+  const uint32_t *ubig;      // per level: where the small update tasks begin (BlockFactor::ubig)
   const int32_t *fwd_srcblk, *bwd_srcblk;
   const double *pa_val, *l, *u, *dscal;
   double *rho_vec, *rho_inv, *Lblk, *Dl, *dinv_scratch, *fwd_val, *bwd_val, *dinv;

@@ -835,6 +835,15 @@ static void build_block_factor(Analysis &an) {
     uint32_t u0 = (uint32_t)(bf.utask.size() / 4), d0 = (uint32_t)bf.dtask.size(), t0 = (uint32_t)(bf.ttask.size() / 2);
     auto &uts = ut_of_level[L];
     std::stable_sort(uts.begin(), uts.end(), [](const UT &a, const UT &b) { return a.te - a.tb > b.te - b.tb; });
+    {
+      // small = at most 16 triples and a target of at most 8 columns (the accumulators of the four-tasks-per-wave form);
+      // the others first, both classes by size
+      auto small = [&](const UT &u) { return u.te - u.tb <= 16u && (bf.blk[4 * u.id + 3] & 255u) <= 8u; };
+      std::stable_partition(uts.begin(), uts.end(), [&](const UT &u) { return !small(u); });
+      uint32_t nbig = 0;
+      while (nbig < uts.size() && !small(uts[nbig])) nbig++;
+      bf.ubig.push_back(u0 + nbig);
+    }
     for (const UT &u : uts) bf.utask.insert(bf.utask.end(), {u.id, u.tb, u.tm, u.te});
     if (getenv("MI_OSQP_DEBUG_ORDER") && !uts.empty()) {
       // critical path of the U step with round-robin assignment to 16 waves (rank-1 batches of 8, general triples)
@@ -844,13 +853,27 @@ static void build_block_factor(Analysis &an) {
       fprintf(stderr, "[mi_osqp] factor level %d: %zu update tasks, rank-1 triples %zu, general %zu, biggest task %u, modelled path %.0f units (ideal %.0f)\n",
               L, uts.size(), r1, gen, uts[0].te - uts[0].tb, *std::max_element(wv.begin(), wv.end()), (r1 / 8.0 + gen * 1.5) / 16);
     }
-    for (int J : cols_of_level[L])
-      for (const auto &[I, id] : colblk[J]) {
-        if (J >= ct0) continue;
-        if (I == J) bf.dtask.push_back(id);
-        else bf.ttask.insert(bf.ttask.end(), {id, colblk[J][0].second});
+    // diagonal blocks and triangular solves: the ones of more than 4 columns first, then the narrow ones (four per wave)
+    for (int pass = 0; pass < 2; pass++) {
+      for (int J : cols_of_level[L]) {
+        if (J >= ct0 || (cw(J) > 4) != (pass == 0)) continue;
+        for (const auto &[I, id] : colblk[J]) {
+          if (I == J) bf.dtask.push_back(id);
+          else bf.ttask.insert(bf.ttask.end(), {id, colblk[J][0].second});
+        }
       }
+      if (pass == 0) { bf.ubig.push_back((uint32_t)bf.dtask.size()); bf.ubig.push_back((uint32_t)(bf.ttask.size() / 2)); }
+    }
     bf.lvl.insert(bf.lvl.end(), {u0, (uint32_t)(bf.utask.size() / 4), d0, (uint32_t)bf.dtask.size(), t0, (uint32_t)(bf.ttask.size() / 2)});
+  }
+  if (getenv("MI_OSQP_DEBUG_ORDER")) {
+    size_t cnt[5] = {0, 0, 0, 0, 0}, small = 0;
+    for (size_t t = 0; t < bf.utask.size() / 4; t++) {
+      const uint32_t w = bf.blk[4 * bf.utask[4 * t] + 3] & 255u, sz = bf.utask[4 * t + 3] - bf.utask[4 * t + 1];
+      cnt[w <= 1 ? 0 : w <= 2 ? 1 : w <= 4 ? 2 : w <= 8 ? 3 : 4]++;
+      small += sz <= 16;
+    }
+    fprintf(stderr, "[mi_osqp] update tasks by target width: 1: %zu, 2: %zu, 3-4: %zu, 5-8: %zu, 9-16: %zu; %zu of %zu with <= 16 triples\n", cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], small, bf.utask.size() / 4);
   }
   bf.utask4.resize(bf.utask.size());
   for (size_t t = 0; t < bf.utask.size() / 4; t++) {

@@ -96,6 +96,9 @@ struct BlockFactor {
   std::vector<uint32_t> utask4;       // DEVICE form, 4/task (one 16-byte load, no second look-up): offset of the target block, tri_begin,
                                       // (h << 27) | (w << 22) | rank-1 triples, general triples
   bool overflow = false;              // a count that does not fit its field of the device form
+  std::vector<uint32_t> ubig;         // 3 per level: first SMALL update task, first NARROW diagonal task, first NARROW solve task (<= 4 columns);
+                                      // update tasks: first update task of the level's SMALL tasks (<= 16 triples, target <= 8 columns; they come last): [u_begin, ubig) one task per wave with its sources split over the lane groups, [ubig, u_end) one
+                                      // task per 16-lane group (factor_kernel at one QP per workgroup)
   std::vector<uint32_t> dtask4;       // DEVICE form, 4/task: the blk tuple of the diagonal block
   std::vector<uint32_t> ttask4;       // DEVICE form, 4/task: offset of the block, first column of its chunk, (h << 8) | w, offset of the diagonal block
   std::vector<uint32_t> dtask;        // diagonal block ids

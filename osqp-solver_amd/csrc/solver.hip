@@ -281,7 +281,7 @@ struct mi_osqp_batch {
   DevBuf<int> iscal, qp_of_slot, flag, npos;
   DevBuf<int2> pairs;
   // device refactorisation (BlockFactor tables + scratch)
-  DevBuf<uint32_t> bf_blk, bf_lvl, bf_utask, bf_tri, bf_dtask, bf_ttask, bf_asm_dst, bf_asm_src;
+  DevBuf<uint32_t> bf_blk, bf_lvl, bf_utask, bf_tri, bf_dtask, bf_ttask, bf_asm_dst, bf_asm_src, bf_ubig;
   DevBuf<int32_t> fwd_srcblk, bwd_srcblk;
   DevBuf<double> pa_val, Lblk, Dl, dinv_scratch;
   // dense tail (host_core.hpp DenseTail): task tables, the per-QP stream of S^-1 (+ setup snapshot), dense scratch
@@ -439,7 +439,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.n = an.n; a.m = an.m; a.N = an.N; a.B = h->B; a.nnzP = an.Pp[an.n]; a.nnzK = an.nnzK();
   a.pa_len = an.Pp[an.n] + an.Ap[an.n]; a.n_levels = an.bf.n_levels; a.force_all = force_all;
   a.storage = an.bf.storage; a.fwd = h->fwd.view(an.fwd); a.bwd = h->bwd.view(an.bwd);
-  a.blk = h->bf_blk.p; a.lvl = h->bf_lvl.p; a.utask = h->bf_utask.p; a.tri4 = h->bf_tri.p; a.dtask = h->bf_dtask.p;
+  a.blk = h->bf_blk.p; a.lvl = h->bf_lvl.p; a.utask = h->bf_utask.p; a.tri4 = h->bf_tri.p; a.dtask = h->bf_dtask.p; a.ubig = h->bf_ubig.p;
   a.ttask = h->bf_ttask.p; a.asm_dst = h->bf_asm_dst.p; a.asm_src = h->bf_asm_src.p;
   a.fwd_srcblk = h->fwd_srcblk.p; a.bwd_srcblk = h->bwd_srcblk.p;
   a.pa_val = h->pa_val.p; a.l = h->l.p; a.u = h->u.p; a.dscal = h->dscal.p;
@@ -868,7 +868,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
   if ((rc = h->iscal.alloc((size_t)IS_COUNT * T)) || (rc = h->qp_of_slot.alloc((size_t)h->ntiles * BT)) || (rc = h->flag.alloc(4))) return rc;
   {
     const BlockFactor &bf = an.bf;
-    if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_utask.upload(bf.utask4)) ||
+    if ((rc = h->bf_blk.upload(bf.blk)) || (rc = h->bf_lvl.upload(bf.lvl)) || (rc = h->bf_ubig.upload(bf.ubig)) || (rc = h->bf_utask.upload(bf.utask4)) ||
         (rc = h->bf_tri.upload(bf.tri4)) || (rc = h->bf_dtask.upload(bf.dtask4)) || (rc = h->bf_ttask.upload(bf.ttask4)) ||
         (rc = h->bf_asm_dst.upload(bf.asm_dst)) || (rc = h->bf_asm_src.upload(bf.asm_src)) ||
         (rc = h->fwd_srcblk.upload(an.fwd_srcblk)) || (rc = h->bwd_srcblk.upload(an.bwd_srcblk))) return rc;
