@@ -1685,21 +1685,22 @@ __device__ __forceinline__ void fct_update(const FactorArgs &a, double *Lb, cons
   }
 }
 
-// The same update for FOUR small tasks at once (one QP per workgroup): lane group g = lane / 16 owns task g entirely - its
+// The same update for SEVERAL small tasks at once (four at one QP per workgroup, two at two): lane group g owns task g entirely - its
 // descriptor, its sources (two rank-1 sources per trip; a general source four columns per trip), its accumulators; the groups
 // share nothing but the instruction stream and the wave-private staging rows (row c * 4 + g belongs to group g).  The factors
 // of the trajectory QPs are thousands of tasks with a handful of sources each: what they cost is the per-task chain of
 // dependent loads, four of which now run side by side.
+template <int BT>
 __device__ __forceinline__ void fct_update_quad(const FactorArgs &a, double *Lb, const double *Dl, double *Ss, const uint4 ud, const bool valid, int lane) {
-  constexpr int BT = 1;
-  const int g = lane >> 4, i = lane & 15, b = 0;
+  constexpr int NG = 64 / (MI_CHUNK * BT);
+  const int g = lane / (MI_CHUNK * BT), i = (lane / BT) % MI_CHUNK, b = lane % BT;
   const uint4 *tri4 = reinterpret_cast<const uint4 *>(a.tri4);
   const uint32_t off = ud.x, q0 = ud.y, qm = q0 + (ud.z & 0x3FFFFFu), q1 = qm + ud.w, h = ud.z >> 27, w = (ud.z >> 22) & 31u;
   const bool row_ok = valid && (uint32_t)i < h;
   constexpr int WQ = 8;                    // columns of a small task's target (BlockFactor::ubig)
   double acc[WQ];
 #pragma unroll
-  for (int j = 0; j < WQ; j++) acc[j] = (row_ok && (uint32_t)j < w) ? Lb[(size_t)off + j * h + i] : 0.0;
+  for (int j = 0; j < WQ; j++) acc[j] = (row_ok && (uint32_t)j < w) ? Lb[((size_t)off + j * h + i) * BT + b] : 0.0;
   for (uint32_t q = q0; __builtin_amdgcn_ballot_w64(valid && q < qm) != 0ull; q += 2) {
     double av[2], bv[2];
 #pragma unroll
@@ -1708,16 +1709,16 @@ __device__ __forceinline__ void fct_update_quad(const FactorArgs &a, double *Lb,
       if (valid && q + c < qm) {
         const uint4 t4 = tri4[q + c];
         const uint32_t ao = t4.x, bo = t4.y, kc0 = t4.z, ah = t4.w >> 16, bh = t4.w & 255u;
-        if ((uint32_t)i < ah) av[c] = Lb[(size_t)ao + i];
-        if ((uint32_t)i < bh) bv[c] = Lb[(size_t)bo + i] * Dl[kc0];
+        if ((uint32_t)i < ah) av[c] = Lb[((size_t)ao + i) * BT + b];
+        if ((uint32_t)i < bh) bv[c] = Lb[((size_t)bo + i) * BT + b] * Dl[(size_t)kc0 * BT + b];
       }
     }
 #pragma unroll
-    for (int c = 0; c < 2; c++) Ss[MI_BS(c * 4 + g, b, i)] = bv[c];
+    for (int c = 0; c < 2; c++) Ss[MI_BS(c * NG + g, b, i)] = bv[c];
     wave_sync();
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(c * 4 + g, b, 0)]);
+      const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(c * NG + g, b, 0)]);
 #pragma unroll
       for (int j2 = 0; j2 < WQ / 2; j2++) {
         const double2 bvv = bs[j2];
@@ -1736,15 +1737,15 @@ __device__ __forceinline__ void fct_update_quad(const FactorArgs &a, double *Lb,
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const uint32_t k = k0 + (uint32_t)c;
-        avk[c] = (arow && k < aw) ? Lb[(size_t)ao + k * ah + i] : 0.0;
-        bvk[c] = (brow && k < aw) ? Lb[(size_t)bo + k * bh + i] * Dl[(size_t)kc0 + k] : 0.0;
+        avk[c] = (arow && k < aw) ? Lb[((size_t)ao + k * ah + i) * BT + b] : 0.0;
+        bvk[c] = (brow && k < aw) ? Lb[((size_t)bo + k * bh + i) * BT + b] * Dl[((size_t)kc0 + k) * BT + b] : 0.0;
       }
 #pragma unroll
-      for (int c = 0; c < 2; c++) Ss[MI_BS(c * 4 + g, b, i)] = bvk[c];
+      for (int c = 0; c < 2; c++) Ss[MI_BS(c * NG + g, b, i)] = bvk[c];
       wave_sync();
 #pragma unroll
       for (int c = 0; c < 2; c++) {
-        const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(c * 4 + g, b, 0)]);
+        const double2 *bs = reinterpret_cast<const double2 *>(&Ss[MI_BS(c * NG + g, b, 0)]);
 #pragma unroll
         for (int j2 = 0; j2 < WQ / 2; j2++) {
           const double2 bvv = bs[j2];
@@ -1757,7 +1758,7 @@ __device__ __forceinline__ void fct_update_quad(const FactorArgs &a, double *Lb,
   }
   if (row_ok) {
 #pragma unroll
-    for (int j = 0; j < WQ; j++) if ((uint32_t)j < w) Lb[(size_t)off + j * h + i] = acc[j];
+    for (int j = 0; j < WQ; j++) if ((uint32_t)j < w) Lb[((size_t)off + j * h + i) * BT + b] = acc[j];
   }
 }
 
@@ -1841,16 +1842,16 @@ __device__ __forceinline__ void fct_trsm(const FactorArgs &a, double *Lb, const 
   wave_sync();
 }
 
-// Four NARROW diagonal blocks (<= 4 columns) per wave: lane group g works in rows 4 g .. 4 g + 3 of the wave's staging area.
-// Same operations as fct_diag<1>.
+// Several NARROW diagonal blocks (<= 4 columns) per wave: lane group g works in rows 4 g .. 4 g + 3 of the wave's staging area.
+// Same operations as fct_diag.
+template <int BT>
 __device__ __forceinline__ void fct_diag_quad(double *Lb, double *Dl, double *dinv, double *Ss, const uint4 tb, const bool valid, int lane, int &npos) {
-  constexpr int BT = 1;
-  const int g = lane >> 4, i = lane & 15, b = 0;
+  const int g = lane / (MI_CHUNK * BT), i = (lane / BT) % MI_CHUNK, b = lane % BT;
   const uint32_t off = tb.x, c0 = tb.z, w = tb.w & 255u;
   const bool ok = valid && (uint32_t)i < w;
 #define MI_QS(k, j) Ss[MI_BS(4 * g + (k), b, (j))]
 #pragma unroll
-  for (int k = 0; k < 4; k++) MI_QS(k, i) = (ok && (uint32_t)k < w) ? Lb[(size_t)off + k * w + i] : 0.0;
+  for (int k = 0; k < 4; k++) MI_QS(k, i) = (ok && (uint32_t)k < w) ? Lb[((size_t)off + k * w + i) * BT + b] : 0.0;
   wave_sync();
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1860,7 +1861,7 @@ __device__ __forceinline__ void fct_diag_quad(double *Lb, double *Dl, double *di
     double lij = 0.0;
     if (on && i > j) { lij = MI_QS(j, i) * di; MI_QS(j, i) = lij; }
     if (on && i == j) {
-      Dl[(size_t)c0 + j] = d; dinv[(size_t)c0 + j] = di;
+      Dl[((size_t)c0 + j) * BT + b] = d; dinv[((size_t)c0 + j) * BT + b] = di;
       if (d > 0.0) npos++;
     }
     wave_sync();
@@ -1870,7 +1871,7 @@ __device__ __forceinline__ void fct_diag_quad(double *Lb, double *Dl, double *di
     }
     wave_sync();
   }
-  if (ok) { for (int k = 0; k < i; k++) Lb[(size_t)off + k * w + i] = MI_QS(k, i); }
+  if (ok) { for (int k = 0; k < i; k++) Lb[((size_t)off + k * w + i) * BT + b] = MI_QS(k, i); }
 #pragma unroll
   for (int j = 2; j >= 0; j--) {
     const bool on = ok && (uint32_t)(j + 2) <= w && i > j;
@@ -1883,26 +1884,26 @@ __device__ __forceinline__ void fct_diag_quad(double *Lb, double *Dl, double *di
     if (on) MI_QS(j, i) = x;
     wave_sync();
   }
-  if (ok && w >= 2) { for (int k = 0; k < i; k++) Lb[(size_t)off + (size_t)i * w + k] = MI_QS(k, i); }
+  if (ok && w >= 2) { for (int k = 0; k < i; k++) Lb[((size_t)off + (size_t)i * w + k) * BT + b] = MI_QS(k, i); }
 }
-// Four triangular solves against NARROW diagonal blocks per wave (same operations as fct_trsm<1>).
+// Several triangular solves against NARROW diagonal blocks per wave (same operations as fct_trsm).
+template <int BT>
 __device__ __forceinline__ void fct_trsm_quad(double *Lb, const double *dinv, double *Ss, const uint4 td, const bool valid, int lane) {
-  constexpr int BT = 1;
-  const int g = lane >> 4, i = lane & 15, b = 0;
+  const int g = lane / (MI_CHUNK * BT), i = (lane / BT) % MI_CHUNK, b = lane % BT;
   const uint32_t off = td.x, h = td.z >> 8, w = td.z & 255u, c0 = td.y, db_off = td.w;
 #pragma unroll
-  for (int k = 0; k < 4; k++) MI_QS(k, i) = (valid && (uint32_t)k < w && (uint32_t)i < w && i > k) ? Lb[(size_t)db_off + k * w + i] : 0.0;
+  for (int k = 0; k < 4; k++) MI_QS(k, i) = (valid && (uint32_t)k < w && (uint32_t)i < w && i > k) ? Lb[((size_t)db_off + k * w + i) * BT + b] : 0.0;
   wave_sync();
   if (valid && (uint32_t)i < h) {
     double ld[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if ((uint32_t)j < w) {
-        double v = Lb[(size_t)off + j * h + i];
+        double v = Lb[((size_t)off + j * h + i) * BT + b];
 #pragma unroll
         for (int k = 0; k < j; k++) v = fma(-ld[k], MI_QS(k, j), v);
         ld[j] = v;
-        Lb[(size_t)off + j * h + i] = v * dinv[(size_t)c0 + j];
+        Lb[((size_t)off + j * h + i) * BT + b] = v * dinv[((size_t)c0 + j) * BT + b];
       }
     }
   }
@@ -2003,7 +2004,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     const uint4 *ut4 = reinterpret_cast<const uint4 *>(a.utask), *dt4 = reinterpret_cast<const uint4 *>(a.dtask), *tt4 = reinterpret_cast<const uint4 *>(a.ttask);
     if (lv[1] > lv[0]) {
       uint32_t ub = lv[1];                 // [lv[0], ub): one task per wave; [ub, lv[1]): the small tasks, one per 16-lane group
-      if constexpr (BT == 1) { if (!(MI_DBG_SKIP(a) & 32)) ub = a.ubig[3 * L]; }
+      if constexpr (BT <= 2) { if (!(MI_DBG_SKIP(a) & 32)) ub = a.ubig[3 * L]; }
       uint32_t t = lv[0] + wave;
       uint4 nxt = t < ub ? ut4[t] : make_uint4(0, 0, 0, 0);
       for (; t < ub; t += nw) {
@@ -2011,23 +2012,24 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
         if (t + nw < ub) nxt = ut4[t + nw];
         fct_update<BT>(a, Lb, Dl, Ss, cur, lane);
       }
-      if constexpr (BT == 1) {
-        const uint32_t g = (uint32_t)lane >> 4;
-        uint32_t tq = ub + 4u * (uint32_t)wave;
+      if constexpr (BT <= 2) {
+        constexpr uint32_t NG = 64 / (MI_CHUNK * BT);
+        const uint32_t g = (uint32_t)lane / (MI_CHUNK * BT);
+        uint32_t tq = ub + NG * (uint32_t)wave;
         uint4 nq = tq + g < lv[1] ? ut4[tq + g] : make_uint4(0, 0, 0, 0);
-        for (; tq < lv[1]; tq += 4u * (uint32_t)nw) {
+        for (; tq < lv[1]; tq += NG * (uint32_t)nw) {
           const uint4 cur = nq;
           const bool valid = tq + g < lv[1];
-          const uint32_t tn = tq + 4u * (uint32_t)nw + g;
+          const uint32_t tn = tq + NG * (uint32_t)nw + g;
           if (tn < lv[1]) nq = ut4[tn];
-          fct_update_quad(a, Lb, Dl, Ss, cur, valid, lane);
+          fct_update_quad<BT>(a, Lb, Dl, Ss, cur, valid, lane);
         }
       }
       sync();
     }
     if (!(MI_DBG_SKIP(a) & 4)) {
       uint32_t db = lv[3];                 // [lv[2], db): one block per wave; [db, lv[3]): the narrow ones, four per wave
-      if constexpr (BT == 1) { if (!(MI_DBG_SKIP(a) & 32)) db = a.ubig[3 * L + 1]; }
+      if constexpr (BT <= 2) { if (!(MI_DBG_SKIP(a) & 32)) db = a.ubig[3 * L + 1]; }
       uint32_t t = lv[2] + wave;
       uint4 nxt = t < db ? dt4[t] : make_uint4(0, 0, 0, 0);
       for (; t < db; t += nw) {
@@ -2035,23 +2037,24 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
         if (t + nw < db) nxt = dt4[t + nw];
         fct_diag<BT>(a, Lb, Dl, dnew, Ss, cur, lane, npos);
       }
-      if constexpr (BT == 1) {
-        const uint32_t g = (uint32_t)lane >> 4;
-        uint32_t tq = db + 4u * (uint32_t)wave;
+      if constexpr (BT <= 2) {
+        constexpr uint32_t NG = 64 / (MI_CHUNK * BT);
+        const uint32_t g = (uint32_t)lane / (MI_CHUNK * BT);
+        uint32_t tq = db + NG * (uint32_t)wave;
         uint4 nq = tq + g < lv[3] ? dt4[tq + g] : make_uint4(0, 0, 0, 0);
-        for (; tq < lv[3]; tq += 4u * (uint32_t)nw) {
+        for (; tq < lv[3]; tq += NG * (uint32_t)nw) {
           const uint4 cur = nq;
           const bool valid = tq + g < lv[3];
-          const uint32_t tn = tq + 4u * (uint32_t)nw + g;
+          const uint32_t tn = tq + NG * (uint32_t)nw + g;
           if (tn < lv[3]) nq = dt4[tn];
-          fct_diag_quad(Lb, Dl, dnew, Ss, cur, valid, lane, npos);
+          fct_diag_quad<BT>(Lb, Dl, dnew, Ss, cur, valid, lane, npos);
         }
       }
     }
     sync();
     if (lv[5] > lv[4] && !(MI_DBG_SKIP(a) & 8)) {
       uint32_t tbg = lv[5];
-      if constexpr (BT == 1) { if (!(MI_DBG_SKIP(a) & 32)) tbg = a.ubig[3 * L + 2]; }
+      if constexpr (BT <= 2) { if (!(MI_DBG_SKIP(a) & 32)) tbg = a.ubig[3 * L + 2]; }
       uint32_t t = lv[4] + wave;
       uint4 nxt = t < tbg ? tt4[t] : make_uint4(0, 0, 0, 0);
       for (; t < tbg; t += nw) {
@@ -2059,16 +2062,17 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
         if (t + nw < tbg) nxt = tt4[t + nw];
         fct_trsm<BT>(a, Lb, Dl, dnew, Ss, cur, lane);
       }
-      if constexpr (BT == 1) {
-        const uint32_t g = (uint32_t)lane >> 4;
-        uint32_t tq = tbg + 4u * (uint32_t)wave;
+      if constexpr (BT <= 2) {
+        constexpr uint32_t NG = 64 / (MI_CHUNK * BT);
+        const uint32_t g = (uint32_t)lane / (MI_CHUNK * BT);
+        uint32_t tq = tbg + NG * (uint32_t)wave;
         uint4 nq = tq + g < lv[5] ? tt4[tq + g] : make_uint4(0, 0, 0, 0);
-        for (; tq < lv[5]; tq += 4u * (uint32_t)nw) {
+        for (; tq < lv[5]; tq += NG * (uint32_t)nw) {
           const uint4 cur = nq;
           const bool valid = tq + g < lv[5];
-          const uint32_t tn = tq + 4u * (uint32_t)nw + g;
+          const uint32_t tn = tq + NG * (uint32_t)nw + g;
           if (tn < lv[5]) nq = tt4[tn];
-          fct_trsm_quad(Lb, dnew, Ss, cur, valid, lane);
+          fct_trsm_quad<BT>(Lb, dnew, Ss, cur, valid, lane);
         }
       }
       sync();
