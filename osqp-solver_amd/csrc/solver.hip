@@ -726,7 +726,10 @@ static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int6
   // ---- tile shape (needed by the schedule layout)
   // 2 QPs per tile: iterate_kernel<2> needs 112 VGPRs, so two 512-thread workgroups share a CU and
   // cover each other's barrier stalls; measured best on the 1024-QP headline batch (4 and 1 are slower)
-  int BT = B >= 384 ? 2 : 1;
+  // (round 3: with several small refactorisation tasks per wave - four at one QP per tile, two at two - and four 20 KB
+  //  workgroups per CU instead of two of 40 KB, one QP per tile now wins on the headline batch: 36.7 -> 35.8 ms per step,
+  //  factor_kernel 1.82 -> 1.48 ms; 1024 GOMP QPs of 7 DOF x 100 waypoints - 50 KB of vector per QP - stay at two: 4.31 vs 4.43 ms)
+  int BT = (B >= 384 && lds_bytes((int)(n + m), 1, h->threads) > 28 * 1024) ? 2 : 1;
   {
     const char *et = getenv("MI_OSQP_TILE");
     if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
