@@ -115,3 +115,17 @@ def test_gomp_example_writes_reference_trajectory_files(tmp_path):
     import re
     assert all(re.fullmatch(r"\(-?[0-9.e+-]+, -?[0-9.e+-]+, -?[0-9.e+-]+\)", line) for line in xyz)
     assert "re-linearisations" in r.stdout
+
+
+@pytest.mark.gpu
+def test_batch_gomp_example_plans_every_trajectory(tmp_path):
+    """examples/batch_gomp_example.cpp: the continuous planner on the reference's robot and scene as a user would call it
+    (SQP step on the device), every trajectory planned."""
+    import osqp_solver_amd as M
+    M.lib()
+    libdir = os.path.join(ROOT, "osqp-solver_amd")
+    out = tmp_path / "batch_gomp_example"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "batch_gomp_example.cpp"),
+                    "-o", str(out), "-L" + libdir, "-lmi_osqp", "-pthread", "-Wl,-rpath," + libdir], check=True)
+    r = subprocess.run([str(out), "16", "40", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "16 of 16 trajectories planned" in r.stdout and "Memory access fault" not in r.stdout + r.stderr, r.stdout + r.stderr
