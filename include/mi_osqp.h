@@ -276,7 +276,7 @@ typedef struct mi_gomp_scene mi_gomp_scene;
 int mi_gomp_scene_create(mi_gomp_scene **out, mi_osqp_batch *h, int64_t dims, int64_t waypoints,
                          int64_t n_balls, const mi_gomp_ball *balls, int64_t n_lines, const mi_gomp_line *lines,
                          const double *con_lo, const double *con_hi);
-void mi_gomp_scene_free(mi_gomp_scene *sc);
+void mi_gomp_scene_free(mi_gomp_scene *sc);          /* before mi_osqp_batch_free of its handle; one scene per handle */
 /* While a scene exists, mi_osqp_batch_reinit_some / _update_A_bounds_some of its handle also keep the QPs' raw constraint
  * data (as ConstraintBuilder::build() produced it) in the scene, so nothing extra is needed when a trajectory enters the
  * handle.  set_rows writes that copy directly ([n_ids][nnzA], [n_ids][m]); get_rows reads it back (tests). */
