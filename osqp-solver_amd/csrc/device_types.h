@@ -44,6 +44,11 @@ struct KernelArgs {
   const double *fwd_val, *bwd_val, *chk_val, *dinv;
   DenseTailDev dt;
   const double *dt_val;                 // per QP: the stream of the inverted Schur complement ([slot][dt.n_steps * 64])
+  // The factor streams exist twice: the snapshot of the last setup / update (fwd_val0, bwd_val0, dt_val0) and the working copy
+  // the refactorisations write.  use_work[slot] != 0: the QP's current factor is the working copy (it was refactored since the
+  // last reset); else its streams are read straight from the snapshot - a reset clears the flags instead of copying gigabytes.
+  const double *fwd_val0, *bwd_val0, *dt_val0;
+  const int *use_work;                  // null: always the working copy
   double *x, *z, *y;
   const double *q, *l, *u, *rho_vec, *rho_inv, *Dsc, *Dsc_inv, *Esc, *Esc_inv;
   double *dx, *dy, *out1, *out2, *dscal;
@@ -82,6 +87,7 @@ struct FactorArgs {
   SchedDev fwd, bwd;
   const uint32_t *blk, *lvl, *utask, *tri4, *dtask, *ttask, *asm_dst, *asm_src;
   const uint32_t *ubig;      // per level: where the small update tasks begin (BlockFactor::ubig)
+  int *use_work;             // per slot: set for every QP refactored here (KernelArgs::use_work), or null
   const int32_t *fwd_srcblk, *bwd_srcblk;
   const double *pa_val, *l, *u, *dscal;
   double *rho_vec, *rho_inv, *Lblk, *Dl, *dinv_scratch, *fwd_val, *bwd_val, *dinv;
@@ -191,6 +197,8 @@ hipError_t launch_resume_flagged(const KernelArgs &a, int nslots, int BT, hipStr
 // dst[slot] = src[slot] for the listed slots: [slot][per] streams / [tile][len][BT] interleaved arrays
 hipError_t launch_copy_slot_streams(double *dst, const double *src, const int *slots, int nslots, size_t per, hipStream_t st);
 hipError_t launch_keep_rows(double *dst, const double *src, const int *ids, int n_ids, int len, hipStream_t st);
+// dst[slot][:] = src[slot][:] for the slots whose flag is set (want = 1) / clear (want = 0); flags null: all
+hipError_t launch_copy_flagged_streams(double *dst, const double *src, const int *flags, int want, int nslots, size_t per, hipStream_t st);
 hipError_t launch_copy_slot_rows(double *dst, const double *src, const int *slots, int nslots, int len, int BT, hipStream_t st);
 // ---- GOMP re-linearisation on the device (solver.hip "gomp scene"): ConstraintBuilder::withObstacles + isSolutionOK for
 // built-in kinematic models ([REF] src/constraints/constraint-builder.h:90-136, src/gomp-solver.h:141-199)

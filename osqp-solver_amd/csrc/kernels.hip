@@ -675,10 +675,12 @@ __device__ __forceinline__ TilePtrs<BT> tile_ptrs(const KernelArgs &a, int tile,
     const size_t slot = t * BT + bb;
     const bool off = skip_done && p.iscal[IS_DONE * BT + bb] != 0;     // wave-uniform: inside a solve, finished QPs (and padding slots) stream nothing
     if (!off) p.act |= 1 << bb;
-    p.vfwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.fwd_val + slot * a.fwd.n_steps * 64, a.fwd.n_steps * 512u);
-    p.vbwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.bwd_val + slot * a.bwd.n_steps * 64, a.bwd.n_steps * 512u);
+    const bool wk = !a.use_work || a.use_work[slot] != 0;                // (wave-uniform) working copy or snapshot of the factor
+    const double *fv = wk ? a.fwd_val : a.fwd_val0, *bv = wk ? a.bwd_val : a.bwd_val0, *dv = wk ? a.dt_val : a.dt_val0;
+    p.vfwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(fv + slot * a.fwd.n_steps * 64, a.fwd.n_steps * 512u);
+    p.vbwd.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(bv + slot * a.bwd.n_steps * 64, a.bwd.n_steps * 512u);
     p.vchk.vals[bb] = off ? make_rsrc(nullptr, 0u) : make_rsrc(a.chk_val + slot * a.chk.n_steps * 64, a.chk.n_steps * 512u);
-    p.vdt[bb] = (off || !a.dt.k) ? make_rsrc(nullptr, 0u) : make_rsrc(a.dt_val + slot * a.dt.n_steps * 64, a.dt.n_steps * 512u);
+    p.vdt[bb] = (off || !a.dt.k) ? make_rsrc(nullptr, 0u) : make_rsrc(dv + slot * a.dt.n_steps * 64, a.dt.n_steps * 512u);
   }
   return p;
 }
@@ -2114,6 +2116,7 @@ __global__ __launch_bounds__(1024) void factor_kernel(FactorArgs a) {
     scatter(bv, a.bwd_srcblk, a.bwd.n_slots);
     for (int e = tid; e < N * BT; e += nthr) a.dinv[H(N, e / BT)] = dnew[e];
   }
+  if (tid < BT && slot >= 0 && flag && a.use_work) a.use_work[slot] = 1;      // this QP's factor now lives in the working copy
   sync();
   __threadfence();          // (continuous batching: an advance launch on another stream may read the flag)
   if (tid < BT && slot >= 0) a.iscal[H(IS_COUNT, IS_NEED_REFACTOR)] = bad_inertia ? -1 : 0;   // -1: the new factor has the wrong inertia
@@ -2811,6 +2814,18 @@ __global__ void copy_slot_streams_kernel(double *dst, const double *__restrict__
   if (slot < 0) return;
   const size_t off = (size_t)slot * per;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) dst[off + e] = src[off + e];
+}
+__global__ void copy_flagged_streams_kernel(double *dst, const double *__restrict__ src, const int *__restrict__ flags, int want, size_t per) {
+  const int slot = blockIdx.y;
+  if (flags && (flags[slot] != 0) != (want != 0)) return;
+  const size_t off = (size_t)slot * per;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (size_t)gridDim.x * blockDim.x) dst[off + e] = src[off + e];
+}
+hipError_t launch_copy_flagged_streams(double *dst, const double *src, const int *flags, int want, int nslots, size_t per, hipStream_t st) {
+  if (!nslots || !per) return hipSuccess;
+  const unsigned gx = (unsigned)std::min<size_t>(64, (per + 1023) / 1024);
+  hipLaunchKernelGGL(copy_flagged_streams_kernel, dim3(gx, nslots), dim3(256), 0, st, dst, src, flags, want, per);
+  return hipGetLastError();
 }
 hipError_t launch_copy_slot_streams(double *dst, const double *src, const int *slots, int nslots, size_t per, hipStream_t st) {
   if (!nslots || !per) return hipSuccess;

@@ -278,6 +278,7 @@ struct mi_osqp_batch {
   DevBuf<unsigned char> rflag;
   DevBuf<double> mw_scratch;            // partial norms / sums of the grid-wide check_kernel
   DevBuf<double> fwd_val0, bwd_val0, dinv0, rho_vec0, rho_inv0, dscal0;   // setup snapshot (reset)
+  DevBuf<int> use_work;                       // per slot: the current factor is the working copy (KernelArgs::use_work)
   DevBuf<int> iscal, qp_of_slot, flag, npos;
   DevBuf<int2> pairs;
   // device refactorisation (BlockFactor tables + scratch)
@@ -410,6 +411,8 @@ static KernelArgs make_args(mi_osqp_batch *h) {
   a.fwd = h->fwd.view((*h->anp).fwd); a.bwd = h->bwd.view((*h->anp).bwd); a.chk = h->chk.view((*h->anp).chk);
   a.pinv = h->pinv.p; a.xloc = h->xloc.p;
   a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.chk_val = h->chk_val.p; a.dinv = h->dinv.p;
+  a.fwd_val0 = h->fwd_val0.p; a.bwd_val0 = h->bwd_val0.p; a.dt_val0 = h->dt_val0.p;
+  a.use_work = (h->fwd_val0.p && h->bwd_val0.p && (!(*h->anp).dt.k || h->dt_val0.p)) ? h->use_work.p : nullptr;     // (before the first snapshot: working copy only)
   a.x = h->x.p; a.z = h->z.p; a.y = h->y.p; a.q = h->q.p; a.l = h->l.p; a.u = h->u.p;
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Dsc = h->Dsc.p; a.Dsc_inv = h->Dsc_inv.p;
   a.Esc = h->Esc.p; a.Esc_inv = h->Esc_inv.p; a.dx = h->dx.p; a.dy = h->dy.p; a.out1 = h->out1.p; a.out2 = h->out2.p;
@@ -444,7 +447,7 @@ static FactorArgs make_factor_args(mi_osqp_batch *h, int force_all) {
   a.fwd_srcblk = h->fwd_srcblk.p; a.bwd_srcblk = h->bwd_srcblk.p;
   a.pa_val = h->pa_val.p; a.l = h->l.p; a.u = h->u.p; a.dscal = h->dscal.p;
   a.rho_vec = h->rho_vec.p; a.rho_inv = h->rho_inv.p; a.Lblk = h->Lblk.p; a.Dl = h->Dl.p; a.dinv_scratch = h->dinv_scratch.p;
-  a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p;
+  a.fwd_val = h->fwd_val.p; a.bwd_val = h->bwd_val.p; a.dinv = h->dinv.p; a.iscal = h->iscal.p; a.npos = h->npos.p; a.use_work = h->use_work.p;
   a.sigma = h->st.sigma; a.home_bt = h->BT; a.dt_k = an.dt.k;
   a.mw_groups = 0; a.mw_bar = h->mw_bar.p;      // (device_refactor_slots decides how many workgroups share a QP)
 #ifdef MI_OSQP_DEBUG_BUILD
@@ -561,10 +564,20 @@ static int snapshot(mi_osqp_batch *h) {
     if (src.n) HIPCHK(hipMemcpyAsync(dst.p, src.p, src.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return 0;
   };
+  // the factor streams: only the QPs whose current factor IS the working copy (the others' snapshot is current, and their
+  // working copy may be a leftover of an earlier solve: a reset clears flags, it does not copy)
+  const Analysis &an = (*h->anp);
+  const int nslots = h->ntiles * h->BT;
+  auto cps = [&](DevBuf<double> &dst, DevBuf<double> &src, size_t per) -> int {
+    const bool fresh = dst.n != src.n;
+    if (fresh) { int rc = dst.alloc(src.n); if (rc) return rc; }
+    if (src.n) HIPCHK(launch_copy_flagged_streams(dst.p, src.p, fresh ? nullptr : h->use_work.p, 1, nslots, per, h->stream));
+    return 0;
+  };
   int rc;
-  if ((rc = cp(h->fwd_val0, h->fwd_val)) || (rc = cp(h->bwd_val0, h->bwd_val)) || (rc = cp(h->dinv0, h->dinv)) ||
-      (rc = cp(h->rho_vec0, h->rho_vec)) || (rc = cp(h->rho_inv0, h->rho_inv)) || (rc = cp(h->dscal0, h->dscal)) ||
-      (rc = cp(h->dt_val0, h->dt_val))) return rc;
+  if ((rc = cps(h->fwd_val0, h->fwd_val, (size_t)an.fwd.phys_steps() * 64)) || (rc = cps(h->bwd_val0, h->bwd_val, (size_t)an.bwd.phys_steps() * 64)) ||
+      (an.dt.k && (rc = cps(h->dt_val0, h->dt_val, (size_t)an.dt.n_steps * 64))) ||
+      (rc = cp(h->dinv0, h->dinv)) || (rc = cp(h->rho_vec0, h->rho_vec)) || (rc = cp(h->rho_inv0, h->rho_inv)) || (rc = cp(h->dscal0, h->dscal))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -706,6 +719,7 @@ static std::mutex &spin_mutex(int device) {
   return mu[(unsigned)device % 64u];
 }
 static int restore_snapshot(mi_osqp_batch *h);
+static int materialise_working(mi_osqp_batch *h);
 static int cont_leave(mi_osqp_batch *h);      // (a blocking call ends the continuous mode of a handle: section "continuous")
 
 // multi-workgroup mode: a grid barrier that gave up waiting (a workgroup of the grid was not resident) leaves its error
@@ -841,6 +855,7 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     for (int j = 0; j < n; j++) { for (int k = an.Pp[j]; k < an.Pp[j + 1]; k++) pc[k] = j; for (int k = an.Ap[j]; k < an.Ap[j + 1]; k++) ac[k] = j; }
     if ((rc = h->rz_prow.upload(pr)) || (rc = h->rz_pcol.upload(pc)) || (rc = h->rz_arow.upload(ar)) || (rc = h->rz_acol.upload(ac))) return rc;
   }
+  if ((rc = h->use_work.alloc(T)) || (rc = h->use_work.zero(h->stream))) return rc;
 #define ALLOC(buf, len) if ((rc = h->buf.alloc((size_t)(len) * T)) || (rc = h->buf.zero(h->stream))) return rc
   ALLOC(fwd_val, (size_t)an.fwd.phys_steps() * 64); ALLOC(bwd_val, (size_t)an.bwd.phys_steps() * 64); ALLOC(chk_val, (size_t)an.chk.phys_steps() * 64); ALLOC(dinv, an.N);
   ALLOC(x, n); ALLOC(z, m); ALLOC(y, m); ALLOC(q, n); ALLOC(l, m); ALLOC(u, m); ALLOC(rho_vec, m); ALLOC(rho_inv, m);
@@ -1301,6 +1316,7 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
   // compaction (re-pairing the QPs still iterating into fewer tiles) is implemented and tested but OFF by default:
   // since the value streams are per QP, a finished QP costs no bytes anyway, and moving data only breaks even
   const bool no_compact = getenv("MI_OSQP_COMPACT") == nullptr || (*h->anp).dt.k != 0;      // (and not combined with the dense tail)
+  if (!no_compact) { const int rc_m = materialise_working(h); if (rc_m) return rc_m; }      // (its slot swaps move working streams)
   auto loop = [&]() -> int {
     int iter = 0, ntl = h->ntiles;     // tiles [0, ntl) hold every QP that is still iterating
     while (true) {
@@ -1619,6 +1635,17 @@ int mi_osqp_batch_reset(mi_osqp_batch *h) {
 }
 }  // extern "C"
 // the state right after setup / the last update that refactored: factor, rho vectors and scalars of the snapshot, cold iterates
+// every QP's current factor into the working copy (what the slot swaps of the compaction path move around)
+static int materialise_working(mi_osqp_batch *h) {
+  const Analysis &an = (*h->anp);
+  const int nslots = h->ntiles * h->BT;
+  if (!h->fwd_val0.p || !h->use_work.p) return MI_OSQP_OK;
+  HIPCHK(launch_copy_flagged_streams(h->fwd_val.p, h->fwd_val0.p, h->use_work.p, 0, nslots, (size_t)an.fwd.phys_steps() * 64, h->stream));
+  HIPCHK(launch_copy_flagged_streams(h->bwd_val.p, h->bwd_val0.p, h->use_work.p, 0, nslots, (size_t)an.bwd.phys_steps() * 64, h->stream));
+  if (an.dt.k && h->dt_val0.p) HIPCHK(launch_copy_flagged_streams(h->dt_val.p, h->dt_val0.p, h->use_work.p, 0, nslots, (size_t)an.dt.n_steps * 64, h->stream));
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->use_work.p, 1, (size_t)nslots, h->stream));
+  return MI_OSQP_OK;
+}
 static int restore_snapshot(mi_osqp_batch *h) {
   h->clear_rho_updates = true;
   auto cp = [&](DevBuf<double> &dst, DevBuf<double> &src) -> int {
@@ -1626,9 +1653,16 @@ static int restore_snapshot(mi_osqp_batch *h) {
     return 0;
   };
   int rc;
-  if ((rc = cp(h->fwd_val, h->fwd_val0)) || (rc = cp(h->bwd_val, h->bwd_val0)) || (rc = cp(h->dinv, h->dinv0)) ||
-      (rc = cp(h->rho_vec, h->rho_vec0)) || (rc = cp(h->rho_inv, h->rho_inv0)) || (rc = cp(h->dscal, h->dscal0)) ||
-      (rc = cp(h->dt_val, h->dt_val0))) return rc;
+  const size_t nflags = (size_t)h->ntiles * h->BT;
+  if (getenv("MI_OSQP_RESET_COPIES")) {
+    // (experiments: everything back into the working copy, as before round 3)
+    if ((rc = cp(h->fwd_val, h->fwd_val0)) || (rc = cp(h->bwd_val, h->bwd_val0)) || (rc = cp(h->dt_val, h->dt_val0))) return rc;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->use_work.p, 1, nflags, h->stream));
+  } else {
+    // every QP's factor is its snapshot again: one word per QP instead of 1 GB of stream copies at the headline batch
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->use_work.p, 0, nflags, h->stream));
+  }
+  if ((rc = cp(h->dinv, h->dinv0)) || (rc = cp(h->rho_vec, h->rho_vec0)) || (rc = cp(h->rho_inv, h->rho_inv0)) || (rc = cp(h->dscal, h->dscal0))) return rc;
   if ((rc = reset_solve_state(h, true))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   // the host mirrors of rho follow the snapshot lazily (sync_rho_to_host, only the host update paths need them)
