@@ -264,7 +264,7 @@ def main():
         trk = tr.get("kernels", {})
         it_traffic = tr.get("bytes_per_launch") if B == HEADLINE_B else None      # the committed profile is of the 1024-QP run
         out["roofline"] = {
-            "bound": "hbm", "kernel": "iterate_kernel<%d,512>" % st["tile"], "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+            "bound": "hbm", "kernel": "iterate_kernel<%d,%d>" % (st["tile"], st["threads_per_block"]), "achieved": ach, "peak": 8000.0, "unit": "GB/s",
             "frac": ach / 8000.0, "traffic": it_traffic,
             "algorithmic_bytes_per_launch": per_min * qp_iters_per_step / launches_per_step,
             "bytes_per_qp_iteration": per_min, "avg_launch_ms": r["avg_ms"], "launches_per_step": launches_per_step,

@@ -765,7 +765,9 @@ static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int6
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     (void)hipGetLastError();
     const int64_t tiles = (B + BT - 1) / BT;
-    if (tiles <= cus || lds_bytes((int)(n + m), BT, 1024) > 80 * 1024) h->threads = 1024;
+    // (end of round 3: at ONE QP per tile the 16-wave workgroup also wins when there are more tiles than CUs - the headline
+    //  batch, 1 024 tiles of 20 KB: 34.1 -> 31.6 ms per step, full-load launches and lone stragglers alike)
+    if (tiles <= cus || BT == 1 || lds_bytes((int)(n + m), BT, 1024) > 80 * 1024) h->threads = 1024;
   }
   // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
   h->global_xs = wide || lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
