@@ -740,10 +740,7 @@ static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int6
   // ---- tile shape (needed by the schedule layout)
   // 2 QPs per tile: iterate_kernel<2> needs 112 VGPRs, so two 512-thread workgroups share a CU and
   // cover each other's barrier stalls; measured best on the 1024-QP headline batch (4 and 1 are slower)
-  // (round 3: with several small refactorisation tasks per wave - four at one QP per tile, two at two - and four 20 KB
-  //  workgroups per CU instead of two of 40 KB, one QP per tile now wins on the headline batch: 36.7 -> 35.8 ms per step,
-  //  factor_kernel 1.82 -> 1.48 ms; 1024 GOMP QPs of 7 DOF x 100 waypoints - 50 KB of vector per QP - stay at two: 4.31 vs 4.43 ms)
-  int BT = (B >= 384 && lds_bytes((int)(n + m), 1, h->threads) > 28 * 1024) ? 2 : 1;
+  int BT = B >= 384 ? 2 : 1;
   {
     const char *et = getenv("MI_OSQP_TILE");
     if (et && (atoi(et) == 1 || atoi(et) == 2 || atoi(et) == 4)) BT = atoi(et);
@@ -765,9 +762,7 @@ static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int6
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     (void)hipGetLastError();
     const int64_t tiles = (B + BT - 1) / BT;
-    // (end of round 3: at ONE QP per tile the 16-wave workgroup also wins when there are more tiles than CUs - the headline
-    //  batch, 1 024 tiles of 20 KB: 34.1 -> 31.6 ms per step, full-load launches and lone stragglers alike)
-    if (tiles <= cus || BT == 1 || lds_bytes((int)(n + m), BT, 1024) > 80 * 1024) h->threads = 1024;
+    if (tiles <= cus || lds_bytes((int)(n + m), BT, 1024) > 80 * 1024) h->threads = 1024;
   }
   // too large for LDS even at one QP per tile: the solve vector goes to a per-tile global buffer
   h->global_xs = wide || lds_bytes((int)(n + m), BT, h->threads) > lds_cap || getenv("MI_OSQP_GLOBAL_XS") != nullptr;
@@ -806,6 +801,31 @@ static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int6
   BT_out = BT; max_extra_out = max_extra;
 }
 
+// Shape and analysis of a handle.  The shape rules above were measured on trajectory QPs (sparse chain-like factors: the
+// iteration is a chain of phases, two QPs per tile share them, and with more tiles than CUs 8-wave workgroups win: 2 048 QPs of
+// 6 DOF x 50 waypoints 3.6 ms per batch solve against 5.4 at one QP per tile in 16 waves).  A pattern whose analysis comes back
+// with a DENSE TAIL is the other kind - its iteration streams the inverted Schur complement, i.e. bandwidth - and runs best at
+// ONE QP per tile in 16-wave workgroups whatever the batch size (the headline batch, end of round 3: two per tile / 8 waves 37.6
+// ms per step, one per tile / 8 waves 36.6, one per tile / 16 waves 32.0; the refactorisation packs four small tasks per wave
+// at one QP per tile against two).  So such a pattern is analysed a second time for that shape (both analyses are cached).
+static int shape_and_analysis(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi, const int64_t *Ap,
+                              const int64_t *Ai, int64_t device, int &BT, int &max_extra, std::shared_ptr<const Analysis> &out) {
+  derive_shape(h, B, n, m, device, BT, max_extra);
+  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), (int)((B + BT - 1) / BT), out);
+  if (rc) return rc;
+  const size_t lds_cap = 160 * 1024 - 1024;
+  if (out->dt.k > 0 && (BT != 1 || h->threads != 1024) && !h->global_xs && !getenv("MI_OSQP_TILE") && !getenv("MI_OSQP_THREADS") &&
+      !getenv("MI_OSQP_NO_DENSE_SHAPE") && lds_bytes((int)(n + m), 1, 1024) + (size_t)2 * 512 * sizeof(double) <= lds_cap) {
+    const int BT2 = 1, thr2 = 1024;
+    const size_t cap_rows = (lds_cap - lds_bytes(0, BT2, thr2)) / (sizeof(double) * BT2);
+    const int max_extra2 = (int)(cap_rows - (size_t)(n + m));
+    std::shared_ptr<const Analysis> an2;
+    rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, thr2 / 64, BT2, max_extra2, 512, 0, (int)B, an2);
+    if (!rc && an2->dt.k > 0) { BT = BT2; h->threads = thr2; max_extra = max_extra2; out = an2; }
+  }
+  return MI_OSQP_OK;
+}
+
 static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, const int64_t *Pp, const int64_t *Pi,
                             const double *Pv, const double *q, const int64_t *Ap, const int64_t *Ai,
                             const double *Av, const double *l, const double *u, int64_t device) {
@@ -816,10 +836,9 @@ static int batch_setup_impl(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, c
     h->st.adaptive_rho_interval = h->st.check_termination ? 4 * h->st.check_termination : 100;
   for (int64_t k = 0; k < B * m; k++) if (l[k] > u[k]) return MI_OSQP_ERR_INVALID_DATA;
   int BT = 1, max_extra = -1;
-  derive_shape(h, B, n, m, device, BT, max_extra);
   const size_t lds_cap = 160 * 1024 - 1024;
   const double ta0 = now_s();
-  int rc = cached_analysis(n, m, Pp, Pi, Ap, Ai, h->threads / 64, BT, max_extra, h->global_xs ? 0 : 512, h->mw_groups * (h->mw_threads / 64), (int)((B + BT - 1) / BT), h->anp);
+  int rc = shape_and_analysis(h, B, n, m, Pp, Pi, Ap, Ai, device, BT, max_extra, h->anp);
   const double t_analysis = now_s() - ta0;
   if (rc) return rc;
   const Analysis &an = (*h->anp);
@@ -1504,9 +1523,8 @@ int mi_osqp_prefetch_analysis(int64_t B, int64_t n, int64_t m, const int64_t *Pp
   if (B <= 0 || n <= 0 || m < 0 || !Pp || !Ap || (Pp[n] > 0 && !Pi) || (Ap[n] > 0 && !Ai)) return MI_OSQP_ERR_INVALID_DATA;
   mi_osqp_batch tmp;
   int BT = 1, max_extra = -1;
-  derive_shape(&tmp, B, n, m, device, BT, max_extra);
   std::shared_ptr<const Analysis> an;
-  return cached_analysis(n, m, Pp, Pi, Ap, Ai, tmp.threads / 64, BT, max_extra, tmp.global_xs ? 0 : 512, tmp.mw_groups * (tmp.mw_threads / 64), (int)((B + BT - 1) / BT), an);
+  return shape_and_analysis(&tmp, B, n, m, Pp, Pi, Ap, Ai, device, BT, max_extra, an);
 }
 
 void mi_osqp_batch_free(mi_osqp_batch *h) { delete h; }
