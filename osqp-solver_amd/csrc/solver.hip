@@ -785,7 +785,10 @@ static void derive_shape(mi_osqp_batch *h, int64_t B, int64_t n, int64_t m, int6
     // 64 x 256 1.06, 128 x 128 1.01, 256 x 128 0.97 (the barrier form in one workgroup: 6.5); 150 x 150 grid: 128 x 128 0.40
     // (round 3, same probe: 316 x 316 grid 128 x 128 threads 0.868, 256 x 128 0.818, 192 x 128 0.823, 128 x 256 0.824, 256 x 64 0.899;
     //  150 x 150 grid: 0.371 / 0.401 / 0.387 / 0.396 / 0.394 - the larger grid for the larger QP)
-    h->mw_groups = eg ? std::max(0, std::min(256, atoi(eg))) : (n + m >= 250000 ? 256 : 128);
+    //  and smaller grids for the mid-size ones (`scripts/groups_probe.py`, ms per 25-iteration solve: the 802-waypoint trajectory QP,
+    //  N = 43 284: 128 x 128 3.46, 64 x 128 3.25, 256 x 128 4.38; 402 waypoints, N = 21 684: 3.34 / 2.96, 32 x 128 2.93)
+    const int64_t Nrows = n + m;
+    h->mw_groups = eg ? std::max(0, std::min(256, atoi(eg))) : (Nrows >= 250000 ? 256 : Nrows >= 60000 ? 128 : Nrows >= 30000 ? 64 : 32);
     h->mw_threads = ew ? std::max(64, std::min(512, atoi(ew) / 64 * 64)) : 128;
     if (h->mw_groups * (h->mw_threads / 64) > 2048) h->mw_groups = 2048 / (h->mw_threads / 64);
     // never more workgroups than the device keeps resident at once (their waits are for each other): the schedules are
