@@ -1358,7 +1358,15 @@ static int solve_impl(mi_osqp_batch *h, double *d_x_out, hipStream_t user_stream
         if (h->mw_groups > 0) HIPCHK(hipMemsetAsync(h->mw_bar.p, 0, 4 * sizeof(uint32_t), h->stream));
         HIPCHK(launch_iterate(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
         HIPCHK(hipEventRecord(h->ev1, h->stream));
-        HIPCHK(launch_check(a, BT, ntl, h->mw_groups > 0 ? h->mw_threads : h->threads, h->lds, h->stream));
+        {
+          // The check of more 16-wave tiles than the CUs hold at once (two each) runs in 8-wave workgroups - four per CU, one round
+          // instead of two; the check schedule is walked stream by stream by however many waves there are, row by row in the
+          // same order (headline batch: 0.19 -> 0.11 ms per check, 31.8 -> 31.5 ms per step).  MI_OSQP_CHECK_THREADS forces.
+          int chk_threads = h->mw_groups > 0 ? h->mw_threads : h->threads;
+          if (h->mw_groups <= 0 && h->threads == 1024 && ntl > 2 * h->n_cus) chk_threads = 512;
+          if (getenv("MI_OSQP_CHECK_THREADS") && h->mw_groups <= 0) chk_threads = std::max(64, std::min(h->threads, atoi(getenv("MI_OSQP_CHECK_THREADS")) / 64 * 64));
+          HIPCHK(launch_check(a, BT, ntl, chk_threads, h->lds, h->stream));
+        }
         HIPCHK(hipMemcpyAsync(h->h_iscal, h->iscal.p, (size_t)ntl * IS_COUNT * BT * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
       }
