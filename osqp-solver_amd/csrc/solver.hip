@@ -1736,8 +1736,18 @@ int mi_osqp_batch_update_bounds(mi_osqp_batch *h, const double *l, const double 
   if (!cnt) return MI_OSQP_OK;
   int rc;
   if ((rc = ensure_stage(h, 2 * cnt, 0)) || (rc = ensure_pin(h, 2 * cnt))) return rc;
-  par_copy(h->pin, l, cnt); par_copy(h->pin + cnt, u, cnt);
-  HIPCHK(hipMemcpyAsync(h->stage.p, h->pin, 2 * cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    // in slices of 4 MB: the transfer of one runs while the host threads copy the next (as in device_update)
+    const size_t slice = (size_t)1 << 19;
+    for (int part = 0; part < 2; part++) {
+      const double *src = part ? u : l;
+      for (size_t o = 0; o < cnt; o += slice) {
+        const size_t len = std::min(slice, cnt - o), off = (size_t)part * cnt + o;
+        par_copy(h->pin + off, src + o, len);
+        HIPCHK(hipMemcpyAsync(h->stage.p + off, h->pin + off, len * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      }
+    }
+  }
   return update_bounds_on_device(h, h->stage.p, h->stage.p + cnt, h->stream, l, u);
 }
 
