@@ -785,3 +785,30 @@ def test_update_from_device_resident_values_equals_the_host_pointer_update_bitwi
         s.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+@pytest.mark.gpu
+def test_launch_shape_follows_the_pattern_class():
+    """solver.hip shape_and_analysis: a batch whose pattern gets a dense tail (bandwidth-bound iteration) runs at one QP per
+    tile in 16-wave workgroups whatever its size; trajectory QPs (phase-bound, no dense tail) keep two per tile from 384 QPs
+    on.  Both solve to the oracle's answer."""
+    pr = PR.random_box_qp(400)
+    s = M.BatchSolver(pr["P"], pr["Px"], pr["q"], pr["A"], pr["Ax"], pr["l"], pr["u"])
+    st = s.stats()
+    assert st["dense_tail_rows"] > 0 and st["tile"] == 1 and st["threads_per_block"] == 1024
+    info = s.solve(); x = s.primal()
+    _compare(info, x, _oracle_batch(pr, [0, 399]), [0, 399])
+    s.close()
+    pg = PR.gomp_batch(400, 3, 20)
+    s = M.BatchSolver(pg["P"], pg["Px"], None, pg["A"], pg["Ax"], pg["l"], pg["u"])
+    st = s.stats()
+    assert st["dense_tail_rows"] == 0 and st["tile"] == 2
+    s.warm_start_x(pg["warm"])
+    info = s.solve(); x = s.primal()
+    for b in (0, 399):
+        P, A = PR.qp_matrices(pg, b)
+        o = O.OracleQPSolver(P, None, A, pg["l"][b], pg["u"][b])
+        o.set_warm_start(pg["warm"][b])
+        sto, xo = o.solve()
+        assert info[b].exit_code == 0 and sto == 1 and info[b].iter == o.info().iter and np.max(np.abs(x[b] - xo)) <= TOL_X
+    s.close()
